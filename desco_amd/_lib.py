@@ -1,0 +1,73 @@
+"""ctypes binding of libdesco_hip.so (C ABI: include/desco_hip.h).
+
+There is NO fallback: if the library is missing the import of any compute entry point raises, and
+every device op raises when handed a CPU tensor.  Build with ``python -c "import __graft_entry__ as
+g; g.build()"`` or ``make -C desco_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdesco_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+i64, i32, f32 = c_int64, c_int, c_float
+vp = c_void_p
+
+# name -> (restype, argtypes); mirrors include/desco_hip.h one to one
+SIGNATURES = {
+    "desco_abi_version": (c_int, []),
+    "desco_device_count": (c_int, []),
+    "desco_last_error": (c_char_p, []),
+    "desco_partition_build": (c_int, [vp, i64, vp, vp, i32, i32, i32, POINTER(vp)]),
+    "desco_partition_sizes": (c_int, [vp, POINTER(i64), POINTER(i64), POINTER(i64), POINTER(i64)]),
+    "desco_partition_export": (c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    "desco_partition_free": (None, [vp]),
+    "desco_linear_smallk_f32": (c_int, [vp, i64, i32, vp, vp, vp, i64, i64, i32, vp]),
+    "desco_csr_gather_sum_f32": (c_int, [vp, i64, vp, vp, i64, i32, vp, vp]),
+    "desco_gemm_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
+                               vp, i64, i64, vp]),
+    "desco_segment_sum_f32": (c_int, [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
+    "desco_count_head_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, f32, i32, vp, i64, i64, i32, vp]),
+    "desco_scatter_rows_f32": (c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
+    "desco_gossip_layer0_f32": (c_int, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "desco_gossip_gather_f32": (c_int, [vp, vp, vp, i64, i32, vp, vp, vp]),
+    "desco_rowdot_add_f32": (c_int, [vp, i64, i32, vp, f32, vp, vp, i64, vp]),
+}
+
+
+class DescoLibraryError(ImportError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises DescoLibraryError when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DescoLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built. desco_amd has no CPU or "
+                "PyTorch fallback; run `make -C desco_amd/csrc` (or __graft_entry__.build()).")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise DescoLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.desco_abi_version() != ABI_VERSION:
+            raise DescoLibraryError("libdesco_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().desco_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdesco_hip {what} failed (code {rc}): {msg}")

@@ -1,0 +1,140 @@
+"""Device-resident batch containers (replace PyG ``HeteroData``/``Data`` batches on the hot path).
+
+The reference moves a collated ``HeteroData`` to the GPU per batch (Lightning) and the model reads
+``node_feature_dict`` / ``edge_index_dict`` (gnn_model.py:60-63).  Here a batch is a handful of
+flat int32/fp32 tensors in HBM in the layout the kernels consume; the PyG-style dict views are
+kept as (lazy, host-side) properties for interop and tests.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .graphs import GraphSet
+from .partition import NeighborhoodPartition
+
+
+def _i32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+class NeighborhoodBatch:
+    """B canonical neighborhoods: N_c count rows followed by B canonical rows, 4-slot CSR."""
+
+    slots = 4
+
+    def __init__(self, part: NeighborhoodPartition, device, node_feature: Optional[torch.Tensor] = None,
+                 y: Optional[torch.Tensor] = None, input_dim: int = 1):
+        self.part = part
+        self.device = torch.device(device)
+        self.num_graphs = part.num_neigh
+        self.num_count = part.num_count
+        self.num_rows = part.num_rows
+        self.count_ptr = _i32(part.count_ptr, device)
+        self.vrowptr = _i32(part.vrowptr, device)
+        self.vcol = _i32(part.vcol, device)
+        self.input_dim = input_dim if node_feature is None else node_feature.shape[1]
+        # None == all-zero features (ZeroNodeFeat, workload.py:431-440): pre_mp output is its bias
+        self.node_feature = None if node_feature is None else node_feature.to(device).float()
+        self.y = None if y is None else y.to(device)
+
+    def to(self, device):
+        if torch.device(device) == self.device:
+            return self
+        return NeighborhoodBatch(self.part, device, self.node_feature, self.y, self.input_dim)
+
+    # PyG-style views -----------------------------------------------------------------------
+    @property
+    def node_feature_dict(self) -> Dict[str, torch.Tensor]:
+        f = self.node_feature
+        if f is None:
+            f = torch.zeros((self.num_rows, self.input_dim), device=self.device)
+        return {"count": f[:self.num_count], "canonical": f[self.num_count:]}
+
+    @property
+    def edge_index_dict(self):
+        return {k: torch.from_numpy(v) for k, v in self.part.edge_index_dict().items()}
+
+    @property
+    def batch_dict(self):
+        b = np.repeat(np.arange(self.num_graphs), np.diff(self.part.count_ptr))
+        return {"count": torch.from_numpy(b), "canonical": torch.arange(self.num_graphs)}
+
+
+def tconv_split(n: int, edges) -> Tuple[np.ndarray, np.ndarray]:
+    """Directed edges (src, dst) of an undirected graph and their tride flag.
+
+    tride = NOT(endpoints share a neighbour) -- ToTconvHetero, transforms.py:201-221
+    (T = A*(A@A) + A, triangle iff T > 1)."""
+    A = np.zeros((n, n), dtype=np.int64)
+    for a, b in edges:
+        if a != b:
+            A[a, b] = A[b, a] = 1
+    T = A * (A @ A) + A
+    src, dst = np.nonzero(A)
+    return np.stack([src, dst]), T[src, dst] <= 1
+
+
+class QueryBatch:
+    """The query graphs as one single-type ("union_node") block with 2 relation slots
+    (union_triangle, union_tride) -- lightning_model.py:37-87, 291-309."""
+
+    slots = 2
+
+    def __init__(self, queries: Sequence[Tuple[int, Sequence[Tuple[int, int]]]], device,
+                 input_dim: int = 1):
+        self.queries = [(int(n), [tuple(e) for e in es]) for n, es in queries]
+        self.device = torch.device(device)
+        self.input_dim = input_dim
+        sizes = np.array([n for n, _ in self.queries], dtype=np.int64)
+        gp = np.concatenate([[0], np.cumsum(sizes)])
+        N = int(gp[-1])
+        cnt = np.zeros(2 * N, dtype=np.int64)
+        ents = []
+        for g, (n, es) in enumerate(self.queries):
+            ei, tride = tconv_split(n, es)
+            for (s, d), t in zip(ei.T.tolist(), tride.tolist()):
+                ents.append(((d + gp[g]) * 2 + int(t), s + gp[g]))
+        ents.sort()
+        for v, _ in ents:
+            cnt[v] += 1
+        self.num_graphs = len(self.queries)
+        self.num_rows = N
+        self.graph_ptr_host = gp
+        self.vrowptr = _i32(np.concatenate([[0], np.cumsum(cnt)]), device)
+        self.vcol = _i32(np.array([c for _, c in ents], dtype=np.int64), device)
+        self.graph_ptr = _i32(gp, device)
+        self.node_feature = None
+
+
+class GossipBatch:
+    """Whole target graphs for the gossip stage: symmetric CSR (ascending cols) + x [N,Q].
+
+    Equivalent of the PyG ``Data`` batch of GossipDataset (workload.py:48-150) after the
+    per-call canonicalisation of gnn_model.py:246-248, done once."""
+
+    def __init__(self, graphs: GraphSet, device, x: Optional[torch.Tensor] = None,
+                 y: Optional[torch.Tensor] = None):
+        self.graphs = graphs
+        self.device = torch.device(device)
+        self.num_graphs = graphs.num_graphs
+        self.num_nodes = graphs.num_nodes
+        if graphs.num_directed_edges >= 2 ** 31:
+            raise ValueError("gossip batch too large for int32 edge offsets; split it")
+        self.rowptr = _i32(graphs.rowptr, device)
+        self.col = _i32(graphs.col, device)
+        self.graph_ptr = _i32(graphs.graph_ptr, device)
+        self.x = None if x is None else x.to(device).float().contiguous()
+        self.y = None if y is None else y.to(device)
+
+    @property
+    def edge_index(self):
+        rp = self.graphs.rowptr
+        dst = np.repeat(np.arange(self.num_nodes, dtype=np.int64), np.diff(rp))
+        return torch.from_numpy(np.stack([self.graphs.col.astype(np.int64), dst]))
+
+    @property
+    def batch(self):
+        return torch.from_numpy(self.graphs.node_graph_ids())

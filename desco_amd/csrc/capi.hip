@@ -1,0 +1,24 @@
+// Library-level entry points of the C ABI (include/desco_hip.h).
+#include "common_device.hpp"
+
+namespace desco {
+std::string& last_error_ref() {
+  static thread_local std::string s;
+  return s;
+}
+int fail(int code, const char* msg) {
+  last_error_ref() = msg ? msg : "";
+  return code;
+}
+}  // namespace desco
+
+extern "C" int desco_abi_version(void) { return DESCO_ABI_VERSION; }
+
+extern "C" int desco_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return -(int)e;
+  return n;
+}
+
+extern "C" const char* desco_last_error(void) { return desco::last_error_ref().c_str(); }

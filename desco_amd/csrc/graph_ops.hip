@@ -1,0 +1,258 @@
+// HBM-bound row kernels of the DeSCo hot path (gfx950): CSR gather-aggregate, segmented pooling,
+// count head, row scatter, small-K input projection.  One 64-lane wavefront per destination row;
+// feature rows are 64 fp32 = 256 B, read and written as whole coalesced rows.
+#include "common_device.hpp"
+
+namespace desco {
+
+template <int S>
+struct VecOf;
+template <>
+struct VecOf<1> {
+  using type = float;
+};
+template <>
+struct VecOf<2> {
+  using type = float2;
+};
+template <>
+struct VecOf<4> {
+  using type = float4;
+};
+
+__device__ __forceinline__ void vadd(float& a, const float b) { a += b; }
+__device__ __forceinline__ void vadd(float2& a, const float2 b) {
+  a.x += b.x;
+  a.y += b.y;
+}
+__device__ __forceinline__ void vadd(float4& a, const float4 b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+__device__ __forceinline__ void vzero(float& a) { a = 0.f; }
+__device__ __forceinline__ void vzero(float2& a) { a = make_float2(0.f, 0.f); }
+__device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// SAGEConv message + aggregate (gnn_model.py:392-394, 402-404) for S relation slots per row.
+// Wave = one destination row; lane group of 64/S lanes = one slot; each lane carries S floats.
+template <int S>
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __restrict__ x,
+                                                             int64_t ldx,
+                                                             const int32_t* __restrict__ vrowptr,
+                                                             const int32_t* __restrict__ vcol,
+                                                             int64_t num_rows,
+                                                             float* __restrict__ out) {
+  using V = typename VecOf<S>::type;
+  constexpr int LG = 64 / S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= num_rows) return;
+  const int group = lane / LG, foff = (lane % LG) * S;
+  const int64_t v = row * S + group;
+  const int e0 = vrowptr[v], e1 = vrowptr[v + 1];
+  V acc0, acc1;
+  vzero(acc0);
+  vzero(acc1);
+  int e = e0;
+  for (; e + 1 < e1; e += 2) {
+    const int64_t j0 = vcol[e], j1 = vcol[e + 1];
+    const V a = *reinterpret_cast<const V*>(x + j0 * ldx + foff);
+    const V b = *reinterpret_cast<const V*>(x + j1 * ldx + foff);
+    vadd(acc0, a);
+    vadd(acc1, b);
+  }
+  if (e < e1) {
+    const int64_t j0 = vcol[e];
+    vadd(acc0, *reinterpret_cast<const V*>(x + j0 * ldx + foff));
+  }
+  vadd(acc0, acc1);
+  *reinterpret_cast<V*>(out + v * 64 + foff) = acc0;
+}
+
+// global_add_pool over contiguous segments (+ one extra row per segment, added last to mirror the
+// reference's cat([count, canonical]) order, gnn_model.py:88-89, 107).
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          int ncols, int nchunks,
+                                                          const int32_t* __restrict__ seg_ptr,
+                                                          int64_t num_seg,
+                                                          const float* __restrict__ extra,
+                                                          int64_t ld_extra, float* __restrict__ out,
+                                                          int64_t ldo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t b = idx / nchunks;
+  if (b >= num_seg) return;
+  const int c = (int)(idx % nchunks) * 64 + lane;
+  if (c >= ncols) return;
+  const int r0 = seg_ptr[b], r1 = seg_ptr[b + 1];
+  float acc0 = 0.f, acc1 = 0.f;
+  int r = r0;
+  for (; r + 1 < r1; r += 2) {
+    acc0 += x[(int64_t)r * ldx + c];
+    acc1 += x[(int64_t)(r + 1) * ldx + c];
+  }
+  if (r < r1) acc0 += x[(int64_t)r * ldx + c];
+  acc0 += acc1;
+  if (extra) acc0 += extra[b * ld_extra + c];
+  out[b * ldo + c] = acc0;
+}
+
+// count head, separable form of lightning_model.py:176-193, 210-221
+__global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
+                                                         const float* __restrict__ qh, int64_t ldq,
+                                                         int hid, const float* __restrict__ w2,
+                                                         float b2, float slope, int exp2m1,
+                                                         float* __restrict__ out, int64_t ldo,
+                                                         int64_t num_b, int num_q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= num_b) return;
+  for (int q = 0; q < num_q; ++q) {
+    float acc = 0.f;
+    for (int c = lane; c < hid; c += 64) {
+      float v = t[b * ldt + c] + qh[(int64_t)q * ldq + c];
+      v = v > 0.f ? v : v * slope;
+      acc += v * w2[c];
+    }
+    acc = wave_sum(acc) + b2;
+    if (lane == 0) out[b * ldo + q] = exp2m1 ? exp2f(acc) - 1.f : acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src,
+                                                           int64_t lds,
+                                                           const int32_t* __restrict__ rows,
+                                                           int64_t num_src, int ncols,
+                                                           float* __restrict__ dst, int64_t ldd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_src * ncols) return;
+  const int64_t b = i / ncols;
+  const int c = (int)(i % ncols);
+  dst[(int64_t)rows[b] * ldd + c] = src[b * lds + c];
+}
+
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ feat,
+                                                            int64_t ldf, int k,
+                                                            const float* __restrict__ wt,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ out, int64_t ldo,
+                                                            int64_t m, int n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n) return;
+  const int64_t r = i / n;
+  const int c = (int)(i % n);
+  float acc = bias ? bias[c] : 0.f;
+  for (int j = 0; j < k; ++j) acc = fmaf(feat[r * ldf + j], wt[(int64_t)j * n + c], acc);
+  out[r * ldo + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void rowdot_add_kernel(const float* __restrict__ y, int64_t ldy,
+                                                         int ncols, const float* __restrict__ w,
+                                                         float b, const float* __restrict__ add,
+                                                         float* __restrict__ out, int64_t num_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= num_rows) return;
+  float acc = 0.f;
+  for (int c = lane; c < ncols; c += 64) acc += y[r * ldy + c] * w[c];
+  acc = wave_sum(acc);
+  if (lane == 0) out[r] = (add ? add[r] : 0.f) + acc + b;
+}
+
+inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= INT32_MAX; }
+
+}  // namespace desco
+
+using namespace desco;
+
+extern "C" int desco_csr_gather_sum_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                        const int32_t* vcol, int64_t num_rows, int slots,
+                                        float* out, desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  if (!x || !vrowptr || !out || num_rows < 0 || ldx % 4 || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || !(slots == 1 || slots == 2 || slots == 4))
+    return fail(DESCO_EINVAL, "desco_csr_gather_sum_f32: bad argument");
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_csr_gather_sum_f32: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (slots == 4)
+    hipLaunchKernelGGL(csr_gather_sum_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+                       vrowptr, vcol, num_rows, out);
+  else if (slots == 2)
+    hipLaunchKernelGGL(csr_gather_sum_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+                       vrowptr, vcol, num_rows, out);
+  else
+    hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+                       vrowptr, vcol, num_rows, out);
+  return launch_status("desco_csr_gather_sum_f32");
+}
+
+extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,
+                                     const int32_t* seg_ptr, int64_t num_seg, const float* extra,
+                                     int64_t ld_extra, float* out, int64_t ldo,
+                                     desco_stream_t stream) {
+  if (num_seg == 0) return 0;
+  if (!seg_ptr || !out || num_seg < 0 || ncols <= 0)
+    return fail(DESCO_EINVAL, "desco_segment_sum_f32: bad argument");
+  const int nch = (ncols + 63) / 64;
+  const int64_t blocks = (num_seg * nch + 3) / 4;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_segment_sum_f32: too many segments");
+  hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, ncols, nch, seg_ptr, num_seg, extra, ld_extra, out, ldo);
+  return launch_status("desco_segment_sum_f32");
+}
+
+extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq,
+                                    int hid, const float* w2, float b2, float slope,
+                                    int exp2_minus_1, float* out, int64_t ldo, int64_t num_b,
+                                    int num_q, desco_stream_t stream) {
+  if (num_b == 0 || num_q == 0) return 0;
+  if (!t || !qh || !w2 || !out || num_b < 0 || num_q < 0 || hid <= 0 || hid % 64)
+    return fail(DESCO_EINVAL, "desco_count_head_f32: bad argument");
+  const int64_t blocks = (num_b + 3) / 4;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_count_head_f32: too many rows");
+  hipLaunchKernelGGL(count_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo, num_b, num_q);
+  return launch_status("desco_count_head_f32");
+}
+
+extern "C" int desco_scatter_rows_f32(const float* src, int64_t lds, const int32_t* rows,
+                                      int64_t num_src, int ncols, float* dst, int64_t ldd,
+                                      desco_stream_t stream) {
+  if (num_src == 0 || ncols == 0) return 0;
+  if (!src || !rows || !dst || num_src < 0 || ncols < 0)
+    return fail(DESCO_EINVAL, "desco_scatter_rows_f32: bad argument");
+  const int64_t blocks = (num_src * ncols + 255) / 256;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_scatter_rows_f32: too many elements");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, lds, rows, num_src, ncols, dst, ldd);
+  return launch_status("desco_scatter_rows_f32");
+}
+
+extern "C" int desco_linear_smallk_f32(const float* feat, int64_t ldf, int k, const float* wt,
+                                       const float* bias, float* out, int64_t ldo, int64_t m,
+                                       int n, desco_stream_t stream) {
+  if (m == 0 || n == 0) return 0;
+  if (!feat || !wt || !out || m < 0 || n < 0 || k < 0)
+    return fail(DESCO_EINVAL, "desco_linear_smallk_f32: bad argument");
+  const int64_t blocks = (m * n + 255) / 256;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_linear_smallk_f32: too many elements");
+  hipLaunchKernelGGL(linear_smallk_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, feat, ldf, k, wt, bias, out, ldo, m, n);
+  return launch_status("desco_linear_smallk_f32");
+}
+
+extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, const float* w, float b,
+                                    const float* add, float* out, int64_t num_rows,
+                                    desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  if (!y || !w || !out || num_rows < 0 || ncols <= 0)
+    return fail(DESCO_EINVAL, "desco_rowdot_add_f32: bad argument");
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_rowdot_add_f32: too many rows");
+  hipLaunchKernelGGL(rowdot_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     y, ldy, ncols, w, b, add, out, num_rows);
+  return launch_status("desco_rowdot_add_f32");
+}

@@ -1,0 +1,354 @@
+// Host-side canonical-partition builder (C ABI: desco_partition_*), see include/desco_hip.h.
+//
+// One pass over every (graph, node) replaces, for a whole dataset at once, the reference's
+//   NeighborhoodDataset.process     workload.py:243-294   (driver loop, 0-edge skip :252-256)
+//   get_neigh_hetero / k_neigh      data.py:375-396 / 329-338
+//   NetworkxToHetero                transforms.py:319-412 (both directions of every edge)
+//   ToTconvHetero                   transforms.py:180-255 (edge is "triangle" iff its endpoints
+//                                   share a neighbour inside the neighborhood)
+//   PyG hetero collate              [EXT]                 (row offsets)
+// and emits the flat destination-major 4-slot CSR the HIP kernels consume.  Written from the
+// algorithm's definition (BFS ball -> id filter -> component -> sorted-adjacency intersection);
+// parallel over graphs with OpenMP, deterministic output.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../../include/desco_hip.h"
+#include "common_host.hpp"
+
+namespace {
+
+struct GraphOut {
+  // per kept neighborhood
+  std::vector<int32_t> canon;      // canonical node (graph-local id)
+  std::vector<int32_t> nsize;      // nodes in the neighborhood (count nodes + 1)
+  std::vector<int64_t> node_off;   // offset into nodes / rowcnt(4x)
+  std::vector<int64_t> col_off;    // offset into cols
+  std::vector<int32_t> nodes;      // graph-local ids, ascending, canonical last
+  std::vector<int32_t> rowcnt;     // 4 per node: edges per relation slot
+  std::vector<int32_t> cols;       // source LOCAL index (position in nodes), per dst, per slot
+  std::vector<uint8_t> indicator;  // per node of the graph
+};
+
+struct Scratch {
+  std::vector<int32_t> mark_ball, mark_keep, mark_comp, lidx;
+  std::vector<int32_t> frontier, next, ball, comp;
+  std::vector<int32_t> slot_tmp[4];
+  int32_t stamp = 0;
+  void ensure(size_t n) {
+    if (mark_ball.size() < n) {
+      mark_ball.assign(n, 0);
+      mark_keep.assign(n, 0);
+      mark_comp.assign(n, 0);
+      lidx.assign(n, 0);
+      stamp = 0;
+    }
+  }
+};
+
+// true iff a and b have a common neighbour c with mark_comp[c] == stamp (adjacency rows sorted)
+inline bool share_neighbor(const int32_t* ra, int da, const int32_t* rb, int db,
+                           const int32_t* mark_comp, int32_t stamp, int64_t base) {
+  int i = 0, j = 0;
+  while (i < da && j < db) {
+    int32_t x = ra[i], y = rb[j];
+    if (x == y) {
+      if (mark_comp[x - base] == stamp) return true;
+      ++i;
+      ++j;
+    } else if (x < y) {
+      ++i;
+    } else {
+      ++j;
+    }
+  }
+  return false;
+}
+
+void process_graph(int64_t base, int64_t n, const int64_t* rowptr, const int32_t* col, int depth,
+                   Scratch& s, GraphOut& o) {
+  s.ensure((size_t)n);
+  o.indicator.assign((size_t)n, 0);
+  for (int64_t v = 0; v < n; ++v) {
+    if (s.stamp == INT32_MAX) {  // never in practice; keep stamps valid
+      std::fill(s.mark_ball.begin(), s.mark_ball.end(), 0);
+      std::fill(s.mark_keep.begin(), s.mark_keep.end(), 0);
+      std::fill(s.mark_comp.begin(), s.mark_comp.end(), 0);
+      s.stamp = 0;
+    }
+    const int32_t st = ++s.stamp;
+    // (1) BFS ball of radius `depth` in the FULL graph (data.py:329-338)
+    s.ball.clear();
+    s.frontier.clear();
+    s.frontier.push_back((int32_t)v);
+    s.mark_ball[v] = st;
+    s.ball.push_back((int32_t)v);
+    for (int l = 0; l < depth && !s.frontier.empty(); ++l) {
+      s.next.clear();
+      for (int32_t u : s.frontier) {
+        const int64_t gu = base + u;
+        for (int64_t e = rowptr[gu]; e < rowptr[gu + 1]; ++e) {
+          const int32_t w = (int32_t)(col[e] - base);
+          if (s.mark_ball[w] != st) {
+            s.mark_ball[w] = st;
+            s.next.push_back(w);
+            s.ball.push_back(w);
+          }
+        }
+      }
+      s.frontier.swap(s.next);
+    }
+    // (2) keep ids <= v, applied AFTER the BFS (data.py:385)
+    for (int32_t u : s.ball)
+      if (u <= v) s.mark_keep[u] = st;
+    // (3) connected component of v inside the induced subgraph (data.py:387-390)
+    s.comp.clear();
+    s.comp.push_back((int32_t)v);
+    s.mark_comp[v] = st;
+    for (size_t h = 0; h < s.comp.size(); ++h) {
+      const int64_t gu = base + s.comp[h];
+      for (int64_t e = rowptr[gu]; e < rowptr[gu + 1]; ++e) {
+        const int32_t w = (int32_t)(col[e] - base);
+        if (w > v) break;  // rows sorted ascending
+        if (s.mark_keep[w] == st && s.mark_comp[w] != st) {
+          s.mark_comp[w] = st;
+          s.comp.push_back(w);
+        }
+      }
+    }
+    if (s.comp.size() == 1) continue;  // 0 edges -> skipped, indicator False (workload.py:252-256)
+    o.indicator[v] = 1;
+    std::sort(s.comp.begin(), s.comp.end());  // ascending id; canonical (= max) is last
+    const int32_t nn = (int32_t)s.comp.size();
+    for (int32_t i = 0; i < nn; ++i) s.lidx[s.comp[i]] = i;
+    o.canon.push_back((int32_t)v);
+    o.nsize.push_back(nn);
+    o.node_off.push_back((int64_t)o.nodes.size());
+    o.col_off.push_back((int64_t)o.cols.size());
+    o.nodes.insert(o.nodes.end(), s.comp.begin(), s.comp.end());
+    // (4) induced directed edges src=b -> dst=a, split by (src is canonical, triangle/tride)
+    for (int32_t i = 0; i < nn; ++i) {
+      const int32_t a = s.comp[i];
+      const int64_t ga = base + a;
+      const int32_t* ra = col + rowptr[ga];
+      const int da = (int)(rowptr[ga + 1] - rowptr[ga]);
+      for (auto& t : s.slot_tmp) t.clear();
+      for (int k = 0; k < da; ++k) {
+        const int32_t b = (int32_t)(ra[k] - base);
+        if (b > v) break;
+        if (s.mark_comp[b] != st) continue;
+        const int64_t gb = base + b;
+        const bool tri = share_neighbor(ra, da, col + rowptr[gb], (int)(rowptr[gb + 1] - rowptr[gb]),
+                                        s.mark_comp.data(), st, base);
+        const int slot = 2 * (b == (int32_t)v ? 1 : 0) + (tri ? 0 : 1);
+        s.slot_tmp[slot].push_back(s.lidx[b]);
+      }
+      for (int sl = 0; sl < 4; ++sl) {
+        o.rowcnt.push_back((int32_t)s.slot_tmp[sl].size());
+        o.cols.insert(o.cols.end(), s.slot_tmp[sl].begin(), s.slot_tmp[sl].end());
+      }
+    }
+  }
+}
+
+}  // namespace
+
+struct desco_partition {
+  int64_t B = 0, Nc = 0, E = 0, Ntot = 0;
+  std::vector<int64_t> neigh_index;
+  std::vector<uint8_t> indicator;
+  std::vector<int32_t> count_ptr, count_orig, vrowptr, vcol;
+};
+
+extern "C" int desco_partition_build(const int64_t* graph_ptr, int64_t num_graphs,
+                                     const int64_t* rowptr, const int32_t* col, int depth,
+                                     int quirk_batch, int num_threads, desco_partition** out) {
+  if (!graph_ptr || !rowptr || (!col && rowptr[graph_ptr[num_graphs]] > 0) || !out || depth < 0 ||
+      num_graphs < 0 || quirk_batch < 0)
+    return desco::fail(DESCO_EINVAL, "desco_partition_build: bad argument");
+  try {
+    std::vector<GraphOut> gout((size_t)num_graphs);
+#ifdef _OPENMP
+    const int nt = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+    const int nt = 1;
+    (void)num_threads;
+#endif
+    int err = 0;
+#pragma omp parallel num_threads(nt)
+    {
+      Scratch s;
+#pragma omp for schedule(dynamic, 4)
+      for (int64_t g = 0; g < num_graphs; ++g) {
+        const int64_t base = graph_ptr[g], n = graph_ptr[g + 1] - base;
+        if (n < 0) {
+          err = 1;
+          continue;
+        }
+        process_graph(base, n, rowptr, col, depth, s, gout[(size_t)g]);
+      }
+    }
+    if (err) return desco::fail(DESCO_EINVAL, "desco_partition_build: graph_ptr not monotone");
+
+    auto* p = new desco_partition();
+    p->Ntot = graph_ptr[num_graphs];
+    // neighborhood offsets
+    std::vector<int64_t> gb((size_t)num_graphs + 1, 0);
+    for (int64_t g = 0; g < num_graphs; ++g) gb[g + 1] = gb[g] + (int64_t)gout[g].canon.size();
+    p->B = gb[num_graphs];
+    const int64_t B = p->B;
+    p->neigh_index.resize((size_t)B * 2);
+    p->indicator.resize((size_t)p->Ntot);
+    p->count_ptr.assign((size_t)B + 1, 0);
+    std::vector<GraphOut*> owner((size_t)B);
+    std::vector<int32_t> local((size_t)B);
+    for (int64_t g = 0; g < num_graphs; ++g) {
+      GraphOut& o = gout[g];
+      std::memcpy(p->indicator.data() + graph_ptr[g], o.indicator.data(), o.indicator.size());
+      for (size_t k = 0; k < o.canon.size(); ++k) {
+        const int64_t b = gb[g] + (int64_t)k;
+        p->neigh_index[2 * b] = g;
+        p->neigh_index[2 * b + 1] = o.canon[k];
+        p->count_ptr[b + 1] = o.nsize[k] - 1;
+        owner[b] = &o;
+        local[b] = (int32_t)k;
+      }
+    }
+    for (int64_t b = 0; b < B; ++b) {
+      const int64_t v = (int64_t)p->count_ptr[b] + p->count_ptr[b + 1];
+      if (v > INT32_MAX) {
+        delete p;
+        return desco::fail(DESCO_EINVAL, "desco_partition_build: more than 2^31 count rows");
+      }
+      p->count_ptr[b + 1] = (int32_t)v;
+    }
+    p->Nc = p->count_ptr[B];
+    const int64_t Nc = p->Nc, N = Nc + B;
+    if (4 * N + 1 > INT32_MAX) {
+      delete p;
+      return desco::fail(DESCO_EINVAL, "desco_partition_build: too many rows for int32 indices");
+    }
+
+    // PyG remove_self_loops quirk on the bipartite types (gnn_model.py:389-390): inside a reference
+    // batch, the edge pair between count node #gl (batch-global) and canonical node #gl is dropped.
+    if (quirk_batch > 0) {
+      for (int64_t b = 0; b < B; ++b) {
+        const int64_t first = (b / quirk_batch) * quirk_batch, gl = b - first;
+        const int64_t c = (int64_t)p->count_ptr[first] + gl;
+        if (c < p->count_ptr[b] || c >= p->count_ptr[b + 1]) continue;
+        GraphOut& o = *owner[b];
+        const int32_t k = local[b], nn = o.nsize[k], ls = (int32_t)(c - p->count_ptr[b]);
+        int32_t* rc = o.rowcnt.data() + 4 * o.node_off[k];
+        int32_t* cl = o.cols.data() + o.col_off[k];
+        int64_t pos = 0;
+        for (int32_t i = 0; i < nn; ++i) {
+          for (int sl = 0; sl < 4; ++sl) {
+            const int32_t cnt = rc[4 * i + sl];
+            for (int32_t e = 0; e < cnt; ++e) {
+              const bool drop = (i == ls && sl >= 2) || (i == nn - 1 && cl[pos + e] == ls);
+              if (drop) cl[pos + e] = -1;
+            }
+            pos += cnt;
+          }
+        }
+      }
+    }
+
+    // per-row slot counts -> vrowptr
+    p->vrowptr.assign((size_t)(4 * N + 1), 0);
+    p->count_orig.resize((size_t)Nc);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t b = 0; b < B; ++b) {
+      GraphOut& o = *owner[b];
+      const int32_t k = local[b], nn = o.nsize[k];
+      const int32_t* rc = o.rowcnt.data() + 4 * o.node_off[k];
+      const int32_t* cl = o.cols.data() + o.col_off[k];
+      const int32_t* nd = o.nodes.data() + o.node_off[k];
+      const int64_t gbase = graph_ptr[p->neigh_index[2 * b]];
+      int64_t pos = 0;
+      for (int32_t i = 0; i < nn; ++i) {
+        const int64_t row = (i < nn - 1) ? (int64_t)p->count_ptr[b] + i : Nc + b;
+        if (i < nn - 1) p->count_orig[row] = (int32_t)(gbase + nd[i]);
+        for (int sl = 0; sl < 4; ++sl) {
+          const int32_t cnt = rc[4 * i + sl];
+          int32_t kept = 0;
+          for (int32_t e = 0; e < cnt; ++e) kept += cl[pos + e] >= 0;
+          p->vrowptr[4 * row + sl + 1] = kept;
+          pos += cnt;
+        }
+      }
+    }
+    int64_t acc = 0;
+    for (int64_t i = 0; i < 4 * N; ++i) {
+      acc += p->vrowptr[i + 1];
+      if (acc > INT32_MAX) {
+        delete p;
+        return desco::fail(DESCO_EINVAL, "desco_partition_build: more than 2^31 edges");
+      }
+      p->vrowptr[i + 1] = (int32_t)acc;
+    }
+    p->E = acc;
+    p->vcol.resize((size_t)p->E);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t b = 0; b < B; ++b) {
+      GraphOut& o = *owner[b];
+      const int32_t k = local[b], nn = o.nsize[k];
+      const int32_t* rc = o.rowcnt.data() + 4 * o.node_off[k];
+      const int32_t* cl = o.cols.data() + o.col_off[k];
+      int64_t pos = 0;
+      for (int32_t i = 0; i < nn; ++i) {
+        const int64_t row = (i < nn - 1) ? (int64_t)p->count_ptr[b] + i : Nc + b;
+        for (int sl = 0; sl < 4; ++sl) {
+          const int32_t cnt = rc[4 * i + sl];
+          int64_t w = p->vrowptr[4 * row + sl];
+          for (int32_t e = 0; e < cnt; ++e) {
+            const int32_t ls = cl[pos + e];
+            if (ls < 0) continue;
+            p->vcol[w++] = (ls < nn - 1) ? p->count_ptr[b] + ls : (int32_t)(Nc + b);
+          }
+          pos += cnt;
+        }
+      }
+    }
+    *out = p;
+    return 0;
+  } catch (const std::bad_alloc&) {
+    return desco::fail(DESCO_ENOMEM, "desco_partition_build: out of memory");
+  }
+}
+
+extern "C" int desco_partition_sizes(const desco_partition* p, int64_t* num_neigh,
+                                     int64_t* num_count, int64_t* num_edges, int64_t* num_nodes) {
+  if (!p) return desco::fail(DESCO_EINVAL, "desco_partition_sizes: null handle");
+  if (num_neigh) *num_neigh = p->B;
+  if (num_count) *num_count = p->Nc;
+  if (num_edges) *num_edges = p->E;
+  if (num_nodes) *num_nodes = p->Ntot;
+  return 0;
+}
+
+extern "C" int desco_partition_export(const desco_partition* p, int64_t* neigh_index,
+                                      uint8_t* indicator, int32_t* count_ptr, int32_t* count_orig,
+                                      int32_t* vrowptr, int32_t* vcol) {
+  if (!p) return desco::fail(DESCO_EINVAL, "desco_partition_export: null handle");
+  auto cp = [](void* dst, const void* src, size_t bytes) {
+    if (dst && bytes) std::memcpy(dst, src, bytes);
+  };
+  cp(neigh_index, p->neigh_index.data(), p->neigh_index.size() * sizeof(int64_t));
+  cp(indicator, p->indicator.data(), p->indicator.size());
+  cp(count_ptr, p->count_ptr.data(), p->count_ptr.size() * sizeof(int32_t));
+  cp(count_orig, p->count_orig.data(), p->count_orig.size() * sizeof(int32_t));
+  cp(vrowptr, p->vrowptr.data(), p->vrowptr.size() * sizeof(int32_t));
+  cp(vcol, p->vcol.data(), p->vcol.size() * sizeof(int32_t));
+  return 0;
+}
+
+extern "C" void desco_partition_free(desco_partition* p) { delete p; }

@@ -1,0 +1,229 @@
+"""NeighborhoodCountingModel / GossipCountingModel with the reference's API surface
+(subgraph_counting/lightning_model.py:37-649) and no Lightning dependency.
+
+``graph_to_count`` / ``train_forward`` run entirely through the HIP kernels (desco_amd.gnn_model);
+the 29-iteration Python loops of the reference (lightning_model.py:210-219, 615-625) are replaced
+by one batched head kernel / a query axis in the gossip kernels.
+"""
+from __future__ import annotations
+
+import argparse
+import warnings
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import networkx as nx
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .batch import GossipBatch, NeighborhoodBatch, QueryBatch
+from .data import graph_atlas_plus
+from .gnn_model import (BaseGNN, H, QUERY_EDGE_TYPES_TCONV, QUERY_EDGE_TYPES_UNION,
+                        QUERY_NODE_TYPES, TARGET_EDGE_TYPES_TCONV, TARGET_EDGE_TYPES_UNION,
+                        TARGET_NODE_TYPES)
+
+
+def gen_queries(query_ids: List[int], queries=None, transform=None, node_feat_len: int = 1,
+                hetero=True, device="cpu"):
+    """Query graphs by atlas id (lightning_model.py:37-87).  Returns ([(n, edges)], [nx.Graph]);
+    the flat pairs replace the list of PyG graphs (``transform`` is applied by QueryBatch)."""
+    if node_feat_len != 1:
+        raise NotImplementedError("--use_node_feature query expansion is outside the hot path")
+    queries_nx = [graph_atlas_plus(q) for q in query_ids] if queries is None else list(queries)
+    flat = []
+    for g in queries_nx:
+        nodes = list(g.nodes)
+        idx = {v: i for i, v in enumerate(nodes)}
+        flat.append((len(nodes), sorted((min(idx[a], idx[b]), max(idx[a], idx[b]))
+                                        for a, b in g.edges())))
+    return flat, queries_nx
+
+
+class _LightningLike(nn.Module):
+    """The slice of pl.LightningModule main.py relies on: device, log, hparams, ckpt round trip."""
+
+    def __init__(self):
+        super().__init__()
+        self.logged: Dict[str, float] = {}
+        self.hparams_dict: Dict[str, Any] = {}
+
+    @property
+    def device(self):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return torch.device("cpu")
+
+    def log(self, name, value, **kwargs):
+        self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
+
+    def save_hyperparameters(self, **hp):
+        self.hparams_dict = hp
+
+    def checkpoint(self) -> Dict[str, Any]:
+        """A Lightning-shaped checkpoint dict (keys read by load_from_checkpoint)."""
+        return {"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                "hyper_parameters": dict(self.hparams_dict)}
+
+    def save_checkpoint(self, path: str):
+        torch.save(self.checkpoint(), path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        hp = dict(ckpt["hyper_parameters"])
+        hp.update(kwargs)
+        args = hp.pop("args")
+        model = cls(hp.pop("input_dim"), hp.pop("hidden_dim"), args, **hp)
+        model.on_load_checkpoint(ckpt)
+        model.load_state_dict(ckpt["state_dict"])
+        return model
+
+    def on_load_checkpoint(self, checkpoint):
+        return None
+
+
+class NeighborhoodCountingModel(_LightningLike):
+    def __init__(self, input_dim, hidden_dim, args, **kwargs):
+        super().__init__()
+        self.emb_with_query = False
+        self.query_loader = None          # a QueryBatch (the reference keeps a DataLoader here)
+        self.hidden_dim, self.input_dim = hidden_dim, input_dim
+        self.kwargs, self.args = kwargs, args
+        for k, v in vars(args).items():   # lightning_model.py:113-114
+            setattr(self, k, v)
+        self.save_hyperparameters(input_dim=input_dim, hidden_dim=hidden_dim, args=args, **kwargs)
+        self.emb_model = BaseGNN(input_dim, hidden_dim, hidden_dim, args,
+                                 emb_channels=hidden_dim, **kwargs)
+        self.emb_model_query = BaseGNN(input_dim, hidden_dim, hidden_dim, args,
+                                       emb_channels=hidden_dim, **kwargs)
+        self.count_model = nn.Sequential(nn.Linear(2 * hidden_dim, 4 * args.hidden_dim),
+                                         nn.LeakyReLU(), nn.Linear(4 * args.hidden_dim, 1))
+        self._qemb_cache = None
+
+    # ---- hetero conversion (lightning_model.py:325-421) -----------------------------------------
+    def to_hetero_old(self, tconv_target=False, tconv_query=False):
+        self.emb_model.gnn_core.to_hetero(
+            TARGET_NODE_TYPES, TARGET_EDGE_TYPES_TCONV if tconv_target else TARGET_EDGE_TYPES_UNION)
+        self.emb_model_query.gnn_core.to_hetero(
+            QUERY_NODE_TYPES, QUERY_EDGE_TYPES_TCONV if tconv_query else QUERY_EDGE_TYPES_UNION)
+        self.tconv_target, self.tconv_query = tconv_target, tconv_query
+        return self
+
+    def to_hetero(self, order: int = 3, SHMP_target=False, SHMP_query=False):
+        if order != 3:
+            raise NotImplementedError("order-4 (union_1..11) SHMP is outside the hot path")
+        return self.to_hetero_old(tconv_target=SHMP_target, tconv_query=SHMP_query)
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:   # :508-532
+        a = checkpoint["hyper_parameters"]["args"]
+        use_canonical = getattr(a, "use_canonical", True)
+        if a.use_hetero and use_canonical:
+            self.to_hetero_old(tconv_target=a.use_tconv, tconv_query=a.use_tconv)
+        elif a.use_hetero:
+            raise NotImplementedError("to_hetero_wo_canonical (ablation) is outside the hot path")
+
+    # ---- queries ----------------------------------------------------------------------------------
+    def set_queries(self, query_ids, queries=None, transform=None, hetero=True, device=None):
+        flat, queries_nx = gen_queries(query_ids, queries, transform=transform,
+                                       node_feat_len=self.input_dim, hetero=hetero)
+        min_len_neighbor = max(nx.diameter(q) for q in queries_nx)
+        if self.depth < min_len_neighbor:                                  # :302-308
+            warnings.warn("neighborhood diameter {:d} is too small for the queries, the minimum is "
+                          "{:d}".format(self.depth, min_len_neighbor))
+        self.queries_flat = flat
+        self.query_loader = QueryBatch(flat, device or self.device, self.input_dim)
+        self._qemb_cache = None
+
+    def _queries(self) -> QueryBatch:
+        if self.query_loader is None:
+            raise RuntimeError("call set_queries() first (main.py:231-233)")
+        if self.query_loader.device != self.device:
+            self.query_loader = QueryBatch(self.queries_flat, self.device, self.input_dim)
+        return self.query_loader
+
+    def get_query_emb(self) -> torch.Tensor:                                # :311-316
+        """[Q, 64] query embeddings.  The reference recomputes them on every batch (:204-207);
+        they only depend on the weights, so they are cached per weight version."""
+        qb = self._queries()
+        ver = self.emb_model_query._param_version()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.emb_model_query.parameters()):
+            return self.emb_model_query(qb)
+        if self._qemb_cache is None or self._qemb_cache[0] != (ver, id(qb)):
+            with torch.no_grad():
+                self._qemb_cache = ((ver, id(qb)), self.emb_model_query(qb))
+        return self._qemb_cache[1]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _logits(self, batch: NeighborhoodBatch, exp2: bool) -> torch.Tensor:
+        emb_q = self.get_query_emb()
+        emb_t = self.emb_model(batch)
+        W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
+        T = ops.gemm(emb_t, W1[:, :H].t().contiguous())                      # target half
+        Qh = ops.gemm(emb_q, W1[:, H:].t().contiguous(), b1)                 # query half + bias
+        w2, b2 = self.count_model[2].weight[0], float(self.count_model[2].bias[0])
+        return ops.count_head(T, Qh, w2, b2, self.count_model[1].negative_slope, exp2)
+
+    def graph_to_count(self, batch) -> torch.Tensor:                         # :198-222
+        with torch.no_grad():
+            return self._logits(batch.to(self.device), exp2=True)
+
+    def predict_step(self, batch, batch_idx) -> torch.Tensor:                # :195-196
+        return self.graph_to_count(batch)
+
+    def graph_to_embed(self, batch) -> torch.Tensor:                         # :224-226
+        with torch.no_grad():
+            return self.emb_model(batch.to(self.device))
+
+    def criterion(self, count, truth):                                       # :285-289
+        return F.smooth_l1_loss(count, truth)
+
+    def configure_optimizers(self):                                          # :160-173
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,
+                                                           patience=20, min_lr=1e-5)
+        return {"optimizer": optimizer, "lr_scheduler": sched,
+                "monitor": "neighborhood_counting_val_loss"}
+
+
+class GossipCountingModel(_LightningLike):
+    def __init__(self, input_dim, hidden_dim, args, **kwargs):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        kwargs["baseline"] = "gossip"                                       # :540
+        for k, v in vars(args).items():
+            setattr(self, k, v)
+        self.save_hyperparameters(input_dim=input_dim, hidden_dim=hidden_dim, args=args, **kwargs)
+        self.emb_model = BaseGNN(input_dim, hidden_dim, 1, args, **kwargs)
+        self.kwargs = kwargs
+        self.query_emb: Optional[torch.Tensor] = None
+
+    def set_query_emb(self, query_emb: torch.Tensor, query_ids=None, queries=None):   # :637-638
+        self.query_emb = query_emb.detach()
+
+    def graph_to_count(self, batch: GossipBatch, query_emb=None) -> torch.Tensor:     # :613-628
+        qe = self.query_emb if query_emb is None else query_emb
+        if qe is None:
+            raise RuntimeError("call set_query_emb() first (main.py:334)")
+        with torch.no_grad():
+            return self.emb_model(batch, query_emb=qe.to(self.device))
+
+    def predict_step(self, batch, batch_idx) -> torch.Tensor:
+        return self.graph_to_count(batch)
+
+    def criterion(self, count, truth):                                      # :630-635
+        return torch.log2(torch.abs(count - truth) + 1)
+
+    def _gate_value(self, query_emb) -> torch.Tensor:                       # :640-649
+        assert self.conv_type == "GOSSIP"
+        with torch.no_grad():
+            return torch.stack([layer._gate_value(query_emb.to(self.device))
+                                for layer in self.emb_model.gnn_core.convs], dim=0)
+
+    def configure_optimizers(self):                                         # :570-583
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,
+                                                           patience=20, min_lr=1e-5)
+        return {"optimizer": optimizer, "lr_scheduler": sched, "monitor": "gossip_counting_val_loss"}

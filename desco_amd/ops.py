@@ -1,0 +1,184 @@
+"""Torch-facing wrappers over the C ABI of libdesco_hip.so.
+
+PyTorch is plumbing here: device memory (``torch.empty``), the current HIP stream and autograd
+bookkeeping.  All arithmetic happens in the hand-written gfx950 kernels.  Every wrapper refuses
+CPU tensors -- there is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"desco_amd.ops: `{name}` must be a tensor on the MI355X (cuda) device; "
+                           "there is no CPU fallback (use oracle/ for CPU checks)")
+    if t.dtype != dtype:
+        raise TypeError(f"desco_amd.ops: `{name}` must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rows(t: torch.Tensor, name: str):
+    """(ptr, leading dim) of a 2-D fp32 row-major view with unit inner stride."""
+    p = _dev(t, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"desco_amd.ops: `{name}` must be 2-D with unit inner stride")
+    return p, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    return None if t is None else _dev(t, name, dtype)
+
+
+def linear_smallk(feat: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor],
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = feat @ wt + bias for tiny K (pre_mp = nn.Linear(input_dim, 64), gnn_model.py:131)."""
+    m, k = feat.shape
+    n = wt.shape[1]
+    if out is None:
+        out = torch.empty((m, n), device=feat.device, dtype=torch.float32)
+    fp, ldf = _rows(feat, "feat")
+    op, ldo = _rows(out, "out")
+    wt = wt.contiguous()
+    L = _lib.lib()
+    _lib.check(L.desco_linear_smallk_f32(fp, ldf, k, _dev(wt, "wt"), _opt(bias, "bias"), op, ldo,
+                                         m, n, _stream()), "linear_smallk")
+    return out
+
+
+def csr_gather_sum(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, num_rows: int,
+                   slots: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """agg[i, s*64:(s+1)*64] = sum over virtual row i*slots+s of x[vcol[e]]  -> [num_rows, slots*64]"""
+    if out is None:
+        out = torch.empty((num_rows, slots * 64), device=x.device, dtype=torch.float32)
+    assert out.is_contiguous() and x.shape[1] == 64
+    xp, ldx = _rows(x, "x")
+    L = _lib.lib()
+    _lib.check(L.desco_csr_gather_sum_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
+                                          _dev(vcol, "vcol", torch.int32), num_rows, slots,
+                                          _dev(out, "out"), _stream()), "csr_gather_sum")
+    return out
+
+
+def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
+         s: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act([a1 | a2] @ wt + bias[row % bias_rows] + s @ ws)  on the f32 MFMA path.
+
+    ``wt`` is [(k1+k2), n] (torch weight transposed); ``bias`` is [n] or [bias_rows, n]."""
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = wt.shape[1]
+    assert wt.shape[0] == k1 + k2 and wt.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), device=a1.device, dtype=torch.float32)
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    op, ldo = _rows(out, "out")
+    bias_rows = 1
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_rows = 1 if bias.dim() == 1 else bias.shape[0]
+    ns = 0
+    if s is not None:
+        assert s.is_contiguous() and s.shape[0] == m and ws is not None and ws.is_contiguous()
+        ns = s.shape[1]
+    L = _lib.lib()
+    _lib.check(L.desco_gemm_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(wt, "wt"), n,
+                                _opt(bias, "bias"), bias_rows, _opt(s, "s"), ns, _opt(ws, "ws"),
+                                act, slope, op, ldo, m, _stream()), "gemm")
+    return out
+
+
+def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
+                extra: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = sum(x[seg_ptr[b]:seg_ptr[b+1]]) + extra[b]   (global_add_pool, gnn_model.py:107)."""
+    ncols = x.shape[1]
+    if out is None:
+        out = torch.empty((num_seg, ncols), device=x.device, dtype=torch.float32)
+    xp, ldx = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
+    L = _lib.lib()
+    _lib.check(L.desco_segment_sum_f32(xp, ldx, ncols, _dev(seg_ptr, "seg_ptr", torch.int32),
+                                       num_seg, ep, lde, op, ldo, _stream()), "segment_sum")
+    return out
+
+
+def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2: float, slope: float,
+               exp2_minus_1: bool) -> torch.Tensor:
+    """[B,Q] logits (or 2**logit - 1) of the separable count head (lightning_model.py:176-221)."""
+    B, hid = t.shape
+    Q = qh.shape[0]
+    out = torch.empty((B, Q), device=t.device, dtype=torch.float32)
+    tp, ldt = _rows(t, "t")
+    qp, ldq = _rows(qh, "qh")
+    L = _lib.lib()
+    _lib.check(L.desco_count_head_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"), b2,
+                                      slope, int(exp2_minus_1), _dev(out, "out"), Q, B, Q,
+                                      _stream()), "count_head")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[rows[b], :] = src[b, :]  (GossipDataset.apply_neighborhood_count, workload.py:107-112)."""
+    sp, lds = _rows(src, "src")
+    dp, ldd = _rows(dst, "dst")
+    L = _lib.lib()
+    _lib.check(L.desco_scatter_rows_f32(sp, lds, _dev(rows, "rows", torch.int32), src.shape[0],
+                                        src.shape[1], dp, ldd, _stream()), "scatter_rows")
+    return dst
+
+
+def gossip_layer0(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, g1, p, r, t, z):
+    """Closed-form first gossip layer for all queries -> (h1 [N*Q,64], scal [N*Q,2])."""
+    N, Q = x.shape
+    h1 = torch.empty((N * Q, 64), device=x.device, dtype=torch.float32)
+    scal = torch.empty((N * Q, 2), device=x.device, dtype=torch.float32)
+    xp, ldx = _rows(x, "x")
+    L = _lib.lib()
+    _lib.check(L.desco_gossip_layer0_f32(xp, ldx, _dev(rowptr, "rowptr", torch.int32),
+                                         _dev(col, "col", torch.int32), N, Q,
+                                         _dev(g0.contiguous(), "g0"), _dev(g1.contiguous(), "g1"),
+                                         _dev(p.contiguous(), "p"), _dev(r.contiguous(), "r"),
+                                         _dev(t.contiguous(), "t"), _dev(z.contiguous(), "z"),
+                                         _dev(h1, "h1"), _dev(scal, "scal"), _stream()),
+               "gossip_layer0")
+    return h1, scal
+
+
+def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
+                  num_q: int, g: torch.Tensor) -> torch.Tensor:
+    """out[i,q,:] = sum_j (j<i ? g[q] : 1-g[q]) * h[j,q,:]   (h: [N*Q, 64] contiguous)."""
+    assert h.is_contiguous()
+    out = torch.empty_like(h)
+    L = _lib.lib()
+    _lib.check(L.desco_gossip_gather_f32(_dev(h, "h"), _dev(rowptr, "rowptr", torch.int32),
+                                         _dev(col, "col", torch.int32), num_nodes, num_q,
+                                         _dev(g.contiguous(), "g"), _dev(out, "out"), _stream()),
+               "gossip_gather")
+    return out
+
+
+def rowdot_add(y: torch.Tensor, w: torch.Tensor, b: float, add: Optional[torch.Tensor]):
+    """out[r] = add[r] + y[r,:] . w + b"""
+    R, n = y.shape
+    out = torch.empty((R,), device=y.device, dtype=torch.float32)
+    yp, ldy = _rows(y, "y")
+    L = _lib.lib()
+    _lib.check(L.desco_rowdot_add_f32(yp, ldy, n, _dev(w.contiguous(), "w"), b,
+                                      _opt(add, "add"), _dev(out, "out"), R, _stream()),
+               "rowdot_add")
+    return out

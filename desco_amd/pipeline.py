@@ -1,0 +1,97 @@
+"""Two-stage inference over a whole dataset, resident in HBM (the hot path of main.py:296-302,
+417-423): neighborhood counting -> apply_neighborhood_count -> gossip -> graph-level aggregation.
+
+The reference round-trips GPU -> CPU -> GPU between the stages and walks fixed 512/256-item
+DataLoader batches; here the dataset shard is packed once into a few large device blocks sized by
+a row budget ("per-GPU dynamic graph-batch packing"), and every stage stays on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .batch import GossipBatch, NeighborhoodBatch
+from .graphs import GraphSet
+from .partition import NeighborhoodPartition, build_partition
+
+
+def _split_by_budget(weights: np.ndarray, budget: int) -> List[int]:
+    """Cut points so that every chunk's total weight <= budget (single items may exceed it)."""
+    cuts, acc, start = [0], 0, 0
+    csum = np.concatenate([[0], np.cumsum(weights, dtype=np.int64)])
+    n = len(weights)
+    while start < n:
+        end = int(np.searchsorted(csum, csum[start] + budget, side="right")) - 1
+        end = max(end, start + 1)
+        end = min(end, n)
+        cuts.append(end)
+        start = end
+    return cuts
+
+
+class InferencePipeline:
+    def __init__(self, neigh_model, gossip_model, graphs: GraphSet, depth: int = 4,
+                 device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 6_000_000,
+                 max_gossip_rows: int = 4_000_000, num_threads: int = 0,
+                 partition: Optional[NeighborhoodPartition] = None):
+        self.nm, self.gm = neigh_model, gossip_model
+        self.graphs = graphs
+        self.device = torch.device(device)
+        self.partition = partition or build_partition(graphs, depth, quirk_batch, num_threads)
+        part = self.partition
+        self.num_queries = None
+        # neighborhood blocks by row budget
+        rows_per_neigh = np.diff(part.count_ptr).astype(np.int64) + 1
+        cuts = _split_by_budget(rows_per_neigh, max_neigh_rows)
+        self.neigh_batches = [NeighborhoodBatch(part.slice(b0, b1), device)
+                              for b0, b1 in zip(cuts[:-1], cuts[1:])]
+        # neighborhood b -> node row of the gossip x matrix (apply_neighborhood_count)
+        rows = graphs.graph_ptr[part.neigh_index[:, 0]] + part.neigh_index[:, 1]
+        self.scatter_index = torch.from_numpy(rows.astype(np.int32)).to(device)
+        # neighborhoods are ordered by graph: segment pointer for aggregate_neighborhood_count
+        per_graph = np.bincount(part.neigh_index[:, 0], minlength=graphs.num_graphs)
+        self.neigh_graph_ptr = torch.from_numpy(
+            np.concatenate([[0], np.cumsum(per_graph)]).astype(np.int32)).to(device)
+        self.node_graph_ptr = torch.from_numpy(graphs.graph_ptr.astype(np.int32)).to(device)
+        # gossip blocks by (node x query) row budget, cut on graph boundaries
+        self._gossip_cuts_budget = max_gossip_rows
+        self.gossip_batches = None
+
+    def _ensure_gossip_batches(self, Q: int):
+        if self.gossip_batches is not None and self.num_queries == Q:
+            return
+        sizes = np.diff(self.graphs.graph_ptr) * Q
+        cuts = _split_by_budget(sizes, self._gossip_cuts_budget)
+        self.gossip_batches = []
+        for g0, g1 in zip(cuts[:-1], cuts[1:]):
+            n0, n1 = int(self.graphs.graph_ptr[g0]), int(self.graphs.graph_ptr[g1])
+            self.gossip_batches.append((n0, n1, GossipBatch(self.graphs.subset(g0, g1), self.device)))
+        self.num_queries = Q
+
+    @torch.no_grad()
+    def run(self, gossip: bool = True) -> Dict[str, torch.Tensor]:
+        nm, gm = self.nm, self.gm
+        counts = [nm.graph_to_count(b) for b in self.neigh_batches]            # main.py:296-301
+        neigh_count = counts[0] if len(counts) == 1 else torch.cat(counts)
+        Q = neigh_count.shape[1]
+        G, N = self.graphs.num_graphs, self.graphs.num_nodes
+        out = {"neigh_count": neigh_count}
+        out["graph_neigh_count"] = ops.segment_sum(neigh_count, self.neigh_graph_ptr, G)   # :400-404
+        if not gossip:
+            return out
+        x = torch.zeros((N, Q), device=self.device)                           # workload.py:107-112
+        ops.scatter_rows(neigh_count, self.scatter_index, x)
+        gm.set_query_emb(nm.get_query_emb())                                  # main.py:334
+        self._ensure_gossip_batches(Q)
+        node = []
+        for n0, n1, gb in self.gossip_batches:
+            gb.x = x[n0:n1]
+            node.append(gm.graph_to_count(gb))                                # main.py:417-420
+        node_count = node[0] if len(node) == 1 else torch.cat(node)
+        out["x"] = x
+        out["node_count"] = node_count
+        out["graph_gossip_count"] = ops.segment_sum(node_count, self.node_graph_ptr, G)    # :421-423
+        return out

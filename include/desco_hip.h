@@ -1,0 +1,156 @@
+/*
+ * desco_hip.h -- C ABI of libdesco_hip.so, the MI355X (gfx950) native layer of the DeSCo hot path.
+ *
+ * The reference (fuvty/DeSCo) has no FFI: its hot path is Python calling PyG / torch ops.  This
+ * header is the boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace those
+ * call sites.  Each entry point names the reference call site it replaces (paths relative to the
+ * reference root, see SURVEY.md section 8a for the row ids A1..A15 / K1..K24).
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a hipError_t value (device entry points) or a
+ *     negative DESCO_E* code (argument errors); desco_last_error() gives a message (thread local).
+ *   - device entry points take DEVICE pointers and a hipStream_t passed as void* (NULL = default
+ *     stream); they only enqueue work, never allocate, never synchronise (graph-capture safe).
+ *   - host entry points (desco_partition_*) take HOST pointers.
+ *   - the hidden width H is fixed at 64 (reference default --neigh_hidden_dim/--gossip_hidden_dim,
+ *     config.py:250,316); feature rows are fp32.
+ *   - "virtual row" CSR: destination row i with relation slot s is virtual row i*S+s.
+ */
+#ifndef DESCO_HIP_H
+#define DESCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DESCO_ABI_VERSION 1
+#define DESCO_H 64
+
+#define DESCO_EINVAL (-1)
+#define DESCO_ENOMEM (-2)
+
+#define DESCO_ACT_NONE 0
+#define DESCO_ACT_RELU 1
+#define DESCO_ACT_LEAKY 2 /* slope given separately */
+
+typedef void* desco_stream_t;
+
+int desco_abi_version(void);
+/* number of visible HIP devices, or a negative hipError_t when the runtime cannot initialise */
+int desco_device_count(void);
+const char* desco_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * HOST: canonical-partition builder.
+ * Replaces NeighborhoodDataset.process (workload.py:243-294: get_neigh_hetero data.py:375-396,
+ * k_neigh data.py:329-338, NetworkxToHetero transforms.py:319-412), the per-item ToTconvHetero
+ * transform (transforms.py:180-255) and PyG's hetero collate, for a whole dataset at once.
+ *
+ * Input: G graphs stored as one CSR over global node ids (graph g owns nodes
+ * graph_ptr[g]..graph_ptr[g+1]-1, ascending = the reference's nx node order); adjacency must be
+ * symmetric, without self loops or duplicates, each row sorted ascending.
+ *
+ * Output (after desco_partition_sizes / desco_partition_export):
+ *   B neighborhoods (one per node whose canonical neighborhood has >= 1 edge), N_c count rows.
+ *   Row order: count rows of neighborhood 0, 1, ... (ascending original id inside each), then
+ *   the B canonical rows; canonical row of neighborhood b is N_c + b.
+ *   neigh_index[B][2] = (graph id, node id inside the graph)   (nx_neighs_index, workload.py:189-195)
+ *   indicator[num_nodes]                                       (nx_neighs_indicator)
+ *   count_ptr[B+1]: count rows of neighborhood b are count_ptr[b]..count_ptr[b+1]-1
+ *   count_orig[N_c]: global node id of every count row
+ *   vrowptr[4*(N_c+B)+1], vcol[E]: destination-major CSR with 4 relation slots per row,
+ *      slot = 2*(source is the canonical node) + (edge is a "tride" edge, i.e. NOT in a triangle);
+ *      vcol holds source ROW ids, ascending inside a slot.
+ * quirk_batch > 0 emulates PyG's remove_self_loops on the bipartite edge types for reference
+ * batches of quirk_batch consecutive neighborhoods (gnn_model.py:389-390); 0 = off.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct desco_partition desco_partition;
+
+int desco_partition_build(const int64_t* graph_ptr, int64_t num_graphs, const int64_t* rowptr,
+                          const int32_t* col, int depth, int quirk_batch, int num_threads,
+                          desco_partition** out);
+int desco_partition_sizes(const desco_partition* p, int64_t* num_neigh, int64_t* num_count,
+                          int64_t* num_edges, int64_t* num_nodes);
+int desco_partition_export(const desco_partition* p, int64_t* neigh_index, uint8_t* indicator,
+                           int32_t* count_ptr, int32_t* count_orig, int32_t* vrowptr,
+                           int32_t* vcol);
+void desco_partition_free(desco_partition* p);
+
+/* ------------------------------------------------------------------------------------------
+ * DEVICE kernels
+ * ------------------------------------------------------------------------------------------ */
+
+/* K1/K16  pre_mp = nn.Linear(input_dim, H) (gnn_model.py:131, 231):
+ * out[i, 0:n] = feat[i, 0:k] * wt[k][n] + bias   (wt = weight transposed, [k][n] row major) */
+int desco_linear_smallk_f32(const float* feat, int64_t ldf, int k, const float* wt,
+                            const float* bias, float* out, int64_t ldo, int64_t m, int n,
+                            desco_stream_t stream);
+
+/* K2/K3  SAGEConv message+aggregate for all relation slots at once (gnn_model.py:392-394,
+ * 402-404: index_select + scatter_add):  out[v, 0:64] = sum_{e in vrow v} x[vcol[e], 0:64].
+ * One wavefront per destination row, one 16-lane group (float4 per lane) per slot; S in {1,2,4}.
+ * out is [num_rows*S, 64] contiguous (== [num_rows, S*64]). */
+int desco_csr_gather_sum_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                             const int32_t* vcol, int64_t num_rows, int slots, float* out,
+                             desco_stream_t stream);
+
+/* K4-K6, K8, K10, K12, K18, K20, K21: every dense projection of the path.
+ * C[m, n] = act( [A1 | A2][m, :] * Wt + bias[(m % bias_rows), n] + sum_j S[m, j] * Ws[j, n] )
+ *   A1: [M, k1] leading dim lda1;  A2: [M, k2] leading dim lda2 (k2 may be 0);  k1, k2 % 32 == 0
+ *   Wt: [(k1+k2), n] row major (= torch weight transposed);  n % 64 == 0
+ *   bias: [bias_rows, n] or NULL (bias_rows >= 1);  S: [M, ns] (ns <= 4) or NULL;  Ws: [ns, n]
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain per output). */
+int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+                   const float* wt, int n, const float* bias, int bias_rows, const float* s,
+                   int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
+                   int64_t m, desco_stream_t stream);
+
+/* K9  global_add_pool (gnn_model.py:107) over contiguous row segments, plus one optional extra row
+ * per segment (the anchored canonical embedding, gnn_model.py:69-73, 88-89):
+ * out[b, 0:ncols] = sum_{r in [seg_ptr[b], seg_ptr[b+1])} x[r, 0:ncols] + extra[b, 0:ncols]
+ * Also used for the node->graph aggregation of counts (workload.py:136-148, 303-324). */
+int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols, const int32_t* seg_ptr,
+                          int64_t num_seg, const float* extra, int64_t ld_extra, float* out,
+                          int64_t ldo, desco_stream_t stream);
+
+/* K12/K13  count head (lightning_model.py:176-193, 210-221) in separable form:
+ * logit[b,q] = sum_c w2[c] * leaky(T[b,c] + Qh[q,c]) + b2;  out = exp2 ? 2^logit - 1 : logit
+ * T: [B, hid] (target half of count_model.0), Qh: [Q, hid] (query half + bias), hid % 64 == 0 */
+int desco_count_head_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq, int hid,
+                         const float* w2, float b2, float slope, int exp2_minus_1, float* out,
+                         int64_t ldo, int64_t num_b, int num_q, desco_stream_t stream);
+
+/* K14  GossipDataset.apply_neighborhood_count (workload.py:107-112): dst[rows[b], :] = src[b, :] */
+int desco_scatter_rows_f32(const float* src, int64_t lds, const int32_t* rows, int64_t num_src,
+                           int ncols, float* dst, int64_t ldd, desco_stream_t stream);
+
+/* K15-K20, layer 0 of the gossip GNN for ALL queries at once, in closed form:
+ * per node i and query q:
+ *   lo/hi = neighbours j<i / j>i (== edge_weight of gnn_model.py:248),
+ *   a0 = g0[q]*deg_lo + (1-g0[q])*deg_hi,  b0 = g0[q]*sum_lo x[j,q] + (1-g0[q])*sum_hi x[j,q]
+ *   h1[i,q,:] = relu(a0*p[q,:] + b0*r[:] + x[i,q]*t[:] + z[q,:])
+ *   scal[i,q,0] = g1[q]*deg_lo + (1-g1[q])*deg_hi,  scal[i,q,1] = x[i,q]
+ * rowptr/col: symmetric CSR of the batch, col ascending per row. */
+int desco_gossip_layer0_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                            int64_t num_nodes, int num_q, const float* g0, const float* g1,
+                            const float* p, const float* r, const float* t, const float* z,
+                            float* h1, float* scal, desco_stream_t stream);
+
+/* K18/K19 for layers >= 1, aggregate-then-transform form:
+ * out[i,q,:] = sum_{j~i} (j<i ? g[q] : 1-g[q]) * h[j,q,:]      (h, out: [num_nodes, num_q, 64]) */
+int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t* col,
+                            int64_t num_nodes, int num_q, const float* g, float* out,
+                            desco_stream_t stream);
+
+/* K21 tail: out[r] = add[r] + sum_c y[r,c]*w[c] + b   (post_mp.7 with output_dim 1, then
+ * pred = neigh_pred + gossip_pred, lightning_model.py:622-625) */
+int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, const float* w, float b,
+                         const float* add, float* out, int64_t num_rows, desco_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DESCO_HIP_H */

@@ -1,0 +1,254 @@
+"""Oracle, float path: pure-torch CPU restatement of the reference's SHMP neighborhood model and
+gossip model, IN THE REFERENCE'S FORM (per-edge-type index_select + index_add_ + Linear, 29-iteration
+Python loops, query graphs re-embedded on every call).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED by the reference: the reference has
+no tests / golden vectors for this path and torch_geometric is not importable here, so the
+third-party semantics marked [EXT] below are recalled from PyG 2.2.0, not executed.
+
+All functions take a plain ``state_dict`` (reference key names) and numpy/torch index
+arrays in PyG convention (``edge_index[0]`` = source index inside the source node type,
+``edge_index[1]`` = destination index inside the destination node type).
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import partition as P
+
+
+def _lin(sd, key, x):
+    return F.linear(x, sd[key + ".weight"], sd[key + ".bias"])
+
+
+def _t(a):
+    return a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+
+
+def sage_conv(sd, key, x_src, n_dst, ei, emulate_quirk, bipartite):
+    """SAGEConv.forward, gnn_model.py:372-404.
+
+    ``remove_self_loops`` (row != col, no bipartite awareness [EXT]) is applied to every non-empty
+    edge type (:389-390): on bipartite types it silently drops edges whose batch-global source and
+    destination indices coincide.  ``emulate_quirk=False`` gives the intended model.
+    message = x_j (:402-404), aggr = add at edge_index[1] [EXT propagate], then ``lin`` on every
+    destination row (:395).
+    """
+    ei = _t(ei).long()
+    if ei.numel() != 0 and (emulate_quirk or not bipartite):
+        ei = ei[:, ei[0] != ei[1]]
+    agg = torch.zeros(n_dst, x_src.shape[1], dtype=x_src.dtype)
+    agg.index_add_(0, ei[1], x_src[ei[0]])
+    return _lin(sd, key + ".lin", agg)
+
+
+def gnn_core_hetero(sd, prefix, feats: Dict[str, torch.Tensor], edge_index: Dict, node_types,
+                    edge_types, layer_num, emulate_quirk=True):
+    """BaseGNNCore.forward (SAGE branch) after pyg.nn.to_hetero(aggr="sum").
+
+    gnn_model.py:230-277; per-type module copies and the pairwise-queue sum over edge types with
+    a common destination type are [EXT].
+    """
+    x = {t: _lin(sd, f"{prefix}.pre_mp.0.{t}", feats[t]) for t in node_types}      # :231
+    emb = dict(x)                                                                   # :253
+    for l in range(layer_num):
+        outs = {t: deque() for t in node_types}
+        for (s, r, d) in edge_types:
+            key = f"{prefix}.convs.{l}.{s}__{r}__{d}"
+            outs[d].append(sage_conv(sd, key, x[s], x[d].shape[0], edge_index[(s, r, d)],
+                                     emulate_quirk, bipartite=(s != d)))            # :262
+        new_x = {}
+        for t in node_types:
+            q = outs[t]
+            while len(q) >= 2:                       # [EXT] to_hetero pairwise torch.add queue
+                a, b = q.popleft(), q.popleft()
+                q.append(a + b)
+            x_neigh = q[0]
+            h = _lin(sd, f"{prefix}.updates.{l}.{t}", torch.cat((x_neigh, x[t]), dim=1))  # :264
+            new_x[t] = F.relu(h)                     # :273 ; dropout p=0 (:274) is the identity
+        x = new_x
+        emb = {t: torch.cat((emb[t], x[t]), dim=1) for t in node_types}             # :275
+    return emb
+
+
+def post_mp(sd, prefix, emb):
+    """BaseGNN.post_mp, gnn_model.py:44-53 (Dropout is the identity at inference / p=0)."""
+    h = _lin(sd, f"{prefix}.post_mp.0", emb)
+    h = F.leaky_relu(h, 0.1)
+    h = F.relu(_lin(sd, f"{prefix}.post_mp.3", h))
+    h = F.relu(_lin(sd, f"{prefix}.post_mp.5", h))
+    return _lin(sd, f"{prefix}.post_mp.7", h)
+
+
+def base_gnn_hetero(sd, prefix, batch: Dict, node_types, edge_types, layer_num, input_dim=1,
+                    feats=None, emulate_quirk=True):
+    """BaseGNN.forward, hetero path, gnn_model.py:58-109.  ``batch`` = oracle.partition.collate()."""
+    if feats is None:       # ZeroNodeFeat / NetworkxToHetero zeros (transforms.py:380-384)
+        feats = {t: torch.zeros(batch["num_nodes"][t], input_dim) for t in node_types}
+    emb = gnn_core_hetero(sd, f"{prefix}.gnn_core", feats, batch["edge_index"], node_types,
+                          edge_types, layer_num, emulate_quirk)                     # :66
+    if "canonical" in emb:                                                          # :69-73
+        emb["canonical"] = F.leaky_relu(_lin(sd, f"{prefix}.anchor_mlp.0", emb["canonical"]), 0.1)
+    allemb = torch.cat([emb[t] for t in node_types], dim=0)                          # :88-89
+    bvec = torch.cat([_t(batch["batch"][t]).long() for t in node_types])
+    pooled = torch.zeros(batch["num_graphs"], allemb.shape[1])
+    pooled.index_add_(0, bvec, allemb)                                              # :107 global_add_pool
+    return post_mp(sd, prefix, pooled)                                              # :108
+
+
+def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1):
+    """emb_model_query on the query batch (lightning_model.py:204-207)."""
+    return base_gnn_hetero(sd, "emb_model_query", qbatch, ("union_node",), P.QUERY_EDGE_TYPES,
+                           layer_num, input_dim)
+
+
+def neighborhood_logits(sd, batch, qbatch, layer_num=8, input_dim=1, feats=None,
+                        emulate_quirk=True):
+    """The [B,Q] pre-exponent outputs of graph_to_count / train_forward.
+
+    lightning_model.py:198-219 + embed_to_count :176-193: the queries are re-embedded on every
+    call, then per query ``count_model(cat(emb_target, query_emb.expand_as(emb_target)))``.
+    """
+    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim)
+    emb_t = base_gnn_hetero(sd, "emb_model", batch, P.NODE_TYPES, P.EDGE_TYPES, layer_num,
+                            input_dim, feats, emulate_quirk)
+    outs = []
+    for q in range(emb_q.shape[0]):
+        e = torch.cat((emb_t, emb_q[q].expand_as(emb_t)), dim=-1)
+        h = F.leaky_relu(_lin(sd, "count_model.0", e))        # nn.LeakyReLU() default slope 0.01
+        outs.append(_lin(sd, "count_model.2", h))
+    return torch.cat(outs, dim=-1), emb_q
+
+
+def neighborhood_graph_to_count(sd, batch, qbatch, **kw):
+    """graph_to_count, lightning_model.py:198-222: ``2**pred - 1``."""
+    logits, _ = neighborhood_logits(sd, batch, qbatch, **kw)
+    return 2 ** logits - 1
+
+
+def neighborhood_loss(sd, batch, qbatch, y, **kw):
+    """train_forward, lightning_model.py:228-254 + criterion :285-289."""
+    logits, _ = neighborhood_logits(sd, batch, qbatch, **kw)
+    losses = [F.smooth_l1_loss(logits[:, q:q + 1], torch.log2(y[:, q].view(-1, 1) + 1))
+              for q in range(logits.shape[1])]
+    return torch.mean(torch.stack(losses))
+
+
+# ------------------------------------------------------------------------------------------
+# gossip
+# ------------------------------------------------------------------------------------------
+def gossip_gate(sd, key, query_emb):
+    """GossipConv.lin_gate, gnn_model.py:294-301: Linear, Sigmoid, Linear, Sigmoid, LeakyReLU()."""
+    g = torch.sigmoid(_lin(sd, key + ".lin_gate.0", query_emb))
+    g = torch.sigmoid(_lin(sd, key + ".lin_gate.2", g))
+    return F.leaky_relu(g)
+
+
+def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2):
+    """BaseGNN.forward (baseline == "gossip") for ONE query, gnn_model.py:58-109, 230-277, 303-350.
+
+    ``x_col`` [N,1] neighborhood counts of this query, ``query_emb`` [1,H].  Returns [N,1].
+    """
+    N = x_col.shape[0]
+    x = _lin(sd, "emb_model.gnn_core.pre_mp.0", x_col)                               # :231
+    x = torch.cat((query_emb.expand(N, -1), x), dim=-1).clone().detach()            # :236-240
+    ei, dirw = P.gossip_edge_index(N, np.asarray(edge_index))                       # :246-248
+    ei, dirw = torch.as_tensor(ei).long(), torch.as_tensor(dirw)
+    emb = x
+    for l in range(layer_num):
+        key = f"emb_model.gnn_core.convs.{l}"
+        gate = gossip_gate(sd, key, query_emb)                                      # :340
+        msg = _lin(sd, key + ".lin_com", x[ei[0]])                                  # :341 (x_j)
+        msg[dirw] *= gate                                                           # :342
+        msg[~dirw] *= 1 - gate                                                      # :343
+        aggr = torch.zeros(N, msg.shape[1]).index_add_(0, ei[1], msg)               # aggr="add"
+        x = _lin(sd, key + ".lin_update", torch.cat((aggr, x), dim=-1))             # :347-348
+        x = F.relu(x)                                                               # :273
+        emb = torch.cat((emb, x), dim=1)                                            # :275
+    return post_mp(sd, "emb_model", emb)                                            # :102-103
+
+
+def gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num=2):
+    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: 29 sequential passes."""
+    outs = []
+    for q in range(query_emb.shape[0]):
+        corr = gossip_single_query(sd, x[:, q].view(-1, 1), edge_index, query_emb[q].view(1, -1),
+                                   layer_num)
+        outs.append(x[:, q].view(-1, 1) + corr)
+    return torch.cat(outs, dim=-1)
+
+
+def gossip_loss(sd, x, y, edge_index, query_emb, layer_num=2):
+    """train_forward + criterion, lightning_model.py:585-608, 630-635 (sum, not mean)."""
+    pred = gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num)
+    return torch.sum(torch.log2(torch.abs(pred - y) + 1))
+
+
+def gossip_gate_values(sd, query_emb, layer_num=2):
+    """GossipCountingModel._gate_value, lightning_model.py:640-649 -> [L,Q,1]."""
+    return torch.stack([gossip_gate(sd, f"emb_model.gnn_core.convs.{l}", query_emb)
+                        for l in range(layer_num)], dim=0)
+
+
+# ------------------------------------------------------------------------------------------
+# dataset-level helpers (A11 / A15)
+# ------------------------------------------------------------------------------------------
+def apply_neighborhood_count(count, indicator):
+    """GossipDataset.apply_neighborhood_count, workload.py:107-112."""
+    x = torch.zeros(len(indicator), count.shape[1])
+    x[torch.as_tensor(np.asarray(indicator, dtype=bool))] = count.detach()
+    return x
+
+
+def aggregate_by_index(count, graph_id, num_graphs):
+    """NeighborhoodDataset.aggregate_neighborhood_count, workload.py:303-324 (index_add_)."""
+    out = torch.zeros(num_graphs, count.shape[1])
+    out.index_add_(0, torch.as_tensor(np.asarray(graph_id)).long(), count.float())
+    return out
+
+
+def aggregate_by_ptr(count, ptr):
+    """GossipDataset.aggregate_neighborhood_count, workload.py:136-148 (segment_csr sum [EXT])."""
+    ptr = np.asarray(ptr)
+    return torch.stack([count[ptr[i]:ptr[i + 1]].sum(dim=0) for i in range(len(ptr) - 1)])
+
+
+def reference_pipeline(sd_neigh, sd_gossip, graphs, queries, depth=4, neigh_batch=512,
+                       gossip_batch=256, layer_num=8, gossip_layers=2, emulate_quirk=True):
+    """End-to-end inference in the reference's form (main.py:296-302, 417-423): neighborhood
+    counts in batches of ``neigh_batch`` neighborhoods, scatter to nodes, gossip in batches of
+    ``gossip_batch`` graphs, per-graph aggregation.  Returns dict of tensors.
+    """
+    index, indicator, neighs = P.neighborhood_dataset(graphs, depth)
+    qbatch = P.query_batch(queries)
+    counts = []
+    for b0 in range(0, len(neighs), neigh_batch):
+        batch = P.neighborhood_batch(neighs[b0:b0 + neigh_batch])
+        counts.append(neighborhood_graph_to_count(sd_neigh, batch, qbatch, layer_num=layer_num,
+                                                  emulate_quirk=emulate_quirk))
+    Q = len(queries)
+    neigh_count = torch.cat(counts) if counts else torch.zeros(0, Q)
+    x = apply_neighborhood_count(neigh_count, indicator)
+    emb_q = neighborhood_embed_queries(sd_neigh, qbatch, layer_num)
+    ptr = np.concatenate([[0], np.cumsum([n for n, _ in graphs])])
+    outs = []
+    for g0 in range(0, len(graphs), gossip_batch):
+        g1 = min(g0 + gossip_batch, len(graphs))
+        n0, n1 = ptr[g0], ptr[g1]
+        es = [np.asarray(sorted(e), dtype=np.int64).reshape(-1, 2) + (ptr[g] - n0)
+              for g, (_, e) in zip(range(g0, g1), graphs[g0:g1])]
+        und = np.concatenate(es) if es else np.zeros((0, 2), dtype=np.int64)
+        ei = np.concatenate([und, und[:, ::-1]]).T          # to_networkx(to_undirected) both dirs
+        outs.append(gossip_graph_to_count(sd_gossip, x[n0:n1], ei, emb_q, gossip_layers))
+    node_count = torch.cat(outs) if outs else torch.zeros(0, Q)
+    return {
+        "index": index, "indicator": indicator, "neigh_count": neigh_count, "x": x,
+        "query_emb": emb_q, "node_count": node_count,
+        "graph_neigh_count": aggregate_by_index(neigh_count, index[:, 0], len(graphs)),
+        "graph_gossip_count": aggregate_by_ptr(node_count, ptr),
+    }

@@ -1,0 +1,184 @@
+"""Kernel-level parity: every C-ABI device entry point vs. a plain torch fp32/fp64 formula."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from desco_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _close(got, ref, rtol=2e-5, atol=2e-5):
+    torch.testing.assert_close(got.detach().cpu().double(), ref.double(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("m", [1, 29, 127, 128, 129, 1000, 4097])
+@pytest.mark.parametrize("k1,k2,n", [(64, 0, 64), (256, 64, 64), (128, 64, 64), (576, 0, 576),
+                                     (64, 0, 256), (64, 64, 64), (576, 0, 64), (256, 0, 64)])
+def test_gemm_shapes(m, k1, k2, n):
+    g = torch.Generator().manual_seed(m * 7 + k1 + n)
+    a1 = torch.randn(m, k1, generator=g)
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    wt = torch.randn(k1 + k2, n, generator=g) / np.sqrt(k1 + k2)
+    bias = torch.randn(n, generator=g)
+    A = a1 if a2 is None else torch.cat([a1, a2], 1)
+    ref = torch.relu(A.double() @ wt.double() + bias.double())
+    got = ops.gemm(a1.to(DEV), wt.to(DEV), bias.to(DEV), a2=None if a2 is None else a2.to(DEV),
+                   act=ops.ACT_RELU)
+    _close(got, ref)
+
+
+def test_gemm_epilogue_and_strides():
+    g = torch.Generator().manual_seed(3)
+    Q, N = 29, 37
+    m = Q * N
+    slab = torch.randn(m + 5, 576, generator=g).to(DEV)
+    a1 = slab[:m, 64:128]                    # strided view, ld = 576
+    agg = torch.randn(m, 256, generator=g).to(DEV)
+    a2 = agg[:, :128]                        # ld = 256, k = 128
+    wt = (torch.randn(64 + 128, 64, generator=g) / 14).to(DEV)
+    bias = torch.randn(Q, 64, generator=g).to(DEV)
+    s = torch.randn(m, 2, generator=g).to(DEV)
+    ws = torch.randn(2, 64, generator=g).to(DEV)
+    out = torch.zeros(m, 576, device=DEV)
+    ops.gemm(a1, wt, bias, a2=a2, act=ops.ACT_LEAKY, slope=0.1, s=s, ws=ws, out=out[:, 128:192])
+    A = torch.cat([a1, a2], 1).double().cpu()
+    ref = A @ wt.double().cpu() + bias.double().cpu().repeat(N, 1) + s.double().cpu() @ ws.double().cpu()
+    ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    _close(out[:, 128:192], ref)
+    assert out[:, :128].abs().sum().item() == 0 and out[:, 192:].abs().sum().item() == 0
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric B catches a transposed C/D map (guide section 3)."""
+    wt = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64)
+    a = torch.eye(64)
+    got = ops.gemm(a.to(DEV), wt.to(DEV))
+    assert torch.equal(got.cpu(), wt)
+
+
+def test_gemm_rejects_cpu_and_bad_shapes():
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 64), torch.zeros(64, 64))
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(4, 48, device=DEV), torch.zeros(48, 64, device=DEV))
+
+
+def _random_vcsr(num_rows, slots, max_deg, n_src, g):
+    cnt = torch.randint(0, max_deg + 1, (num_rows * slots,), generator=g)
+    cnt[::7] = 0
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(cnt, 0)])
+    col = torch.randint(0, n_src, (int(ptr[-1]),), generator=g)
+    return ptr.to(torch.int32), col.to(torch.int32), cnt
+
+
+@pytest.mark.parametrize("slots", [1, 2, 4])
+@pytest.mark.parametrize("num_rows,max_deg", [(1, 3), (257, 5), (1000, 40)])
+def test_csr_gather_sum(slots, num_rows, max_deg):
+    g = torch.Generator().manual_seed(slots * 100 + num_rows)
+    n_src = num_rows + 11
+    slab = torch.randn(n_src, 576, generator=g)
+    x = slab[:, 64:128]
+    ptr, col, cnt = _random_vcsr(num_rows, slots, max_deg, n_src, g)
+    ref = torch.zeros(num_rows * slots, 64, dtype=torch.double)
+    vrow = torch.repeat_interleave(torch.arange(num_rows * slots), cnt)
+    ref.index_add_(0, vrow, x.double()[col.long()])
+    got = ops.csr_gather_sum(slab.to(DEV)[:, 64:128], ptr.to(DEV), col.to(DEV), num_rows, slots)
+    _close(got.reshape(num_rows * slots, 64), ref, atol=1e-5)
+
+
+def test_segment_sum_and_extra():
+    g = torch.Generator().manual_seed(5)
+    sizes = torch.randint(0, 30, (200,), generator=g)
+    sizes[3] = 0
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(sizes, 0)])
+    x = torch.randn(int(ptr[-1]), 64, generator=g)
+    extra = torch.randn(200, 576, generator=g)
+    ref = torch.zeros(200, 64, dtype=torch.double)
+    ref.index_add_(0, torch.repeat_interleave(torch.arange(200), sizes), x.double())
+    ref += extra[:, 128:192].double()
+    out = torch.zeros(200, 576, device=DEV)
+    ops.segment_sum(x.to(DEV), ptr.to(torch.int32).to(DEV), 200, extra=extra.to(DEV)[:, 128:192],
+                    out=out[:, 64:128])
+    _close(out[:, 64:128], ref, atol=1e-5)
+
+
+def test_count_head():
+    g = torch.Generator().manual_seed(6)
+    B, Q = 333, 29
+    t, qh = torch.randn(B, 256, generator=g), torch.randn(Q, 256, generator=g)
+    w2, b2 = torch.randn(256, generator=g) / 16, 0.3
+    pre = torch.nn.functional.leaky_relu(t.double()[:, None, :] + qh.double()[None], 0.01)
+    ref = pre @ w2.double() + b2
+    got = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), b2, 0.01, False)
+    _close(got, ref)
+    got2 = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), b2, 0.01, True)
+    _close(got2, 2 ** ref - 1, rtol=1e-4, atol=1e-4)
+
+
+def test_scatter_rows_and_linear_smallk_and_rowdot():
+    g = torch.Generator().manual_seed(8)
+    src = torch.randn(50, 29, generator=g)
+    rows = torch.randperm(80, generator=g)[:50].to(torch.int32)
+    dst = torch.zeros(80, 29, device=DEV)
+    ops.scatter_rows(src.to(DEV), rows.to(DEV), dst)
+    ref = torch.zeros(80, 29)
+    ref[rows.long()] = src
+    assert torch.equal(dst.cpu(), ref)
+
+    feat = torch.randn(123, 3, generator=g)
+    wt, b = torch.randn(3, 64, generator=g), torch.randn(64, generator=g)
+    got = ops.linear_smallk(feat.to(DEV), wt.to(DEV), b.to(DEV))
+    _close(got, feat.double() @ wt.double() + b.double())
+
+    y, w, add = torch.randn(777, 256, generator=g), torch.randn(256, generator=g), torch.randn(777, generator=g)
+    got = ops.rowdot_add(y.to(DEV), w.to(DEV), 0.25, add.to(DEV))
+    _close(got, y.double() @ w.double() + 0.25 + add.double(), atol=1e-4)
+
+
+def _sym_csr(n, m, g):
+    a = torch.randint(0, n, (m,), generator=g)
+    b = torch.randint(0, n, (m,), generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.cat([a * n + b, b * n + a]))
+    r, c = key // n, key % n
+    ptr = torch.zeros(n + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return ptr.to(torch.int32), c.to(torch.int32), r, c
+
+
+def test_gossip_layer0_and_gather():
+    g = torch.Generator().manual_seed(9)
+    n, Q = 150, 29
+    ptr, col, r, c = _sym_csr(n, 400, g)
+    x = torch.rand(n, Q, generator=g) * 20
+    g0, g1 = torch.rand(Q, generator=g), torch.rand(Q, generator=g)
+    p, z = torch.randn(Q, 64, generator=g), torch.randn(Q, 64, generator=g)
+    rv, tv = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    h1, scal = ops.gossip_layer0(x.to(DEV), ptr.to(DEV), col.to(DEV), g0.to(DEV), g1.to(DEV),
+                                 p.to(DEV), rv.to(DEV), tv.to(DEV), z.to(DEV))
+    # dense reference: edge (src=c -> dst=r); lo iff src < dst
+    lo = (c < r).double()
+    xd = x.double()
+    deg_lo = torch.zeros(n, dtype=torch.double).index_add_(0, r, lo)
+    deg_hi = torch.zeros(n, dtype=torch.double).index_add_(0, r, 1 - lo)
+    s_lo = torch.zeros(n, Q, dtype=torch.double).index_add_(0, r, xd[c] * lo[:, None])
+    s_hi = torch.zeros(n, Q, dtype=torch.double).index_add_(0, r, xd[c] * (1 - lo)[:, None])
+    a0 = g0.double() * deg_lo[:, None] + (1 - g0.double()) * deg_hi[:, None]
+    b0 = g0.double() * s_lo + (1 - g0.double()) * s_hi
+    a1 = g1.double() * deg_lo[:, None] + (1 - g1.double()) * deg_hi[:, None]
+    ref_h1 = torch.relu(a0[..., None] * p.double() + b0[..., None] * rv.double() +
+                        xd[..., None] * tv.double() + z.double())
+    _close(h1.view(n, Q, 64), ref_h1, rtol=1e-4, atol=1e-3)
+    _close(scal.view(n, Q, 2)[..., 0], a1, atol=1e-5)
+    _close(scal.view(n, Q, 2)[..., 1], xd)
+
+    h = torch.randn(n * Q, 64, generator=g)
+    got = ops.gossip_gather(h.to(DEV), ptr.to(DEV), col.to(DEV), n, Q, g1.to(DEV))
+    hd = h.double().view(n, Q, 64)
+    w = lo[:, None] * g1.double() + (1 - lo)[:, None] * (1 - g1.double())      # [E,Q]
+    ref = torch.zeros(n, Q, 64, dtype=torch.double).index_add_(0, r, hd[c] * w[..., None])
+    _close(got.view(n, Q, 64), ref, atol=1e-4)

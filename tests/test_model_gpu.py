@@ -1,0 +1,107 @@
+"""Model-level parity on the GPU: HIP path (through the C ABI) vs. the CPU oracle in the reference's
+form, same seeded weights, golden-fixture graphs.  fp32 tolerance: rtol 1e-4 / atol 1e-4 on the
+log-space head outputs and on gossip corrections (different but equivalent summation orders and
+folded weights; both sides are fp32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from desco_amd.batch import GossipBatch, NeighborhoodBatch, QueryBatch  # noqa: E402
+from desco_amd.graphs import GraphSet  # noqa: E402
+from desco_amd.partition import build_partition  # noqa: E402
+from oracle import model as OM  # noqa: E402
+from oracle import partition as OP  # noqa: E402
+
+from helpers import cpu_sd, golden_graphs, make_models, report, standard_queries  # noqa: E402
+
+DEV = "cuda"
+RTOL, ATOL = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def setup():
+    nm, gm = make_models(seed=0)
+    qids, queries = standard_queries()
+    nm = nm.to(DEV)
+    gm = gm.to(DEV)
+    nm.set_queries(qids)
+    return nm, gm, qids, queries
+
+
+def test_query_embeddings(setup):
+    nm, gm, qids, queries = setup
+    got = nm.get_query_emb()
+    ref = OM.neighborhood_embed_queries(cpu_sd(nm), OP.query_batch(queries), 8)
+    report("query_emb", got, ref)
+    torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("quirk", [0, 512, 16])
+def test_neighborhood_logits_vs_oracle(setup, quirk):
+    nm, gm, qids, queries = setup
+    graphs = golden_graphs(max_n=60)
+    gs = GraphSet.from_edge_lists(graphs)
+    part = build_partition(gs, 4, quirk_batch=quirk)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    sd, qb = cpu_sd(nm), OP.query_batch(queries)
+    bs = quirk if quirk else len(neighs)
+    refs = []
+    for b0 in range(0, len(neighs), bs):
+        ob = OP.neighborhood_batch(neighs[b0:b0 + bs])
+        refs.append(OM.neighborhood_logits(sd, ob, qb, emulate_quirk=bool(quirk))[0])
+    ref = torch.cat(refs)
+    batch = NeighborhoodBatch(part, DEV)
+    with torch.no_grad():
+        got = nm._logits(batch, exp2=False)
+    report(f"neigh_logits quirk={quirk}", got, ref)
+    torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=ATOL)
+    cnt = nm.graph_to_count(batch)
+    torch.testing.assert_close(cnt.cpu(), 2 ** ref - 1, rtol=1e-3, atol=1e-3)
+
+
+def test_neighborhood_batch_slicing_equals_full(setup):
+    nm, *_ = setup
+    graphs = golden_graphs(max_n=60)
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    full = nm.graph_to_count(NeighborhoodBatch(part, DEV))
+    parts = [nm.graph_to_count(NeighborhoodBatch(part.slice(b0, b0 + 100), DEV))
+             for b0 in range(0, part.num_neigh, 100)]
+    torch.testing.assert_close(torch.cat(parts), full, rtol=1e-5, atol=1e-5)
+
+
+def test_gossip_vs_oracle(setup):
+    nm, gm, qids, queries = setup
+    graphs = golden_graphs(max_n=60)
+    gs = GraphSet.from_edge_lists(graphs)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(gs.num_nodes, len(queries), generator=g) * 30
+    x[torch.rand(gs.num_nodes, generator=g) < 0.2] = 0
+    qemb = nm.get_query_emb()
+    gm.set_query_emb(qemb)
+    batch = GossipBatch(gs, DEV, x=x)
+    got = gm.graph_to_count(batch)
+    ref = OM.gossip_graph_to_count(cpu_sd(gm), x, batch.edge_index.numpy(), qemb.cpu(), 2)
+    report("gossip_pred", got, ref)
+    report("gossip_corr", got.cpu() - x, ref - x)
+    torch.testing.assert_close(got.cpu() - x, ref - x, rtol=RTOL, atol=ATOL)
+    gates = gm._gate_value(qemb)
+    torch.testing.assert_close(gates.cpu(), OM.gossip_gate_values(cpu_sd(gm), qemb.cpu()),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_end_to_end_pipeline_vs_oracle(setup):
+    """neighborhood counts -> scatter to nodes -> gossip -> per-graph aggregation (main.py:296-423)."""
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    graphs = golden_graphs(max_n=60)
+    gs = GraphSet.from_edge_lists(graphs)
+    ref = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), graphs, queries, emulate_quirk=False)
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV)
+    out = pipe.run()
+    assert (pipe.partition.neigh_index == ref["index"]).all()
+    assert (pipe.partition.indicator == ref["indicator"]).all()
+    for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
+        report(k, out[k], ref[k])
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
