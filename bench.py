@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- graphs/sec of the DeSCo hot path (29-query neighborhood + gossip inference).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full pass of the hot path (neighborhood counting -> apply_neighborhood_count ->
+gossip propagation -> per-graph aggregation, main.py:296-302, 417-423 of the reference) over the
+rank's resident shard: a COX2-shaped synthetic dataset (467 graphs, BASELINE.json configs[1])
+replicated ``--replicas`` times so that one pass saturates the GPU.  Inputs (CSR blocks, weights)
+are resident in HBM before the timed region.  Data parallel over graphs, no data-path collective
+(weak scaling: every rank owns the same number of graphs).
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  "roofline":     dominant kernel, achieved vs peak from HIP events recorded live in the timed region
+  "cpu_baseline": the CPU oracle (reference-form torch port) timed on a bounded sample (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s, ~6.3 achievable)
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (same guide)
+MFMA_KERNELS = {"gemm_f32_kernel", "shmp_layer_f32_kernel", "gossip_fused_kernel"}
+
+
+def build_models(device, seed=0):
+    """Random-init weights of the reference architecture (no checkpoint is reachable offline):
+    default nn.Linear init, matrices widened so that 8 relu layers keep O(1), finite activations."""
+    from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
+    na = argparse.Namespace(layer_num=8, conv_type="SAGE", use_hetero=True, dropout=0.0, depth=4,
+                            lr=1e-4, weight_decay=0.0, use_tconv=True, hidden_dim=64, input_dim=1,
+                            batch_size=512)
+    ga = argparse.Namespace(layer_num=2, conv_type="GOSSIP", use_hetero=False, dropout=0.0,
+                            lr=1e-3, weight_decay=0.0, hidden_dim=64, batch_size=256)
+    torch.manual_seed(seed)
+    nm = NeighborhoodCountingModel(1, 64, na).to_hetero_old(True, True)
+    gm = GossipCountingModel(1, 64, ga, emb_channels=64, input_pattern_emb=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m, gain in ((nm, 1.3), (gm, 1.4)):
+            for p in m.parameters():
+                if p.dim() == 2:
+                    p.mul_(gain)
+                else:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+    return nm.to(device), gm.to(device)
+
+
+def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=15.0):
+    """The CPU oracle in the reference's form on a bounded sample of the same workload."""
+    from oracle import model as OM
+    sd_n = {k: v.detach().cpu().float() for k, v in nm.state_dict().items()}
+    sd_g = {k: v.detach().cpu().float() for k, v in gm.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    probe = graphs_host[:4]
+    t0 = time.perf_counter()
+    OM.reference_pipeline(sd_n, sd_g, probe, queries, emulate_quirk=False)
+    per_graph = (time.perf_counter() - t0) / len(probe)
+    n = int(max(4, min(len(graphs_host), target_seconds / max(per_graph, 1e-6))))
+    sample = graphs_host[:n]
+    t0 = time.perf_counter()
+    ref = OM.reference_pipeline(sd_n, sd_g, sample, queries, emulate_quirk=False)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} graphs of the COX2-shaped set (incl. canonical partition), "
+                      f"reference-form batches 512/256, {dt:.1f} s, torch fp32, {cores} threads"}, ref, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cox2", choices=["cox2", "mutag", "syn_1827", "msrc_imdb"])
+    ap.add_argument("--replicas", type=int, default=64, help="dataset replication factor per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from desco_amd import ops, synthetic
+    from desco_amd.data import STANDARD_QUERY_IDS
+    from desco_amd.pipeline import InferencePipeline
+
+    base = synthetic.WORKLOADS[args.workload]()
+    graphs = base.replicate(args.replicas)
+    nm, gm = build_models(device)
+    nm.set_queries(STANDARD_QUERY_IDS)
+    t0 = time.perf_counter()
+    pipe = InferencePipeline(nm, gm, graphs, depth=4, device=device)
+    t_build = time.perf_counter() - t0
+    part = pipe.partition
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = pipe.run()
+    sync()
+    ops.PROFILER.enabled = not args.no_profile
+    ops.PROFILER.reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.run()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only exchange of the inference path: graph-level counts to rank 0
+        gathered = [torch.empty_like(out["graph_gossip_count"]) for _ in range(world)] if rank == 0 else None
+        dist.gather(out["graph_gossip_count"], gathered, dst=0)
+
+    graphs_per_step = graphs.num_graphs * world
+    value = graphs_per_step * args.steps / elapsed
+    result = {
+        "metric": "graphs/sec (29-query neighborhood+gossip inference)",
+        "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}-shaped synthetic ({base.num_graphs} graphs) x{args.replicas} "
+                        f"replicas per GPU, 29 standard queries, depth-4 canonical neighborhoods, "
+                        f"neighborhood+gossip inference, random-init weights",
+            "graphs_per_gpu": graphs.num_graphs, "nodes_per_gpu": graphs.num_nodes,
+            "neighborhoods_per_gpu": part.num_neigh, "neighborhood_rows_per_gpu": part.num_rows,
+            "neighborhood_directed_edges_per_gpu": part.num_edges,
+            "parallelism": f"dp{world} (graph sharding, no data-path collective)",
+            "host_partition_build_s": round(t_build, 3),
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from the HIP events of the timed region -----------
+        roof = None
+        if not args.no_profile:
+            summ = ops.PROFILER.summary()
+            tot = sum(d["ms"] for d in summ.values())
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            calls = d["calls"]
+            if name in MFMA_KERNELS:
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
+            else:
+                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
+            roof.update({"kernel": name, "launches": calls, "avg_launch_ms": d["ms"] / calls,
+                         "share_of_kernel_time": d["ms"] / tot,
+                         "algorithmic_per_launch": (d["flops"] if roof["bound"] == "mfma" else d["bytes"]) / calls})
+            result["roofline"] = roof
+            result["kernels"] = {
+                k: {"calls": v["calls"], "ms": round(v["ms"], 3),
+                    "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 else None,
+                    "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        # ---- CPU baseline (N=1 only) + parity of the sample ------------------------------------
+        if world == 1 and not args.no_cpu_baseline:
+            with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as f:
+                qj = json.load(f)
+            queries = [(q["n"], [tuple(e) for e in q["edges"]]) for q in qj["queries"]]
+            cb, ref, n = cpu_baseline(nm, gm, base.edge_lists(), queries, args.cpu_seconds)
+            got = out["graph_gossip_count"][:n].cpu()
+            err = (got - ref["graph_gossip_count"]).abs().max().item()
+            cb["max_abs_diff_vs_gpu"] = err
+            result["cpu_baseline"] = cb
+            result["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

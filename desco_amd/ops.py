@@ -15,6 +15,54 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing on the launch stream (used by bench.py's roofline leg).
+
+    When enabled every wrapper brackets its single kernel launch with two events recorded on the
+    current stream and notes the launch's algorithmic flops / bytes."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []      # (kernel, flops, bytes, start_event, end_event)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """kernel -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+PROFILER = LaunchProfiler()
+
+
+class _Timed:
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILER.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILER.enabled:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILER.records.append((self.name, self.flops, self.bytes, self.e0, e1))
+        return False
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -51,8 +99,9 @@ def linear_smallk(feat: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Ten
     op, ldo = _rows(out, "out")
     wt = wt.contiguous()
     L = _lib.lib()
-    _lib.check(L.desco_linear_smallk_f32(fp, ldf, k, _dev(wt, "wt"), _opt(bias, "bias"), op, ldo,
-                                         m, n, _stream()), "linear_smallk")
+    with _Timed("linear_smallk_kernel", 2.0 * m * k * n, 4.0 * (m * k + m * n)):
+        _lib.check(L.desco_linear_smallk_f32(fp, ldf, k, _dev(wt, "wt"), _opt(bias, "bias"), op,
+                                             ldo, m, n, _stream()), "linear_smallk")
     return out
 
 
@@ -64,9 +113,12 @@ def csr_gather_sum(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, n
     assert out.is_contiguous() and x.shape[1] == 64
     xp, ldx = _rows(x, "x")
     L = _lib.lib()
-    _lib.check(L.desco_csr_gather_sum_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
-                                          _dev(vcol, "vcol", torch.int32), num_rows, slots,
-                                          _dev(out, "out"), _stream()), "csr_gather_sum")
+    # algorithmic bytes: every source row once + indices + the S aggregate rows
+    nb = 256.0 * x.shape[0] + 4.0 * (vcol.numel() + num_rows * slots + 1) + 256.0 * num_rows * slots
+    with _Timed("csr_gather_sum_kernel", float(vcol.numel()) * 64, nb):
+        _lib.check(L.desco_csr_gather_sum_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
+                                              _dev(vcol, "vcol", torch.int32), num_rows, slots,
+                                              _dev(out, "out"), _stream()), "csr_gather_sum")
     return out
 
 
@@ -95,9 +147,11 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
         assert s.is_contiguous() and s.shape[0] == m and ws is not None and ws.is_contiguous()
         ns = s.shape[1]
     L = _lib.lib()
-    _lib.check(L.desco_gemm_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(wt, "wt"), n,
-                                _opt(bias, "bias"), bias_rows, _opt(s, "s"), ns, _opt(ws, "ws"),
-                                act, slope, op, ldo, m, _stream()), "gemm")
+    kk = k1 + k2
+    with _Timed("gemm_f32_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n + m * ns)):
+        _lib.check(L.desco_gemm_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(wt, "wt"), n,
+                                    _opt(bias, "bias"), bias_rows, _opt(s, "s"), ns,
+                                    _opt(ws, "ws"), act, slope, op, ldo, m, _stream()), "gemm")
     return out
 
 
@@ -112,8 +166,10 @@ def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
     op, ldo = _rows(out, "out")
     ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
     L = _lib.lib()
-    _lib.check(L.desco_segment_sum_f32(xp, ldx, ncols, _dev(seg_ptr, "seg_ptr", torch.int32),
-                                       num_seg, ep, lde, op, ldo, _stream()), "segment_sum")
+    with _Timed("segment_sum_kernel", float(x.shape[0]) * ncols,
+                4.0 * (x.shape[0] * ncols + 2 * num_seg * ncols + num_seg)):
+        _lib.check(L.desco_segment_sum_f32(xp, ldx, ncols, _dev(seg_ptr, "seg_ptr", torch.int32),
+                                           num_seg, ep, lde, op, ldo, _stream()), "segment_sum")
     return out
 
 
@@ -126,9 +182,10 @@ def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2: float, s
     tp, ldt = _rows(t, "t")
     qp, ldq = _rows(qh, "qh")
     L = _lib.lib()
-    _lib.check(L.desco_count_head_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"), b2,
-                                      slope, int(exp2_minus_1), _dev(out, "out"), Q, B, Q,
-                                      _stream()), "count_head")
+    with _Timed("count_head_kernel", 4.0 * B * Q * hid, 4.0 * (B * hid + Q * hid + B * Q)):
+        _lib.check(L.desco_count_head_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"), b2,
+                                          slope, int(exp2_minus_1), _dev(out, "out"), Q, B, Q,
+                                          _stream()), "count_head")
     return out
 
 
@@ -137,8 +194,10 @@ def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor) -> to
     sp, lds = _rows(src, "src")
     dp, ldd = _rows(dst, "dst")
     L = _lib.lib()
-    _lib.check(L.desco_scatter_rows_f32(sp, lds, _dev(rows, "rows", torch.int32), src.shape[0],
-                                        src.shape[1], dp, ldd, _stream()), "scatter_rows")
+    with _Timed("scatter_rows_kernel", 0.0, 8.0 * src.numel() + 4.0 * src.shape[0]):
+        _lib.check(L.desco_scatter_rows_f32(sp, lds, _dev(rows, "rows", torch.int32),
+                                            src.shape[0], src.shape[1], dp, ldd, _stream()),
+                   "scatter_rows")
     return dst
 
 
@@ -149,7 +208,9 @@ def gossip_layer0(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, 
     scal = torch.empty((N * Q, 2), device=x.device, dtype=torch.float32)
     xp, ldx = _rows(x, "x")
     L = _lib.lib()
-    _lib.check(L.desco_gossip_layer0_f32(xp, ldx, _dev(rowptr, "rowptr", torch.int32),
+    with _Timed("gossip_layer0_kernel", 8.0 * N * Q * 64,
+                4.0 * (N * Q + col.numel() + N) + N * Q * (256.0 + 8.0)):
+      _lib.check(L.desco_gossip_layer0_f32(xp, ldx, _dev(rowptr, "rowptr", torch.int32),
                                          _dev(col, "col", torch.int32), N, Q,
                                          _dev(g0.contiguous(), "g0"), _dev(g1.contiguous(), "g1"),
                                          _dev(p.contiguous(), "p"), _dev(r.contiguous(), "r"),
@@ -165,7 +226,9 @@ def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_
     assert h.is_contiguous()
     out = torch.empty_like(h)
     L = _lib.lib()
-    _lib.check(L.desco_gossip_gather_f32(_dev(h, "h"), _dev(rowptr, "rowptr", torch.int32),
+    with _Timed("gossip_gather_kernel", 2.0 * col.numel() * num_q * 64,
+                512.0 * num_nodes * num_q + 4.0 * (col.numel() + num_nodes)):
+      _lib.check(L.desco_gossip_gather_f32(_dev(h, "h"), _dev(rowptr, "rowptr", torch.int32),
                                          _dev(col, "col", torch.int32), num_nodes, num_q,
                                          _dev(g.contiguous(), "g"), _dev(out, "out"), _stream()),
                "gossip_gather")
@@ -178,7 +241,8 @@ def rowdot_add(y: torch.Tensor, w: torch.Tensor, b: float, add: Optional[torch.T
     out = torch.empty((R,), device=y.device, dtype=torch.float32)
     yp, ldy = _rows(y, "y")
     L = _lib.lib()
-    _lib.check(L.desco_rowdot_add_f32(yp, ldy, n, _dev(w.contiguous(), "w"), b,
-                                      _opt(add, "add"), _dev(out, "out"), R, _stream()),
-               "rowdot_add")
+    with _Timed("rowdot_add_kernel", 2.0 * R * n, 4.0 * (R * n + 2 * R)):
+        _lib.check(L.desco_rowdot_add_f32(yp, ldy, n, _dev(w.contiguous(), "w"), b,
+                                          _opt(add, "add"), _dev(out, "out"), R, _stream()),
+                   "rowdot_add")
     return out

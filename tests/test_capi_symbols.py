@@ -1,0 +1,53 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/desco_hip.h declares.
+No compute entry point is called (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from desco_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "desco_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(desco_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/desco_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    assert L.desco_abi_version() == 1
+
+
+def test_argument_errors_are_reported_not_crashed():
+    L = _lib.lib()
+    rc = L.desco_gemm_f32(None, 0, 48, None, 0, 0, None, 64, None, 1, None, 0, None, 0, 0.0, None,
+                          64, 5, None)
+    assert rc == -1
+    assert b"desco_gemm_f32" in L.desco_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "gemm")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from desco_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.csr_gather_sum(torch.zeros(4, 64), torch.zeros(5, dtype=torch.int32),
+                           torch.zeros(0, dtype=torch.int32), 1, 4)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DescoLibraryError, match="no CPU or PyTorch fallback"):
+        _lib.lib()

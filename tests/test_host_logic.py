@@ -1,0 +1,133 @@
+"""Host-side mirror of the reference API: config defaults, metrics, queries, state-dict names,
+workload bookkeeping -- all CPU."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import gossip_args, make_models, neigh_args, standard_queries
+
+
+def test_config_defaults_match_reference():
+    from desco_amd import config
+    p = argparse.ArgumentParser()
+    config.parse_neighborhood(p)
+    config.parse_gossip(p)
+    config.parse_optimizer(p)
+    ns = vars(p.parse_args([]))
+    assert ns == load_golden("config_defaults.json")
+    n, g, o = config.split_namespaces(p.parse_args(["--neigh_layer_num", "3", "--gpu", "0", "1"]))
+    assert n.layer_num == 3 and n.conv_type == "SAGE" and n.depth == 4 and g.lr == 1e-3
+    assert g.conv_type == "GOSSIP" and o.gpu == [0, 1] and n.batch_size == 512 and g.batch_size == 256
+
+
+def test_metrics_match_reference():
+    from desco_amd import analysis
+    m = load_golden("metrics.json")
+    pred, truth = np.array(m["pred"], dtype=np.float32), np.array(m["truth"], dtype=np.float32)
+    np.testing.assert_allclose(analysis.norm_mse(pred, truth, m["groups"]), m["norm_mse"], rtol=1e-12)
+    np.testing.assert_allclose(analysis.mse(pred, truth, m["groups"]), m["mse"], rtol=1e-12)
+    np.testing.assert_allclose(analysis.mae(pred, truth, m["groups"]), m["mae"], rtol=1e-6)
+    np.testing.assert_allclose(analysis.norm_mse(pred, truth), m["norm_mse_all"], rtol=1e-12)
+
+
+def test_query_ids_and_atlas(queries_golden):
+    from desco_amd import data
+    assert data.gen_query_ids([3, 4, 5]) == queries_golden["query_ids"] == data.STANDARD_QUERY_IDS
+    for q in queries_golden["queries"]:
+        g = data.graph_atlas_plus(q["atlas_id"])
+        assert g.number_of_nodes() == q["n"]
+        assert sorted((min(a, b), max(a, b)) for a, b in g.edges()) == [tuple(e) for e in q["edges"]]
+    with pytest.raises(NotImplementedError):
+        data.graph_atlas_plus(8000)
+
+
+def test_state_dict_names_and_sizes():
+    nm, gm = make_models()
+    ks = set(nm.state_dict())
+    for k in ["emb_model.gnn_core.pre_mp.0.count.weight",
+              "emb_model.gnn_core.convs.7.canonical__union_tride__count.lin.bias",
+              "emb_model.gnn_core.convs.0.count__union_triangle__canonical.lin.weight",
+              "emb_model.gnn_core.updates.3.canonical.weight", "emb_model.anchor_mlp.0.weight",
+              "emb_model.post_mp.7.bias", "emb_model_query.gnn_core.pre_mp.0.union_node.bias",
+              "emb_model_query.gnn_core.convs.2.union_node__union_tride__union_node.lin.weight",
+              "count_model.0.weight", "count_model.2.bias"]:
+        assert k in ks, k
+    assert sum(p.numel() for p in nm.parameters()) == 1311105
+    assert sum(p.numel() for p in nm.emb_model.parameters()) == 738560
+    assert sum(p.numel() for p in nm.emb_model_query.parameters()) == 539264
+    assert sum(p.numel() for p in gm.parameters()) == 144899
+    gk = set(gm.state_dict())
+    assert {"emb_model.gnn_core.convs.1.lin_gate.2.weight", "emb_model.gnn_core.convs.0.lin_com.weight",
+            "emb_model.gnn_core.convs.0.lin_update.bias", "emb_model.post_mp.7.weight"} <= gk
+    assert gm.emb_model.gnn_core.convs[0].lin_update.weight.shape == (64, 192)
+    assert gm.emb_model.post_mp[0].weight.shape == (64, 256)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
+    nm, gm = make_models(seed=3)
+    nm.save_checkpoint(tmp_path / "n.ckpt")
+    gm.save_checkpoint(tmp_path / "g.ckpt")
+    nm2 = NeighborhoodCountingModel.load_from_checkpoint(tmp_path / "n.ckpt")
+    gm2 = GossipCountingModel.load_from_checkpoint(tmp_path / "g.ckpt")
+    for a, b in ((nm, nm2), (gm, gm2)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert nm2.depth == 4 and nm2.emb_model.gnn_core.node_types == ["count", "canonical"]
+
+
+def test_model_refuses_cpu_batches():
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.graphs import GraphSet
+    from desco_amd.partition import build_partition
+    nm, _ = make_models()
+    nm.set_queries(standard_queries()[0])
+    part = build_partition(GraphSet.from_edge_lists([(3, [(0, 1), (1, 2)])]), 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nm.graph_to_count(NeighborhoodBatch(part, "cpu"))
+
+
+def test_set_queries_warns_on_small_depth():
+    from desco_amd.lightning_model import NeighborhoodCountingModel
+    nm = NeighborhoodCountingModel(1, 64, neigh_args(depth=1)).to_hetero_old(True, True)
+    with pytest.warns(UserWarning, match="too small"):
+        nm.set_queries([6, 14])
+
+
+def test_workload_bookkeeping(tmp_path):
+    from desco_amd.graphs import GraphSet
+    from desco_amd.workload import Workload
+    graphs = [(8, [(0, 1), (1, 2), (2, 3), (3, 0), (0, 2), (3, 4), (4, 5), (5, 6), (6, 7), (7, 2)]),
+              (3, [(0, 1)])]
+    w = Workload(GraphSet.from_edge_lists(graphs), str(tmp_path))
+    w.generate_pipeline_datasets(depth_neigh=4)
+    nd = w.neighborhood_dataset
+    assert nd.nx_neighs_indicator.tolist() == [False] + [True] * 7 + [False, True, False]
+    assert nd.nx_neighs_index.tolist() == [[0, v] for v in range(1, 8)] + [[1, 1]]
+    # reference file names / dtypes of the interchange pair (workload.py:197-213, 293-294)
+    pdir = tmp_path / "NeighborhoodDataset" / "processed"
+    idx = np.load(pdir / "neighs_index_depth_4.npy")
+    ind = np.load(pdir / "neighs_indicator_depth_4.npy")
+    assert idx.dtype == np.int64 and ind.dtype == bool and idx.shape == (8, 2)
+    count = torch.arange(8 * 3, dtype=torch.float).reshape(8, 3)
+    w.apply_neighborhood_count(count)
+    x = w.gossip_dataset.x
+    assert x.shape == (11, 3) and x[0].abs().sum() == 0 and torch.equal(x[1], count[0]) and torch.equal(x[9], count[7])
+    assert torch.equal(nd.aggregate_neighborhood_count(count),
+                       torch.stack([count[:7].sum(0), count[7]]))
+    assert torch.equal(w.gossip_dataset.aggregate_neighborhood_count(x),
+                       torch.stack([x[:8].sum(0), x[8:].sum(0)]))
+    # cache is re-used
+    w2 = Workload(GraphSet.from_edge_lists(graphs), str(tmp_path))
+    w2.generate_pipeline_datasets(depth_neigh=4)
+    assert (w2.neighborhood_dataset.partition.vcol == nd.partition.vcol).all()
+    sizes = [b.num_graphs for b in nd.batches(3)]
+    assert sizes == [3, 3, 2]
+    truth = torch.arange(11 * 2, dtype=torch.double).reshape(11, 2)
+    nd.apply_truth_from_dataset(truth)
+    assert torch.equal(nd.y, truth[torch.from_numpy(nd.nx_neighs_indicator)])
