@@ -96,7 +96,7 @@ def base_gnn_hetero(sd, prefix, batch: Dict, node_types, edge_types, layer_num, 
         emb["canonical"] = F.leaky_relu(_lin(sd, f"{prefix}.anchor_mlp.0", emb["canonical"]), 0.1)
     allemb = torch.cat([emb[t] for t in node_types], dim=0)                          # :88-89
     bvec = torch.cat([_t(batch["batch"][t]).long() for t in node_types])
-    pooled = torch.zeros(batch["num_graphs"], allemb.shape[1])
+    pooled = torch.zeros(batch["num_graphs"], allemb.shape[1], dtype=allemb.dtype)
     pooled.index_add_(0, bvec, allemb)                                              # :107 global_add_pool
     return post_mp(sd, prefix, pooled)                                              # :108
 
@@ -166,7 +166,7 @@ def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2):
         msg = _lin(sd, key + ".lin_com", x[ei[0]])                                  # :341 (x_j)
         msg[dirw] *= gate                                                           # :342
         msg[~dirw] *= 1 - gate                                                      # :343
-        aggr = torch.zeros(N, msg.shape[1]).index_add_(0, ei[1], msg)               # aggr="add"
+        aggr = torch.zeros(N, msg.shape[1], dtype=msg.dtype).index_add_(0, ei[1], msg)               # aggr="add"
         x = _lin(sd, key + ".lin_update", torch.cat((aggr, x), dim=-1))             # :347-348
         x = F.relu(x)                                                               # :273
         emb = torch.cat((emb, x), dim=1)                                            # :275
