@@ -53,48 +53,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int arow = tid >> 3, ac4 = tid & 7;    // A: 8 threads x float4 cover one 32-float row
   const int brow = tid >> 4, bc4 = tid & 15;   // B: 16 threads x float4 cover one 64-float row
 
-  int64_t arows[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t r = m0 + arow + 32 * i;
-    arows[i] = r < g.m ? r : g.m - 1;
-  }
+  // Per-thread element offsets of its 4 A rows in both K segments (kept in registers: no arrays
+  // indexed at run time, no lambdas -- hipcc otherwise parks the prefetch registers in scratch).
+  int64_t r0 = m0 + arow, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
+  const int64_t mlast = g.m - 1;
+  r0 = r0 < g.m ? r0 : mlast;
+  r1 = r1 < g.m ? r1 : mlast;
+  r2 = r2 < g.m ? r2 : mlast;
+  r3 = r3 < g.m ? r3 : mlast;
+  const float* p10 = g.a1 + r0 * g.lda1 + 4 * ac4;
+  const float* p11 = g.a1 + r1 * g.lda1 + 4 * ac4;
+  const float* p12 = g.a1 + r2 * g.lda1 + 4 * ac4;
+  const float* p13 = g.a1 + r3 * g.lda1 + 4 * ac4;
+  const float* p20 = g.k2 ? g.a2 + r0 * g.lda2 + 4 * ac4 - g.k1 : p10;
+  const float* p21 = g.k2 ? g.a2 + r1 * g.lda2 + 4 * ac4 - g.k1 : p11;
+  const float* p22 = g.k2 ? g.a2 + r2 * g.lda2 + 4 * ac4 - g.k1 : p12;
+  const float* p23 = g.k2 ? g.a2 + r3 * g.lda2 + 4 * ac4 - g.k1 : p13;
+  const float* pb = g.wt + (int64_t)brow * g.n + n0 + 4 * bc4;
+  const int64_t bstep = (int64_t)16 * g.n;
 
-  float4 ra[4], rb[2];
-  auto load_chunk = [&](int ch) {
-    const int kk = ch * BK;
-    const float* ab;
-    int64_t lda;
-    if (kk < g.k1) {
-      ab = g.a1 + kk;
-      lda = g.lda1;
-    } else {
-      ab = g.a2 + (kk - g.k1);
-      lda = g.lda2;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      ra[i] = *reinterpret_cast<const float4*>(ab + arows[i] * lda + 4 * ac4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      rb[i] = *reinterpret_cast<const float4*>(g.wt + (int64_t)(kk + brow + 16 * i) * g.n + n0 +
-                                               4 * bc4);
-  };
-  auto store_chunk = [&](int buf) {
-    float* a = As + buf * BM * ASTR;
-    float* b = Bs + buf * BK * BN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* d = a + (arow + 32 * i) * ASTR + 4 * ac4;
-      d[0] = ra[i].x;
-      d[1] = ra[i].y;
-      d[2] = ra[i].z;
-      d[3] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(b + (brow + 16 * i) * BN + 4 * bc4) = rb[i];
-  };
+  float4 ra0, ra1, ra2, ra3, rb0, rb1;
+#define DESCO_LOAD_CHUNK(kk_)                                                     \
+  {                                                                               \
+    const int k_ = (kk_);                                                         \
+    const bool s1_ = k_ < g.k1;                                                   \
+    ra0 = *reinterpret_cast<const float4*>((s1_ ? p10 : p20) + k_);               \
+    ra1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);               \
+    ra2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);               \
+    ra3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);               \
+    rb0 = *reinterpret_cast<const float4*>(pb + (int64_t)k_ * g.n);               \
+    rb1 = *reinterpret_cast<const float4*>(pb + (int64_t)k_ * g.n + bstep);       \
+  }
+#define DESCO_STORE_A(dst_, v_)  \
+  {                              \
+    float* d_ = (dst_);          \
+    d_[0] = (v_).x;              \
+    d_[1] = (v_).y;              \
+    d_[2] = (v_).z;              \
+    d_[3] = (v_).w;              \
+  }
+#define DESCO_STORE_CHUNK(buf_)                                                        \
+  {                                                                                    \
+    float* a_ = As + (buf_)*BM * ASTR + arow * ASTR + 4 * ac4;                         \
+    float* b_ = Bs + (buf_)*BK * BN + brow * BN + 4 * bc4;                             \
+    DESCO_STORE_A(a_, ra0)                                                             \
+    DESCO_STORE_A(a_ + 32 * ASTR, ra1)                                                 \
+    DESCO_STORE_A(a_ + 64 * ASTR, ra2)                                                 \
+    DESCO_STORE_A(a_ + 96 * ASTR, ra3)                                                 \
+    *reinterpret_cast<float4*>(b_) = rb0;                                              \
+    *reinterpret_cast<float4*>(b_ + 16 * BN) = rb1;                                    \
+  }
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -103,12 +111,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     acc1[i] = 0.f;
   }
 
-  load_chunk(0);
-  store_chunk(0);
+  DESCO_LOAD_CHUNK(0)
+  DESCO_STORE_CHUNK(0)
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    // unconditional prefetch of the next chunk (the last iteration re-reads its own chunk)
+    const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+    DESCO_LOAD_CHUNK(chn * BK)
     // MFMA 32x32x2 f32 operand maps: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
     const float* as = As + buf * BM * ASTR + (wave * 32 + (lane & 31)) * ASTR + (lane >> 5);
     const float* bs = Bs + buf * BK * BN + (lane >> 5) * BN + (lane & 31);
@@ -120,9 +130,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
     }
-    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+    DESCO_STORE_CHUNK(buf ^ 1)
     __syncthreads();
   }
+#undef DESCO_LOAD_CHUNK
+#undef DESCO_STORE_CHUNK
+#undef DESCO_STORE_A
 
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col = lane & 31;

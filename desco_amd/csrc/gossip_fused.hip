@@ -1,0 +1,327 @@
+// Fused gossip stage for gfx950: for a tile of 64 nodes and ONE query the whole per-query network
+// of the reference (BaseGNN gossip path, gnn_model.py:58-103, 230-260, 303-350; looped over queries
+// in lightning_model.py:613-628) runs on chip:
+//
+//   scalars (pre-pass kernel)  a0,b0,a1,x per (node,query)          -> scal4 [N*Q] float4
+//   h1   = relu(a0*p_q + b0*r + x*t + z_q)                           (layer 0, closed form)
+//   hh   = sum_j (j<i ? g1 : 1-g1) * h1_j                            (h1_j recomputed from j's scalars)
+//   h2   = relu([hh|h1] W1 + a1*u + d1)                              (layer 1, K=128)      MFMA
+//   y1   = leaky([h1|h2] Wp + x*tp + zp_q, 0.1)                      (post_mp.0, K=128)    MFMA
+//   y2   = relu(y1 W3 + b3)                                          (post_mp.3, K=64)     MFMA
+//   out  = x + b7 + sum_c relu(y2 W5 + b5)[c] * w7[c]                (post_mp.5/.7, N=256) MFMA
+//
+// Nothing but the 16-byte scalar records and the [N,Q] result crosses HBM (the unfused path moves
+// ~2.3 KB per (node,query)); the kernel is bound by the f32 MFMA rate (288 MFMAs per wave and tile).
+// Block = 4 waves, output tiles 64x64 as 2x2 wave tiles of 32x32 (v_mfma_f32_32x32x2_f32); three
+// 64x65 activation images + one 64x64 weight image in LDS (66 KB -> 2 blocks per CU); weight
+// blocks are prefetched into registers under the previous block's MFMAs.  Algebra: DESIGN.md 4.2.
+#include "common_device.hpp"
+
+namespace desco {
+
+constexpr int GT = 64;      // rows (nodes) per tile
+constexpr int GAS = 65;     // activation image row stride (floats)
+constexpr int ECAP = 768;   // neighbour records staged per pass (aliases the third image)
+
+struct GossipFusedArgs {
+  const float4* scal;       // [N*Q] (a0, b0, a1, x)
+  const int32_t* rowptr;
+  const int32_t* col;
+  int64_t num_nodes;
+  int Q;
+  const float* g1;          // [Q]
+  const float* p;           // [Q,64]
+  const float* z;           // [Q,64]
+  const float* zp;          // [Q,64]
+  const float* r;           // [64]
+  const float* t;           // [64]
+  const float* u;           // [64]  D1a c1
+  const float* tp;          // [64]  P0[:,64:128] w_pre
+  const float* d1;          // [64]
+  const float* w1;          // [128,64]
+  const float* wp;          // [128,64]
+  const float* w3;          // [64,64]
+  const float* b3;          // [64]
+  const float* w5;          // [64,256]
+  const float* b5;          // [256]
+  const float* w7;          // [256]
+  float b7;
+  float* out;               // [N,Q]
+};
+
+// scalars pre-pass: one wave per node, lane = query
+__global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             int64_t num_nodes, int Q,
+                                                             const float* __restrict__ g0,
+                                                             const float* __restrict__ g1,
+                                                             float4* __restrict__ scal) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= num_nodes) return;
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  const int q = lane < Q ? lane : Q - 1;
+  float slo = 0.f, shi = 0.f;
+  int dlo = 0;
+  for (int e = e0; e < e1; ++e) {
+    const int64_t j = col[e];
+    const float xv = x[j * ldx + q];
+    if (j < i) {
+      slo += xv;
+      ++dlo;
+    } else {
+      shi += xv;
+    }
+  }
+  const float flo = (float)dlo, fhi = (float)(e1 - e0 - dlo);
+  const float a = g0[q], b = g1[q];
+  if (lane < Q)
+    scal[i * Q + lane] = make_float4(a * flo + (1.f - a) * fhi, a * slo + (1.f - a) * shi,
+                                     b * flo + (1.f - b) * fhi, x[i * ldx + q]);
+}
+
+#define DESCO_WLOAD(src_, ld_)                                                          \
+  {                                                                                     \
+    const float* s_ = (src_) + (int64_t)(tid >> 4) * (ld_) + 4 * (tid & 15);            \
+    w0 = *reinterpret_cast<const float4*>(s_);                                          \
+    w1 = *reinterpret_cast<const float4*>(s_ + 16 * (int64_t)(ld_));                    \
+    w2 = *reinterpret_cast<const float4*>(s_ + 32 * (int64_t)(ld_));                    \
+    w3 = *reinterpret_cast<const float4*>(s_ + 48 * (int64_t)(ld_));                    \
+  }
+#define DESCO_WSTORE()                                                                  \
+  {                                                                                     \
+    float* d_ = Bs + (tid >> 4) * 64 + 4 * (tid & 15);                                  \
+    *reinterpret_cast<float4*>(d_) = w0;                                                \
+    *reinterpret_cast<float4*>(d_ + 16 * 64) = w1;                                      \
+    *reinterpret_cast<float4*>(d_ + 32 * 64) = w2;                                      \
+    *reinterpret_cast<float4*>(d_ + 48 * 64) = w3;                                      \
+  }
+// 32 MFMAs of one 64-deep K block: A image rows 32wr.., B image cols 32wc..
+#define DESCO_MFMA_BLOCK(Aimg_)                                                         \
+  {                                                                                     \
+    const float* as_ = (Aimg_) + (wr * 32 + (lane & 31)) * GAS + (lane >> 5);           \
+    const float* bs_ = Bs + (lane >> 5) * 64 + wc * 32 + (lane & 31);                   \
+    _Pragma("unroll") for (int kk = 0; kk < 32; ++kk) acc =                             \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(as_[2 * kk], bs_[2 * kk * 64], acc, 0, 0, 0); \
+  }
+#define DESCO_ACC_ZERO() \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[i_] = 0.f;
+
+__global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g) {
+  __shared__ float lds[3 * GT * GAS + 64 * 64 + 4 * GT + 68];
+  float* A0 = lds;                      // h1, later y2
+  float* A1 = lds + GT * GAS;           // hh, later y1
+  float* A2 = lds + 2 * GT * GAS;       // neighbour staging, later h2, later head partials
+  float* Bs = lds + 3 * GT * GAS;       // 64x64 weight block
+  float4* srow = reinterpret_cast<float4*>(Bs + 64 * 64);   // scalars of the tile rows
+  int* rp = reinterpret_cast<int*>(Bs + 64 * 64 + 4 * GT);  // rowptr[n0 .. n0+64]
+  int* ecol = reinterpret_cast<int*>(A2);                   // [ECAP]
+  float4* escal = reinterpret_cast<float4*>(A2 + ECAP);     // [ECAP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int q = blockIdx.y, Q = g.Q;
+  const int64_t n0 = (int64_t)blockIdx.x * GT;
+  const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
+
+  // first weight block (W1 rows 0..63) in flight while the tile is being assembled
+  float4 w0, w1, w2, w3;
+  DESCO_WLOAD(g.w1, 64)
+
+  // ---- phase 0: tile scalars + rowptr ------------------------------------------------------
+  if (tid < GT) {
+    const int64_t node = n0 + (tid < nrows ? tid : nrows - 1);
+    srow[tid] = g.scal[node * Q + q];
+  }
+  if (tid <= GT) rp[tid] = g.rowptr[n0 + (tid < nrows ? tid : nrows)];
+  const float gq = g.g1[q];
+  const float pc = g.p[q * 64 + lane], zc = g.z[q * 64 + lane];
+  const float rc = g.r[lane], tc = g.t[lane];
+  __syncthreads();
+
+  // ---- phase 1: h1 of the tile rows, gated neighbour sum hh ---------------------------------
+  float hh[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hh[k] = 0.f;
+  const int ebeg = rp[0], eend = rp[GT];
+  for (int base = ebeg; base < eend || base == ebeg; base += ECAP) {
+    const int cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
+    for (int e = tid; e < cnt; e += 256) {
+      const int j = g.col[base + e];
+      ecol[e] = j;
+      escal[e] = g.scal[(int64_t)j * Q + q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int row = wave * 16 + k;
+      const int node = (int)n0 + row;
+      int lo = rp[row] - base, hi = rp[row + 1] - base;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > cnt ? cnt : hi;
+      float a = hh[k];
+      for (int e = lo; e < hi; ++e) {
+        const float4 sj = escal[e];
+        float h = sj.x * pc + sj.y * rc + sj.w * tc + zc;
+        h = h > 0.f ? h : 0.f;
+        a += (ecol[e] < node ? gq : 1.f - gq) * h;
+      }
+      hh[k] = a;
+    }
+    __syncthreads();
+    if (eend == ebeg) break;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = wave * 16 + k;
+    const float4 si = srow[row];
+    float h = si.x * pc + si.y * rc + si.w * tc + zc;
+    A0[row * GAS + lane] = h > 0.f ? h : 0.f;
+    A1[row * GAS + lane] = hh[k];
+  }
+
+  f32x16 acc;
+  const int col = wc * 32 + (lane & 31);
+  // ---- G1: h2 = relu([hh|h1] W1 + a1*u + d1) -> A2 -----------------------------------------
+  DESCO_ACC_ZERO()
+  DESCO_WSTORE()
+  __syncthreads();
+  DESCO_WLOAD(g.w1 + 64 * 64, 64)
+  DESCO_MFMA_BLOCK(A1)
+  __syncthreads();
+  DESCO_WSTORE()
+  __syncthreads();
+  DESCO_WLOAD(g.wp, 64)
+  DESCO_MFMA_BLOCK(A0)
+  {
+    const float uc = g.u[col], dc = g.d1[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const float v = acc[reg] + srow[row].z * uc + dc;
+      A2[row * GAS + col] = v > 0.f ? v : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- G2: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> A1 ----------------------------------
+  DESCO_ACC_ZERO()
+  DESCO_WSTORE()
+  __syncthreads();
+  DESCO_WLOAD(g.wp + 64 * 64, 64)
+  DESCO_MFMA_BLOCK(A0)
+  __syncthreads();
+  DESCO_WSTORE()
+  __syncthreads();
+  DESCO_WLOAD(g.w3, 64)
+  DESCO_MFMA_BLOCK(A2)
+  {
+    const float tpc = g.tp[col], zpc = g.zp[q * 64 + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const float v = acc[reg] + srow[row].w * tpc + zpc;
+      A1[row * GAS + col] = v > 0.f ? v : 0.1f * v;
+    }
+  }
+  __syncthreads();
+  // ---- G3: y2 = relu(y1 W3 + b3) -> A0 ------------------------------------------------------
+  DESCO_ACC_ZERO()
+  DESCO_WSTORE()
+  __syncthreads();
+  DESCO_WLOAD(g.w5, 256)
+  DESCO_MFMA_BLOCK(A1)
+  {
+    const float bc = g.b3[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const float v = acc[reg] + bc;
+      A0[row * GAS + col] = v > 0.f ? v : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- G4/G5: head partials  sum_c relu(y2 W5 + b5)[c] * w7[c], 4 column groups of 64 --------
+  float part[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) part[k] = 0.f;
+#pragma unroll
+  for (int cg = 0; cg < 4; ++cg) {
+    DESCO_ACC_ZERO()
+    DESCO_WSTORE()
+    __syncthreads();
+    if (cg < 3) DESCO_WLOAD(g.w5 + 64 * (cg + 1), 256)
+    DESCO_MFMA_BLOCK(A0)
+    const float bc = g.b5[cg * 64 + col], wv = g.w7[cg * 64 + col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float v = acc[reg] + bc;
+      part[reg] += (v > 0.f ? v : 0.f) * wv;
+    }
+    __syncthreads();
+  }
+  // reduce the 64 column partials of every row through the (now free) A2 image
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    A2[row * GAS + col] = part[reg];
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 2, qt = tid & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += A2[row * GAS + qt * 16 + c];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (qt == 0 && row < nrows) g.out[(n0 + row) * Q + q] = s + g.b7 + srow[row].w;
+  }
+}
+
+#undef DESCO_WLOAD
+#undef DESCO_WSTORE
+#undef DESCO_MFMA_BLOCK
+#undef DESCO_ACC_ZERO
+
+}  // namespace desco
+
+using namespace desco;
+
+extern "C" int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr,
+                                        const int32_t* col, int64_t num_nodes, int num_q,
+                                        const float* g0, const float* g1, float* scal4,
+                                        desco_stream_t stream) {
+  if (num_nodes == 0) return 0;
+  if (!x || !rowptr || !g0 || !g1 || !scal4 || num_nodes < 0 || num_q < 1 || num_q > 64 ||
+      (reinterpret_cast<uintptr_t>(scal4) & 15))
+    return fail(DESCO_EINVAL, "desco_gossip_scalars_f32: bad argument (1 <= num_q <= 64)");
+  const int64_t blocks = (num_nodes + 3) / 4;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_scalars_f32: too many nodes");
+  hipLaunchKernelGGL(gossip_scalars_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, rowptr, col, num_nodes, num_q, g0, g1,
+                     reinterpret_cast<float4*>(scal4));
+  return launch_status("desco_gossip_scalars_f32");
+}
+
+extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
+                                      int64_t num_nodes, int num_q, const float* g1, const float* p,
+                                      const float* z, const float* zp, const float* r,
+                                      const float* t, const float* u, const float* tp,
+                                      const float* d1, const float* w1, const float* wp,
+                                      const float* w3, const float* b3, const float* w5,
+                                      const float* b5, const float* w7, float b7, float* out,
+                                      desco_stream_t stream) {
+  if (num_nodes == 0) return 0;
+  auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
+  if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !w1 || !wp ||
+      !w3 || !b3 || !w5 || !b5 || !w7 || !out || num_nodes < 0 || num_q < 1 || num_q > 65535 ||
+      mis16(scal4) || mis16(w1) || mis16(wp) || mis16(w3) || mis16(w5))
+    return fail(DESCO_EINVAL, "desco_gossip_fused_f32: bad argument");
+  const int64_t bx = (num_nodes + GT - 1) / GT;
+  if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f32: too many nodes");
+  GossipFusedArgs a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z,
+                    zp, r, t, u, tp, d1, w1, wp, w3, b3, w5, b5, w7, b7, out};
+  hipLaunchKernelGGL(gossip_fused_kernel, dim3((unsigned)bx, (unsigned)num_q), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return launch_status("desco_gossip_fused_f32");
+}

@@ -23,6 +23,10 @@ from . import ops
 from .batch import GossipBatch, NeighborhoodBatch, QueryBatch
 
 H = 64
+# one fused gather+MFMA launch per destination type and layer (False: gather kernel + GEMM)
+FUSED_SHMP_LAYER = True
+# scalars pre-pass + one on-chip kernel for the whole gossip network (False: 7 launches via HBM)
+FUSED_GOSSIP = True
 
 TARGET_NODE_TYPES = ["count", "canonical"]
 # metadata of to_hetero_old(tconv_target=True), lightning_model.py:376-383
@@ -292,13 +296,19 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         ops.linear_smallk(feat[r0:r1], wt, b, out=x[r0:r1])               # :231
     X = [x]
     for l in range(core.layer_num):
-        agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
         xn = torch.empty((N, H), device=dev)
-        for t, r0, r1, su in groups:
-            if r1 > r0:
-                wt, b = pk["layers"][l][t]
-                ops.gemm(agg[r0:r1, :su * H], wt, b, a2=X[-1][r0:r1], act=ops.ACT_RELU,
-                         out=xn[r0:r1])                                    # :262-264, :273
+        if FUSED_SHMP_LAYER:
+            for t, r0, r1, su in groups:                                   # :262-264, :273, :389-395
+                if r1 > r0:
+                    wt, b = pk["layers"][l][t]
+                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su, wt, b, xn)
+        else:
+            agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
+            for t, r0, r1, su in groups:
+                if r1 > r0:
+                    wt, b = pk["layers"][l][t]
+                    ops.gemm(agg[r0:r1, :su * H], wt, b, a2=X[-1][r0:r1], act=ops.ACT_RELU,
+                             out=xn[r0:r1])
         X.append(xn)
     B = batch.num_graphs
     P = H * (core.layer_num + 1)
@@ -382,6 +392,13 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
     N, Q = x.shape
     if Q != query_emb.shape[0]:
         raise ValueError("batch.x has a different number of query columns than query_emb rows")
+    if FUSED_GOSSIP:
+        scal4 = ops.gossip_scalars(x, batch.rowptr, batch.col, q["g0"], q["g1"])
+        (w3, b3), (w5, b5) = pk["post"]
+        v = {"g1": q["g1"], "p": q["p"], "z": q["z"], "zp": q["zp"], "r": q["r"], "t": q["t"],
+             "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"], "w1": pk["wt1"], "wp": pk["wtp"],
+             "w3": w3, "b3": b3, "w5": w5, "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
+        return ops.gossip_fused(scal4, batch.rowptr, batch.col, N, Q, v)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0
     hh = ops.gossip_gather(h1, batch.rowptr, batch.col, N, Q, q["g1"])           # layer 1 aggregate

@@ -155,6 +155,27 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0: int,
+               num_rows: int, slots_stored: int, slots_used: int, wt: torch.Tensor,
+               bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h)."""
+    assert wt.is_contiguous() and wt.shape == ((slots_used + 1) * 64, 64)
+    assert out.data_ptr() != x.data_ptr()
+    xp, ldx = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    L = _lib.lib()
+    # executed flops; compulsory bytes: x once + out once + indices
+    fl = 2.0 * num_rows * (slots_used + 1) * 64 * 64
+    nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
+    with _Timed("shmp_layer_f32_kernel", fl, nb):
+        _lib.check(L.desco_shmp_layer_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
+                                          _dev(vcol, "vcol", torch.int32), row0, num_rows,
+                                          slots_stored, slots_used, _dev(wt, "wt"),
+                                          _dev(bias.contiguous(), "bias"), op, ldo, _stream()),
+                   "shmp_layer")
+    return out
+
+
 def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
                 extra: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -232,6 +253,45 @@ def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_
                                          _dev(col, "col", torch.int32), num_nodes, num_q,
                                          _dev(g.contiguous(), "g"), _dev(out, "out"), _stream()),
                "gossip_gather")
+    return out
+
+
+def gossip_scalars(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, g1) -> torch.Tensor:
+    """scal4[i*Q+q] = (a0, b0, a1, x[i,q]) -- the per-(node, query) scalars of the gossip stage."""
+    N, Q = x.shape
+    scal = torch.empty((N * Q, 4), device=x.device, dtype=torch.float32)
+    xp, ldx = _rows(x, "x")
+    L = _lib.lib()
+    with _Timed("gossip_scalars_kernel", 6.0 * col.numel() * Q, 4.0 * (col.numel() * (Q + 1) + N) + 20.0 * N * Q):
+        _lib.check(L.desco_gossip_scalars_f32(xp, ldx, _dev(rowptr, "rowptr", torch.int32),
+                                              _dev(col, "col", torch.int32), N, Q,
+                                              _dev(g0.contiguous(), "g0"), _dev(g1.contiguous(), "g1"),
+                                              _dev(scal, "scal"), _stream()), "gossip_scalars")
+    return scal
+
+
+# executed MFMA flops per (node, query) row of the fused gossip kernel: K=128,128,64 (N=64), 64 (N=256)
+GOSSIP_FUSED_FLOPS_PER_ROW = 2.0 * 64 * (128 + 128 + 64) + 2.0 * 64 * 256
+
+
+def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
+                 num_q: int, v: dict) -> torch.Tensor:
+    """One on-chip pass per (64-node tile, query): returns pred [N, Q] (see desco_hip.h)."""
+    out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
+    L = _lib.lib()
+    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1", "wp", "w3", "b3", "w5", "b5", "w7")
+    ptrs = []
+    for n in names:
+        if not v[n].is_contiguous():
+            raise ValueError(f"gossip_fused: operand {n} must be contiguous")
+        ptrs.append(_dev(v[n], n))
+    rows = float(num_nodes) * num_q
+    with _Timed("gossip_fused_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
+                rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
+        _lib.check(L.desco_gossip_fused_f32(_dev(scal, "scal"), _dev(rowptr, "rowptr", torch.int32),
+                                            _dev(col, "col", torch.int32), num_nodes, num_q, *ptrs,
+                                            float(v["b7"]), _dev(out, "out"), _stream()),
+                   "gossip_fused")
     return out
 
 

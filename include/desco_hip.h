@@ -108,6 +108,18 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
                    int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
                    int64_t m, desco_stream_t stream);
 
+/* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip): per destination row i in
+ * [row0, row0+num_rows) gather the relation slots s < slots_used into LDS and multiply
+ * [agg_0 .. agg_{su-1} | x_i] by Wt ((slots_used+1)*64 x 64, row major) on the f32 MFMA:
+ *   out[i] = relu( sum_s (sum_{e in vrow(i*slots_stored+s)} x[vcol[e]]) * Wt_s + x[i] * Wt_su + bias )
+ * x / out are indexed by the same global row ids as vrowptr (leading dims ldx / ldo); out must not
+ * alias x.  Replaces SAGEConv.propagate + lin + to_hetero sum + updates + relu
+ * (gnn_model.py:262-264, 273, 392-395) without materialising the aggregates. */
+int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
+                         int64_t row0, int64_t num_rows, int slots_stored, int slots_used,
+                         const float* wt, const float* bias, float* out, int64_t ldo,
+                         desco_stream_t stream);
+
 /* K9  global_add_pool (gnn_model.py:107) over contiguous row segments, plus one optional extra row
  * per segment (the anchored canonical embedding, gnn_model.py:69-73, 88-89):
  * out[b, 0:ncols] = sum_{r in [seg_ptr[b], seg_ptr[b+1])} x[r, 0:ncols] + extra[b, 0:ncols]
@@ -144,6 +156,27 @@ int desco_gossip_layer0_f32(const float* x, int64_t ldx, const int32_t* rowptr, 
 int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t* col,
                             int64_t num_nodes, int num_q, const float* g, float* out,
                             desco_stream_t stream);
+
+/* Fused gossip stage (csrc/gossip_fused.hip), two launches for all queries:
+ *  (1) desco_gossip_scalars_f32: scal4[i*Q+q] = (a0, b0, a1, x[i,q]) with
+ *      a_l = g_l[q]*deg_lo(i) + (1-g_l[q])*deg_hi(i),  b0 = g0[q]*sum_{j<i} x[j,q] + (1-g0[q])*sum_{j>i} x[j,q]
+ *  (2) desco_gossip_fused_f32: per tile of 64 nodes and one query, entirely on chip,
+ *      h1 = relu(a0*p_q + b0*r + x*t + z_q);  hh = sum_j (j<i ? g1 : 1-g1)*h1_j;
+ *      h2 = relu([hh|h1] w1 + a1*u + d1);  y1 = leaky_0.1([h1|h2] wp + x*tp + zp_q);
+ *      y2 = relu(y1 w3 + b3);  out[i,q] = x + b7 + sum_c relu(y2 w5 + b5)[c]*w7[c]
+ *      (w1, wp: [128,64]; w3: [64,64]; w5: [64,256]; row major = torch weights transposed/folded).
+ * Replaces BaseGNN.forward (gossip) for every query: gnn_model.py:58-103, 230-260, 303-350 and the
+ * loop of lightning_model.py:613-628; equals layer0 + gather + 4 GEMMs + rowdot of the unfused path. */
+int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                             int64_t num_nodes, int num_q, const float* g0, const float* g1,
+                             float* scal4, desco_stream_t stream);
+int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
+                           int64_t num_nodes, int num_q, const float* g1, const float* p,
+                           const float* z, const float* zp, const float* r, const float* t,
+                           const float* u, const float* tp, const float* d1, const float* w1,
+                           const float* wp, const float* w3, const float* b3, const float* w5,
+                           const float* b5, const float* w7, float b7, float* out,
+                           desco_stream_t stream);
 
 /* K21 tail: out[r] = add[r] + sum_c y[r,c]*w[c] + b   (post_mp.7 with output_dim 1, then
  * pred = neigh_pred + gossip_pred, lightning_model.py:622-625) */

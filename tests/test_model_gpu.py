@@ -105,3 +105,43 @@ def test_end_to_end_pipeline_vs_oracle(setup):
     for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
         report(k, out[k], ref[k])
         torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
+
+
+def test_fused_gossip_equals_unfused_incl_hubs(setup):
+    """The on-chip gossip kernel vs the 7-launch path on a graph set with hub nodes whose tile
+    holds more neighbour records than one staging pass (ECAP = 768)."""
+    import desco_amd.gnn_model as GM
+    nm, gm, qids, queries = setup
+    rng = np.random.default_rng(5)
+    hub_n = 1500
+    hub = (hub_n, [(7, v) for v in range(hub_n) if v != 7] + [(v, v + 1) for v in range(20, 400)] +
+           [(1400, v) for v in range(0, 1300, 2)])
+    graphs = golden_graphs(max_n=60)[:6] + [hub] + golden_graphs(max_n=60)[6:9]
+    gs = GraphSet.from_edge_lists(graphs)
+    x = torch.from_numpy(rng.gamma(1.0, 4.0, size=(gs.num_nodes, len(queries)))).float()
+    gm.set_query_emb(nm.get_query_emb())
+    batch = GossipBatch(gs, DEV, x=x)
+    try:
+        GM.FUSED_GOSSIP = True
+        fused = gm.graph_to_count(batch)
+        GM.FUSED_GOSSIP = False
+        unfused = gm.graph_to_count(batch)
+    finally:
+        GM.FUSED_GOSSIP = True
+    report("gossip fused vs unfused", fused - batch.x, unfused - batch.x)
+    torch.testing.assert_close(fused - batch.x, unfused - batch.x, rtol=1e-4, atol=2e-4)
+
+
+def test_unfused_shmp_equals_fused(setup):
+    import desco_amd.gnn_model as GM
+    nm, *_ = setup
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=60)), 4)
+    batch = NeighborhoodBatch(part, DEV)
+    try:
+        GM.FUSED_SHMP_LAYER = False
+        a = nm._logits(batch, exp2=False)
+    finally:
+        GM.FUSED_SHMP_LAYER = True
+    with torch.no_grad():
+        b = nm._logits(batch, exp2=False)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
