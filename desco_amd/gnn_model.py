@@ -260,7 +260,13 @@ def pack_shmp(gnn: BaseGNN) -> dict:
                 blocks.append((Un @ conv.lin.weight).t())        # (U_n W_s)^T
                 bsum = bsum + conv.lin.bias
             blocks.append(Ux.t())
-            per_type[t] = (torch.cat(blocks, 0).contiguous(), (Un @ bsum + c).contiguous())
+            entry = {"wt": torch.cat(blocks, 0).contiguous(), "b": (Un @ bsum + c).contiguous()}
+            if len(blocks) == 5:
+                # count destinations: the two canonical->count relations have at most one source
+                # per row; apply them from a pre-transformed table (K 320 -> 192)
+                entry["wt_mfma"] = torch.cat([blocks[0], blocks[1], blocks[4]], 0).contiguous()
+                entry["wt_tab"] = torch.cat([blocks[2], blocks[3]], 1).contiguous()      # [64,128]
+            per_type[t] = entry
         pk["layers"].append(per_type)
     pk["anchor"] = _lin_t(gnn.anchor_mlp[0])
     pk["post"] = [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]
@@ -299,16 +305,23 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         xn = torch.empty((N, H), device=dev)
         if FUSED_SHMP_LAYER:
             for t, r0, r1, su in groups:                                   # :262-264, :273, :389-395
-                if r1 > r0:
-                    wt, b = pk["layers"][l][t]
-                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su, wt, b, xn)
+                if r1 <= r0:
+                    continue
+                e = pk["layers"][l][t]
+                if "wt_tab" in e:
+                    ytab = ops.gemm(X[-1][Nc:], e["wt_tab"])               # canonical rows x [W2|W3]
+                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2, e["wt_mfma"],
+                                   e["b"], xn, ytab=ytab, ytab_row0=Nc)
+                else:
+                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su, e["wt"],
+                                   e["b"], xn)
         else:
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
             for t, r0, r1, su in groups:
                 if r1 > r0:
-                    wt, b = pk["layers"][l][t]
-                    ops.gemm(agg[r0:r1, :su * H], wt, b, a2=X[-1][r0:r1], act=ops.ACT_RELU,
-                             out=xn[r0:r1])
+                    e = pk["layers"][l][t]
+                    ops.gemm(agg[r0:r1, :su * H], e["wt"], e["b"], a2=X[-1][r0:r1],
+                             act=ops.ACT_RELU, out=xn[r0:r1])
         X.append(xn)
     B = batch.num_graphs
     P = H * (core.layer_num + 1)

@@ -156,23 +156,28 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0: int,
-               num_rows: int, slots_stored: int, slots_used: int, wt: torch.Tensor,
-               bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h)."""
-    assert wt.is_contiguous() and wt.shape == ((slots_used + 1) * 64, 64)
-    assert out.data_ptr() != x.data_ptr()
+               num_rows: int, slots_stored: int, slots_mfma: int, wt: torch.Tensor,
+               bias: torch.Tensor, out: torch.Tensor, ytab: Optional[torch.Tensor] = None,
+               ytab_row0: int = 0) -> torch.Tensor:
+    """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
+    ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1."""
+    assert wt.is_contiguous() and wt.shape == ((slots_mfma + 1) * 64, 64)
     xp, ldx = _rows(x, "x")
     op, ldo = _rows(out, "out")
+    st, yp, ldy = 0, None, 0
+    if ytab is not None:
+        st = ytab.shape[1] // 64
+        yp, ldy = _rows(ytab, "ytab")
     L = _lib.lib()
-    # executed flops; compulsory bytes: x once + out once + indices
-    fl = 2.0 * num_rows * (slots_used + 1) * 64 * 64
+    # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
+    fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
     with _Timed("shmp_layer_f32_kernel", fl, nb):
         _lib.check(L.desco_shmp_layer_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
                                           _dev(vcol, "vcol", torch.int32), row0, num_rows,
-                                          slots_stored, slots_used, _dev(wt, "wt"),
-                                          _dev(bias.contiguous(), "bias"), op, ldo, _stream()),
-                   "shmp_layer")
+                                          slots_stored, slots_mfma, st, _dev(wt, "wt"),
+                                          _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
+                                          op, ldo, _stream()), "shmp_layer")
     return out
 
 

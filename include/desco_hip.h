@@ -108,16 +108,19 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
                    int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
                    int64_t m, desco_stream_t stream);
 
-/* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip): per destination row i in
- * [row0, row0+num_rows) gather the relation slots s < slots_used into LDS and multiply
- * [agg_0 .. agg_{su-1} | x_i] by Wt ((slots_used+1)*64 x 64, row major) on the f32 MFMA:
- *   out[i] = relu( sum_s (sum_{e in vrow(i*slots_stored+s)} x[vcol[e]]) * Wt_s + x[i] * Wt_su + bias )
- * x / out are indexed by the same global row ids as vrowptr (leading dims ldx / ldo); out must not
- * alias x.  Replaces SAGEConv.propagate + lin + to_hetero sum + updates + relu
+/* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip).  For destination rows i in
+ * [row0, row0+num_rows), with sm = slots_mfma <= 3, st = slots_table <= 2, S = slots_stored (sm+st <= S <= 4):
+ *   out[i] = relu( sum_{s<sm} (sum_{e in vrow(i*S+s)} x[vcol[e]]) * Wt_s + x[i] * Wt_sm + bias
+ *                  + sum_{sm<=s<sm+st} sum_{e in vrow(i*S+s)} ytab[vcol[e]-ytab_row0][(s-sm)*64 : +64] )
+ * Wt: [(sm+1)*64, 64] row major.  "Table slots" are relations whose sources were already multiplied
+ * by their weight block (ytab = x_src * [Wt_sm' | ...], ld ldy): (sum_j x_j) W = sum_j (x_j W).
+ * x / out are indexed by the same global row ids as vrowptr; out must not alias x.
+ * Replaces SAGEConv.propagate + lin + to_hetero sum + updates + relu
  * (gnn_model.py:262-264, 273, 392-395) without materialising the aggregates. */
 int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
-                         int64_t row0, int64_t num_rows, int slots_stored, int slots_used,
-                         const float* wt, const float* bias, float* out, int64_t ldo,
+                         int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
+                         int slots_table, const float* wt, const float* bias, const float* ytab,
+                         int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                          desco_stream_t stream);
 
 /* K9  global_add_pool (gnn_model.py:107) over contiguous row segments, plus one optional extra row

@@ -184,22 +184,32 @@ def test_gossip_layer0_and_gather():
     _close(got.view(n, Q, 64), ref, atol=1e-4)
 
 
-@pytest.mark.parametrize("S,su", [(4, 4), (4, 2), (2, 2)])
-@pytest.mark.parametrize("num_rows,row0,max_deg", [(1, 0, 3), (63, 5, 4), (64, 0, 2), (1000, 17, 9), (333, 0, 70)])
-def test_fused_shmp_layer(S, su, num_rows, row0, max_deg):
-    g = torch.Generator().manual_seed(S * 1000 + su * 100 + num_rows)
+@pytest.mark.parametrize("S,sm,st", [(4, 3, 0), (4, 2, 0), (2, 2, 0), (4, 2, 2), (1, 1, 0), (4, 0, 1), (4, 3, 1)])
+@pytest.mark.parametrize("num_rows,row0,max_deg", [(1, 0, 3), (63, 5, 4), (256, 0, 2), (1000, 17, 9),
+                                                   (333, 0, 70), (70000, 3, 3), (70000, 0, 6)])
+def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg):
+    g = torch.Generator().manual_seed(S * 1000 + sm * 100 + st * 10 + num_rows)
     n_all = row0 + num_rows + 9
     x = torch.randn(n_all, 64, generator=g)
     ptr, col, cnt = _random_vcsr(n_all, S, max_deg, n_all, g)
-    wt = torch.randn((su + 1) * 64, 64, generator=g) / 12
+    wt = torch.randn((sm + 1) * 64, 64, generator=g) / 12
     bias = torch.randn(64, generator=g)
     agg = torch.zeros(n_all * S, 64, dtype=torch.double)
     agg.index_add_(0, torch.repeat_interleave(torch.arange(n_all * S), cnt), x.double()[col.long()])
-    A = torch.cat([agg.view(n_all, S * 64)[:, :su * 64], x.double()], 1)
-    ref = torch.relu(A @ wt.double() + bias.double())[row0:row0 + num_rows]
+    aggv = agg.view(n_all, S * 64)
+    A = torch.cat([aggv[:, :sm * 64], x.double()], 1)
+    ref = A @ wt.double() + bias.double()
+    ytab = None
+    if st:
+        wtab = torch.randn(64, 64 * st, generator=g) / 8
+        ytab_cpu = x @ wtab                                   # fp32 table, as the product path builds it
+        for s in range(st):
+            ref = ref + aggv[:, (sm + s) * 64:(sm + s + 1) * 64] @ wtab.double()[:, s * 64:(s + 1) * 64]
+        ytab = ytab_cpu.to(DEV)
+    ref = torch.relu(ref)[row0:row0 + num_rows]
     out = torch.full((n_all, 64), -7.0, device=DEV)
-    ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, su, wt.to(DEV),
-                   bias.to(DEV), out)
-    _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=1e-4)
+    ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, wt.to(DEV),
+                   bias.to(DEV), out, ytab=ytab, ytab_row0=0)
+    _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
     rest = torch.cat([out[:row0], out[row0 + num_rows:]])
     assert (rest == -7.0).all()          # rows outside the range are untouched
