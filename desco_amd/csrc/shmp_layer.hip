@@ -11,17 +11,19 @@
 // the canonical->count relations (at most one source per row), cutting K from 320 to 192.
 //
 // Structure (wave-autonomous, persistent, software-pipelined):
-//   * block = 8 waves = one CU (2 waves per SIMD); all (sm+1) 64x64 weight blocks are loaded into
-//     LDS ONCE per block and stay resident while the block strides over 256-row tiles;
+//   * block = 12 waves = one CU (3 waves per SIMD); all (sm+1) 64x64 weight blocks are loaded into
+//     LDS ONCE per block and stay resident while the block strides over 384-row tiles;
 //   * every wave owns 32 destination rows of a tile end to end and never meets a block barrier in
-//     the tile loop: while one wave of a SIMD waits on its gather the other feeds the MFMA pipe;
+//     the tile loop: while two waves of a SIMD wait on gathers the third feeds the MFMA pipe;
 //   * the CSR slice of the wave's NEXT tile (row pointers, then up to WCAP source ids) is
 //     prefetched into a second private LDS buffer under the current tile's work, so the only
-//     dependent global access on the critical path is the 256-B feature row of a neighbour
-//     (16 lanes x float4 per row, 8 rows in flight per lane group);
-//   * table slots are folded into the accumulator INIT (their loads fly under the first gather);
-//   * a K block is multiplied through a private [32][65] A image (64 MFMAs: 32x64 output, two
-//     accumulators share the A fragment);
+//     dependent global access on the critical path is the feature row of a neighbour;
+//   * a K block is processed as two 32-column halves: 8-lane groups x float4 gather one 128-B
+//     half row per neighbour (8 rows in flight per pass, 4 passes kept in flight together) into a
+//     private [32][33] A image, then 32 MFMAs (32x64 output, two accumulators share the A fragment);
+//   * table slots run as one extra pseudo K block: their pre-transformed source rows are gathered
+//     the same way, staged in the A image and ADDED to the accumulators in the C/D layout
+//     (16 LDS reads per half instead of 32 MFMAs);
 //   * HBM traffic per row and layer: one 256-B read of x, one 256-B write, ~20 B of indices
 //     (neighbour re-reads hit L2: a neighborhood's rows are contiguous).
 #include "common_device.hpp"
@@ -29,15 +31,12 @@
 namespace desco {
 
 constexpr int WR = 32;        // rows per wave
-constexpr int NW = 8;         // waves per block (2 per SIMD)
-constexpr int AH = 65;        // A image row stride (floats): conflict-free ds_read_b32 over rows
-constexpr int CS = 68;        // C staging row stride (floats, 16-B aligned rows)
+constexpr int NW = 12;        // waves per block (3 per SIMD: <= 168 VGPRs each)
+constexpr int AH = 33;        // half-K A image row stride (floats): conflict-free ds_read_b32
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
-// source ids staged per wave (longer slices fall back to global); sized so that KB resident weight
-// blocks + 8 wave regions fit the 160 KB LDS
-constexpr int wcap_for(int kb) { return kb >= 4 ? 128 : 256; }   // multiples of 64
-constexpr int wave_lds_for(int kb) { return WR * CS + 2 * RPN + 2 * wcap_for(kb); }   // floats
+constexpr int WCAP = 128;     // source ids staged per wave (longer slices fall back to global)
+constexpr int WAVE_LDS = WR * AH + 2 * RPN + 2 * WCAP;   // floats per wave
 
 struct ShmpArgs {
   const float* x;
@@ -63,13 +62,11 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 
 template <int KB, int ST>   // KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2)
 __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
-  constexpr int WCAP = wcap_for(KB);
-  constexpr int WAVE_LDS = wave_lds_for(KB);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Bimg = lds;                                       // [KB*64][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* Aw = lds + KB * 64 * 64 + wave * WAVE_LDS;        // [32][65]
-  int* rpb = reinterpret_cast<int*>(Aw + WR * CS);         // 2 x [32*S+1] row pointers (absolute)
+  float* Aw = lds + KB * 64 * 64 + wave * WAVE_LDS;        // [32][33]
+  int* rpb = reinterpret_cast<int*>(Aw + WR * AH);         // 2 x [32*S+1] row pointers (absolute)
   int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids
 
   // ---- resident weights -------------------------------------------------------------------
@@ -77,7 +74,16 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     *reinterpret_cast<float4*>(Bimg + 4 * i) = *reinterpret_cast<const float4*>(g.wt + 4 * i);
   __syncthreads();
 
-  const int grp = lane >> 4, l16 = lane & 15;
+  // The 3 waves of a SIMD (w, w+4, w+8) run the same program; equal priority keeps them in
+  // lockstep (memory phases and MFMA phases line up and add).  Distinct static priorities let one
+  // wave finish its MFMA block first, so its loads/stores overlap the others' MFMAs.
+  {
+    const int pr = __builtin_amdgcn_readfirstlane(wave >> 2);
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+  }
+  const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
   const int S = g.S;
   const int nslot = WR * S + 1;                            // <= 129: at most 3 per lane
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
@@ -120,16 +126,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
       if (lane + 128 < nslot) p2 = src[lane + 128 < nptr ? lane + 128 : nptr - 1];
     }
-    int qn[WCAP / 64];         // source ids of the next tile (registers until the tile ends)
-#pragma unroll
-    for (int i = 0; i < WCAP / 64; ++i) qn[i] = 0;
+    int qn0 = 0, qn1 = 0;      // source ids of the next tile (registers until the tile ends)
     int ebn = 0, ecntn = 0;
 
     const int ebase = rp[0];
     const int cl = lane & 31;
-    // ---- accumulator init: bias + table slots.  Round k adds the k-th source of every
-    // (row, table slot); all loads of a round are independent, so they fly together (and under
-    // the first gather).  Absent sources read table row 0 and are discarded by a select.
+    // ---- accumulator init: bias ----------------------------------------------------------------
     f32x16 acc0, acc1;
     {
       const float bv0 = g.bias ? g.bias[cl] : 0.f, bv1 = g.bias ? g.bias[32 + cl] : 0.f;
@@ -139,62 +141,60 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
         acc1[i] = bv1;
       }
     }
-    if (ST > 0) {
-      for (int round = 0;; ++round) {
-        bool more = false;
+#pragma unroll 1
+    for (int kh = 0; kh < 2 * KB + (ST > 0 ? 2 : 0); ++kh) {
+      const int kb = kh >> 1, h = kh & 1;
+      const bool is_tab = ST > 0 && kb == KB;      // table pseudo block: gather ytab rows, add in C layout
+      // ---- gather half h (columns 32h..32h+31) of K block kb: slot kb, or the row itself -----
+      // lane group g8 serves rows it*8 + g8 (it = 0..3), 4 floats at column 32h + 4*l8
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      const float* xb = g.x + 32 * h + 4 * l8;
+      if (is_tab) {
+        // sources of the table slots sm .. sm+ST-1 (already multiplied by their weight block)
+        const float* yb = g.ytab + 32 * h + 4 * l8 - g.ytab_row0 * g.ldy;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-#pragma unroll
-          for (int ts = 0; ts < ST; ++ts) {
-            const int v = r * S + g.sm + ts;
-            const int e = rp[v] - ebase + round, e1 = rp[v + 1] - ebase;
-            const bool ok = e < e1;
-            more |= e + 1 < e1;
-            const int64_t j = ok ? (int64_t)(e < WCAP ? ec[e < WCAP ? e : 0] : g.vcol[ebase + e]) -
-                                       g.ytab_row0
-                                 : 0;
-            const float* y = g.ytab + j * g.ldy + ts * 64 + cl;
-            const float y0 = y[0], y1 = y[32];
-            acc0[reg] += ok ? y0 : 0.f;
-            acc1[reg] += ok ? y1 : 0.f;
+        for (int ts = 0; ts < ST; ++ts) {
+          int c0, c1, c2, c3, n0, n1, n2, n3;
+#define DESCO_CUR(c_, n_, it_)                          \
+  {                                                     \
+    const int v_ = ((it_) * 8 + g8) * S + g.sm + ts;    \
+    c_ = rp[v_] - ebase;                                \
+    n_ = rp[v_ + 1] - ebase;                            \
+  }
+          DESCO_CUR(c0, n0, 0) DESCO_CUR(c1, n1, 1) DESCO_CUR(c2, n2, 2) DESCO_CUR(c3, n3, 3)
+#undef DESCO_CUR
+          while (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
+#define DESCO_STEP(av_, c_, n_)                                                          \
+  if (c_ < n_) {                                                                         \
+    const int64_t j_ = c_ < WCAP ? ec[c_] : g.vcol[ebase + c_];                          \
+    f4add(av_, *reinterpret_cast<const float4*>(yb + j_ * g.ldy + ts * 64));             \
+    ++c_;                                                                                \
+  }
+            DESCO_STEP(a0, c0, n0) DESCO_STEP(a1, c1, n1) DESCO_STEP(a2, c2, n2)
+            DESCO_STEP(a3, c3, n3)
+#undef DESCO_STEP
           }
         }
-        if (!__any(more)) break;
-      }
-    }
-
-#pragma unroll 1
-    for (int kb = 0; kb < KB; ++kb) {
-      // ---- gather K block kb (slot kb, or the row itself for kb == KB-1) ----------------------
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0,
-             a6 = a0, a7 = a0;
-      if (kb == KB - 1) {
-        const float* xs = g.x + grow0 * g.ldx + 4 * l16;
+      } else if (kb == KB - 1) {
         // rows beyond nr re-read the wave's last valid row (never stored)
-#define DESCO_SELF(av_, it_)                                                   \
-  {                                                                            \
-    const int r_ = (it_) * 4 + grp;                                            \
-    av_ = *reinterpret_cast<const float4*>(xs + (int64_t)(r_ < nr ? r_ : nr - 1) * g.ldx); \
+#define DESCO_SELF(av_, it_)                                                                   \
+  {                                                                                            \
+    const int r_ = (it_) * 8 + g8;                                                             \
+    av_ = *reinterpret_cast<const float4*>(xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * g.ldx);    \
   }
         DESCO_SELF(a0, 0) DESCO_SELF(a1, 1) DESCO_SELF(a2, 2) DESCO_SELF(a3, 3)
-        DESCO_SELF(a4, 4) DESCO_SELF(a5, 5) DESCO_SELF(a6, 6) DESCO_SELF(a7, 7)
 #undef DESCO_SELF
       } else {
-        // edge cursors of the 8 rows this lane group serves (row = it*4 + grp)
-        int c0, c1, c2, c3, c4, c5, c6, c7, n0, n1, n2, n3, n4, n5, n6, n7;
+        int c0, c1, c2, c3, n0, n1, n2, n3;
 #define DESCO_CUR(c_, n_, it_)                        \
   {                                                   \
-    const int v_ = ((it_) * 4 + grp) * S + kb;        \
+    const int v_ = ((it_) * 8 + g8) * S + kb;         \
     c_ = rp[v_] - ebase;                              \
     n_ = rp[v_ + 1] - ebase;                          \
   }
         DESCO_CUR(c0, n0, 0) DESCO_CUR(c1, n1, 1) DESCO_CUR(c2, n2, 2) DESCO_CUR(c3, n3, 3)
-        DESCO_CUR(c4, n4, 4) DESCO_CUR(c5, n5, 5) DESCO_CUR(c6, n6, 6) DESCO_CUR(c7, n7, 7)
 #undef DESCO_CUR
-        const float* xb = g.x + 4 * l16;
-        while (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3) | (c4 < n4) | (c5 < n5) |
-                     (c6 < n6) | (c7 < n7))) {
+        while (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
 #define DESCO_STEP(av_, c_, n_)                                                          \
   if (c_ < n_) {                                                                         \
     const int64_t j_ = c_ < WCAP ? ec[c_] : g.vcol[ebase + c_];                          \
@@ -202,40 +202,47 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     ++c_;                                                                                \
   }
           DESCO_STEP(a0, c0, n0) DESCO_STEP(a1, c1, n1) DESCO_STEP(a2, c2, n2)
-          DESCO_STEP(a3, c3, n3) DESCO_STEP(a4, c4, n4) DESCO_STEP(a5, c5, n5)
-          DESCO_STEP(a6, c6, n6) DESCO_STEP(a7, c7, n7)
+          DESCO_STEP(a3, c3, n3)
 #undef DESCO_STEP
         }
       }
-      if (kb == 0 && has_next) {
+      if (kh == 0 && has_next) {
         // next tile's row pointers have landed: publish them, then fetch its source ids
         rpn[lane] = p0;
         if (lane + 64 < nslot) rpn[lane + 64] = p1;
         if (lane + 128 < nslot) rpn[lane + 128] = p2;
         ebn = rpn[0];
         ecntn = rpn[WR * S] - ebn;
-#pragma unroll
-        for (int i = 0; i < WCAP / 64; ++i)
-          if (lane + 64 * i < ecntn) qn[i] = g.vcol[ebn + lane + 64 * i];
+        if (lane < ecntn) qn0 = g.vcol[ebn + lane];
+        if (lane + 64 < ecntn) qn1 = g.vcol[ebn + lane + 64];
       }
-      // ---- write the A image (row = it*4 + grp, 4 floats at 4*l16), 64 MFMAs -------------------
-#define DESCO_PUT(av_, it_)                              \
-  {                                                      \
-    float* d_ = Aw + ((it_) * 4 + grp) * AH + 4 * l16;   \
-    d_[0] = av_.x;                                       \
-    d_[1] = av_.y;                                       \
-    d_[2] = av_.z;                                       \
-    d_[3] = av_.w;                                       \
+      // ---- write the half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8) --------
+#define DESCO_PUT(av_, it_)                             \
+  {                                                     \
+    float* d_ = Aw + ((it_) * 8 + g8) * AH + 4 * l8;    \
+    d_[0] = av_.x;                                      \
+    d_[1] = av_.y;                                      \
+    d_[2] = av_.z;                                      \
+    d_[3] = av_.w;                                      \
   }
       DESCO_PUT(a0, 0) DESCO_PUT(a1, 1) DESCO_PUT(a2, 2) DESCO_PUT(a3, 3)
-      DESCO_PUT(a4, 4) DESCO_PUT(a5, 5) DESCO_PUT(a6, 6) DESCO_PUT(a7, 7)
 #undef DESCO_PUT
-      {
-        // A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
-        const float* as = Aw + (lane & 31) * AH + (lane >> 5);
-        const float* bs = Bimg + (kb * 64 + (lane >> 5)) * 64 + (lane & 31);
+      if (is_tab) {
+        // add the staged table half rows in the C/D layout: acc_h[reg] += stage[row(reg)][lane&31]
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
+        for (int reg = 0; reg < 16; ++reg) {
+          const float v = Aw[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * AH + cl];
+          if (h == 0)
+            acc0[reg] += v;
+          else
+            acc1[reg] += v;
+        }
+      } else {
+        // 32 MFMAs: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
+        const float* as = Aw + (lane & 31) * AH + (lane >> 5);
+        const float* bs = Bimg + (kb * 64 + h * 32 + (lane >> 5)) * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
           const float a = as[2 * kk];
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[2 * kk * 64], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[2 * kk * 64 + 32], acc1, 0, 0, 0);
@@ -244,27 +251,20 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     }
 
     if (has_next) {   // publish the next tile's source ids
-#pragma unroll
-      for (int i = 0; i < WCAP / 64; ++i)
-        if (lane + 64 * i < ecntn) ecn[lane + 64 * i] = qn[i];
+      if (lane < ecntn) ecn[lane] = qn0;
+      if (lane + 64 < ecntn && lane + 64 < WCAP) ecn[lane + 64] = qn1;
     }
 
-    // ---- epilogue: relu, transpose through the (now free) A image as [32][68], then whole-row
-    // float4 stores (4 rows x 256 B per wave instruction instead of 2 x 128 B dword stores).
-    // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue: relu + store; C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5) ----
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const float v0 = acc0[reg], v1 = acc1[reg];
-      Aw[r * CS + cl] = v0 > 0.f ? v0 : 0.f;
-      Aw[r * CS + 32 + cl] = v1 > 0.f ? v1 : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = it * 4 + grp;
-      if (r < nr)
-        *reinterpret_cast<float4*>(g.out + (grow0 + r) * g.ldo + 4 * l16) =
-            *reinterpret_cast<const float4*>(Aw + r * CS + 4 * l16);
+      if (r < nr) {
+        const float v0 = acc0[reg], v1 = acc1[reg];
+        float* o = g.out + (grow0 + r) * g.ldo + cl;
+        o[0] = v0 > 0.f ? v0 : 0.f;
+        o[32] = v1 > 0.f ? v1 : 0.f;
+      }
     }
   }
 }
@@ -282,7 +282,7 @@ extern "C" int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* 
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (!x || !vrowptr || !wt || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > 3 || slots_table < 0 || slots_mfma + slots_table > slots_stored || slots_stored < 1 ||
-      slots_stored > MAXS || slots_table > 2 || (slots_table > 0 && !ytab) || ldx % 4 || ldo % 4 || mis16(x) || mis16(wt) || mis16(out) ||
+      slots_stored > MAXS || slots_table > 2 || (slots_table > 0 && !ytab) || ldx % 4 || mis16(x) || mis16(wt) ||
       x == out)
     return fail(DESCO_EINVAL, "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
   const int64_t ntiles = (num_rows + NW * WR - 1) / (NW * WR);
@@ -293,7 +293,7 @@ extern "C" int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* 
       cus = v;
   }
   const int kb = slots_mfma + 1;
-  const size_t shmem = sizeof(float) * ((size_t)kb * 64 * 64 + (size_t)NW * wave_lds_for(kb));
+  const size_t shmem = sizeof(float) * ((size_t)kb * 64 * 64 + (size_t)NW * WAVE_LDS);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   ShmpArgs g{x,   ldx,  vrowptr, vcol, row0,      num_rows, slots_stored, slots_mfma, slots_table,
              wt,  bias, ytab,    ldy,  ytab_row0, out,      ldo};
