@@ -1,0 +1,118 @@
+"""torch.autograd bookkeeping around the HIP kernels (training path).
+
+Every Function's forward AND backward are C-ABI kernel launches (desco_amd.ops); torch only wires
+the graph, so ``loss.backward()`` + ``torch.optim.Adam`` train the reference-named parameters.
+The weight folding of gnn_model.pack_* is done with (tiny) differentiable torch ops, so gradients
+reach the original ``lin`` / ``updates`` / ``anchor_mlp`` / ``post_mp`` / ``count_model`` tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class GatherSum(torch.autograd.Function):
+    """agg = csr_gather_sum(x); backward = gather over the transposed index (csr_t)."""
+
+    @staticmethod
+    def forward(ctx, x, vrowptr, vcol, t_rowptr, t_col, num_rows, slots):
+        ctx.save_for_backward(t_rowptr, t_col)
+        ctx.n_src = x.shape[0]
+        return ops.csr_gather_sum(x.contiguous(), vrowptr, vcol, num_rows, slots)
+
+    @staticmethod
+    def backward(ctx, dagg):
+        t_rowptr, t_col = ctx.saved_tensors
+        d = dagg.contiguous().view(-1, 64)                     # [num_rows*slots, 64] virtual rows
+        dx = ops.csr_gather_sum(d, t_rowptr, t_col, ctx.n_src, 1)
+        return dx, None, None, None, None, None, None
+
+
+class Linear(torch.autograd.Function):
+    """c = act([a1 | a2] @ wt + bias);  wt is [(k1+k2), n] (a differentiable function of params)."""
+
+    @staticmethod
+    def forward(ctx, a1, a2, wt, bias, act, slope):
+        wt = wt.contiguous()
+        c = ops.gemm(a1, wt, bias, a2=a2, act=act, slope=slope)
+        ctx.save_for_backward(a1, a2 if a2 is not None else a1.new_empty(0), wt, c)
+        ctx.has_a2, ctx.act, ctx.slope, ctx.has_bias = a2 is not None, act, slope, bias is not None
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a1, a2, wt, c = ctx.saved_tensors
+        dz = ops.act_grad(dc.contiguous(), c, ctx.act, ctx.slope)
+        k1 = a1.shape[1]
+        da1 = da2 = dwt = dbias = None
+        need_a1, need_a2 = ctx.needs_input_grad[0], ctx.has_a2 and ctx.needs_input_grad[1]
+        if need_a1 or need_a2:
+            da = ops.gemm(dz, wt.t().contiguous())             # dA = dZ @ Wt^T  (k % 64 == 0)
+            if need_a1:
+                da1 = da[:, :k1]
+            if need_a2:
+                da2 = da[:, k1:]
+        if ctx.needs_input_grad[2]:
+            dwt = torch.empty_like(wt)
+            ops.gemm_tn(a1, dz, out=dwt[:k1])
+            if ctx.has_a2:
+                ops.gemm_tn(a2, dz, out=dwt[k1:])
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dbias = ops.colsum(dz)
+        return da1, da2, dwt, dbias, None, None
+
+
+class SmallKLinear(torch.autograd.Function):
+    """pre_mp: out = feat @ wt + bias with tiny K (gnn_model.py:131); feat carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, feat, wt, bias):
+        ctx.save_for_backward(feat)
+        return ops.linear_smallk(feat, wt.contiguous(), bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (feat,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dwt = None
+        if ctx.needs_input_grad[1]:
+            # K is 1 in the reference pipeline; a [K, n] product over M rows: K column-sums
+            dwt = torch.stack([ops.colsum(dout * feat[:, k:k + 1]) for k in range(feat.shape[1])])
+        return None, dwt, ops.colsum(dout)
+
+
+class SegmentSum(torch.autograd.Function):
+    """out[b] = sum_{rows of b} x + extra[b]; backward = broadcast (gather by segment id)."""
+
+    @staticmethod
+    def forward(ctx, x, seg_ptr, seg_id, ident_ptr, extra):
+        ctx.save_for_backward(seg_id, ident_ptr)
+        ctx.has_extra = extra is not None
+        return ops.segment_sum(x.contiguous(), seg_ptr, seg_ptr.numel() - 1, extra=extra)
+
+    @staticmethod
+    def backward(ctx, dout):
+        seg_id, ident_ptr = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = ops.csr_gather_sum(dout, ident_ptr, seg_id, seg_id.numel(), 1)   # dx[r] = dout[seg(r)]
+        return dx, None, None, None, (dout if ctx.has_extra else None)
+
+
+class CountHead(torch.autograd.Function):
+    """logit[b,q] = sum_c w2[c]*leaky(T[b,c]+Qh[q,c]) + b2 (lightning_model.py:176-193)."""
+
+    @staticmethod
+    def forward(ctx, t, qh, w2, b2, slope):
+        ctx.save_for_backward(t, qh, w2)
+        ctx.slope = slope
+        return ops.count_head(t, qh, w2, float(b2), slope, False)
+
+    @staticmethod
+    def backward(ctx, dl):
+        t, qh, w2 = ctx.saved_tensors
+        dt, dqh, dw2 = ops.count_head_bwd(t, qh, w2, ctx.slope, dl)
+        db2 = ops.colsum(dl.contiguous().view(-1, 1)).view(())
+        return dt, dqh, dw2, db2, None

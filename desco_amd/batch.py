@@ -20,7 +20,35 @@ def _i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
 
-class NeighborhoodBatch:
+def _transpose_index(vrowptr: np.ndarray, vcol: np.ndarray, n_src: int):
+    """For every source row, the virtual rows that read it (the index of the backward gather)."""
+    cnt = np.diff(vrowptr.astype(np.int64))
+    vrow_of_edge = np.repeat(np.arange(len(cnt), dtype=np.int64), cnt)
+    src = vcol.astype(np.int64)
+    order = np.argsort(src, kind="stable")
+    t_rowptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n_src))])
+    return t_rowptr, vrow_of_edge[order]
+
+
+class _TrainIndexMixin:
+    """Lazily built device indices the backward pass needs (transposed CSR, segment ids)."""
+
+    def train_index(self):
+        if getattr(self, "_train_index", None) is None:
+            vr = self.vrowptr.cpu().numpy()
+            vc = self.vcol.cpu().numpy()
+            t_rowptr, t_col = _transpose_index(vr, vc, self.num_rows)
+            seg_ptr = self._seg_ptr_host()
+            seg_id = np.repeat(np.arange(len(seg_ptr) - 1), np.diff(seg_ptr))
+            dev = self.vrowptr.device
+            self._train_index = {
+                "t_rowptr": _i32(t_rowptr, dev), "t_col": _i32(t_col, dev),
+                "seg_id": _i32(seg_id, dev), "ident_ptr": _i32(np.arange(len(seg_id) + 1), dev),
+            }
+        return self._train_index
+
+
+class NeighborhoodBatch(_TrainIndexMixin):
     """B canonical neighborhoods: N_c count rows followed by B canonical rows, 4-slot CSR."""
 
     slots = 4
@@ -44,6 +72,9 @@ class NeighborhoodBatch:
         if torch.device(device) == self.device:
             return self
         return NeighborhoodBatch(self.part, device, self.node_feature, self.y, self.input_dim)
+
+    def _seg_ptr_host(self):
+        return self.part.count_ptr.astype(np.int64)
 
     # PyG-style views -----------------------------------------------------------------------
     @property
@@ -77,7 +108,7 @@ def tconv_split(n: int, edges) -> Tuple[np.ndarray, np.ndarray]:
     return np.stack([src, dst]), T[src, dst] <= 1
 
 
-class QueryBatch:
+class QueryBatch(_TrainIndexMixin):
     """The query graphs as one single-type ("union_node") block with 2 relation slots
     (union_triangle, union_tride) -- lightning_model.py:37-87, 291-309."""
 
@@ -107,6 +138,9 @@ class QueryBatch:
         self.vcol = _i32(np.array([c for _, c in ents], dtype=np.int64), device)
         self.graph_ptr = _i32(gp, device)
         self.node_feature = None
+
+    def _seg_ptr_host(self):
+        return self.graph_ptr_host
 
 
 class GossipBatch:

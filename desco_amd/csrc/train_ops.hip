@@ -1,0 +1,263 @@
+// Backward-pass kernels of the DeSCo hot path (gfx950).  The forward kernels are linear maps with
+// pointwise non-linearities, so the backward pass needs only:
+//   * weight gradients   dWt[k,n] = A[M,k]^T * dZ[M,n]          -> gemm_tn (MFMA, split over M)
+//   * bias gradients     db[n]    = sum_m dZ[m,n]                -> colsum
+//   * activation masks   dZ = dC * act'(C)                       -> act_grad
+//   * count-head backward (lightning_model.py:176-193 in separable form)
+// Input gradients reuse the forward kernels: dA = dZ * W is desco_gemm_f32 with the un-transposed
+// weight, and the transpose of a CSR gather is a CSR gather over the transposed index.
+// Everything is deterministic: partial sums go to a workspace and are reduced in a fixed order
+// (no floating-point atomics).
+#include "common_device.hpp"
+
+namespace desco {
+
+constexpr int TK = 64, TN = 64, TMC = 32;   // output tile 64(k) x 64(n), M chunk of 32 rows
+
+// partial[s][k0:k0+64][n0:n0+64] = sum over the M slab s of A[m,k]^T dZ[m,n]
+__global__ __launch_bounds__(256) void gemm_tn_partial_kernel(const float* __restrict__ a,
+                                                              int64_t lda,
+                                                              const float* __restrict__ b,
+                                                              int64_t ldb, int64_t M, int K, int N,
+                                                              int64_t slab,
+                                                              float* __restrict__ partial) {
+  __shared__ float lds[2 * TMC * 64];
+  float* As = lds;              // [32 m][64 k]
+  float* Bs = lds + TMC * 64;   // [32 m][64 n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
+  const int64_t m_beg = (int64_t)blockIdx.z * slab;
+  const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  // staging map: 256 threads x 2 float4 cover a 32 x 64 chunk
+  const int srow = tid >> 4, sc4 = tid & 15;
+  for (int64_t m0 = m_beg; m0 < m_end; m0 += TMC) {
+    float4 va0, va1, vb0, vb1;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ra = m0 + srow, rb = m0 + srow + 16;
+    va0 = ra < m_end ? *reinterpret_cast<const float4*>(a + ra * lda + k0 + 4 * sc4) : zero;
+    va1 = rb < m_end ? *reinterpret_cast<const float4*>(a + rb * lda + k0 + 4 * sc4) : zero;
+    vb0 = ra < m_end ? *reinterpret_cast<const float4*>(b + ra * ldb + n0 + 4 * sc4) : zero;
+    vb1 = rb < m_end ? *reinterpret_cast<const float4*>(b + rb * ldb + n0 + 4 * sc4) : zero;
+    __syncthreads();   // previous chunk consumed
+    *reinterpret_cast<float4*>(As + srow * 64 + 4 * sc4) = va0;
+    *reinterpret_cast<float4*>(As + (srow + 16) * 64 + 4 * sc4) = va1;
+    *reinterpret_cast<float4*>(Bs + srow * 64 + 4 * sc4) = vb0;
+    *reinterpret_cast<float4*>(Bs + (srow + 16) * 64 + 4 * sc4) = vb1;
+    __syncthreads();
+    // MFMA: A-operand[i = k index][kk = m], B-operand[kk = m][j = n index]
+    const float* as = As + (lane >> 5) * 64 + wr * 32 + (lane & 31);
+    const float* bs = Bs + (lane >> 5) * 64 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int mm = 0; mm < TMC / 2; ++mm)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * mm * 64], bs[2 * mm * 64], acc, 0, 0, 0);
+  }
+  float* out = partial + ((int64_t)blockIdx.z * K + k0) * N + n0;
+  const int col = wc * 32 + (lane & 31);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    out[(int64_t)row * N + col] = acc[reg];
+  }
+}
+
+// out[i] (+)= sum_s partial[s][i]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              int64_t count, int splits,
+                                                              float* __restrict__ out, int64_t ldo,
+                                                              int ncols, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * count + i];
+  float* o = out + (i / ncols) * ldo + (i % ncols);
+  *o = accumulate ? *o + s : s;
+}
+
+// out[i] = sum_s partial[s*stride + offset + i]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_strided_kernel(const float* __restrict__ partial,
+                                                             int64_t stride, int64_t offset,
+                                                             int64_t count, int splits,
+                                                             float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * stride + offset + i];
+  out[i] = s;
+}
+
+// partial[s][n] = sum over the M slab s of x[m, n]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x,
+                                                             int64_t ldx, int64_t M, int N,
+                                                             int64_t slab,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t m_beg = (int64_t)blockIdx.y * slab;
+  const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
+  float s = 0.f;
+  if (c < N)
+    for (int64_t m = m_beg + wave; m < m_end; m += 4) s += x[m * ldx + c];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < N)
+    partial[(int64_t)blockIdx.y * N + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ __launch_bounds__(256) void act_grad_kernel(const float* __restrict__ dc,
+                                                       const float* __restrict__ c, int act,
+                                                       float slope, float* __restrict__ dz,
+                                                       int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float g = dc[i], y = c[i];
+  float d = g;
+  if (act == DESCO_ACT_RELU)
+    d = y > 0.f ? g : 0.f;
+  else if (act == DESCO_ACT_LEAKY)
+    d = y > 0.f ? g : g * slope;     // y and the pre-activation have the same sign (slope > 0)
+  dz[i] = d;
+}
+
+// count head backward, part 1: dT[b,c] = w2[c] * sum_q dl[b,q] * leaky'(T[b,c] + Qh[q,c])
+__global__ __launch_bounds__(256) void count_head_bwd_t_kernel(
+    const float* __restrict__ t, int64_t ldt, const float* __restrict__ qh, int64_t ldq, int hid,
+    const float* __restrict__ w2, float slope, const float* __restrict__ dl, int64_t lddl,
+    float* __restrict__ dt, int64_t lddt, int64_t num_b, int num_q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= num_b) return;
+  for (int c = lane; c < hid; c += 64) {
+    const float tv = t[b * ldt + c];
+    float s = 0.f;
+    for (int q = 0; q < num_q; ++q) {
+      const float z = tv + qh[(int64_t)q * ldq + c];
+      s += dl[b * lddl + q] * (z > 0.f ? 1.f : slope);
+    }
+    dt[b * lddt + c] = s * w2[c];
+  }
+}
+
+// part 2 (partials over b slabs): dQh[q,c] = w2[c] * sum_b dl*leaky'(z);  dw2[c] = sum_{b,q} dl*leaky(z)
+// partial layout: [slab][num_q + 1][hid]  (row num_q = dw2)
+__global__ __launch_bounds__(256) void count_head_bwd_q_kernel(
+    const float* __restrict__ t, int64_t ldt, const float* __restrict__ qh, int64_t ldq, int hid,
+    const float* __restrict__ w2, float slope, const float* __restrict__ dl, int64_t lddl,
+    int64_t num_b, int num_q, int64_t slab, float* __restrict__ partial) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= hid) return;
+  const int64_t b_beg = (int64_t)blockIdx.y * slab;
+  const int64_t b_end = (b_beg + slab) < num_b ? (b_beg + slab) : num_b;
+  float* out = partial + (int64_t)blockIdx.y * (num_q + 1) * hid;
+  const float wv = w2[c];
+  float dw = 0.f;
+  for (int q = 0; q < num_q; ++q) {
+    const float qv = qh[(int64_t)q * ldq + c];
+    float s = 0.f;
+    for (int64_t b = b_beg; b < b_end; ++b) {
+      const float z = t[b * ldt + c] + qv;
+      const float g = dl[b * lddl + q];
+      s += g * (z > 0.f ? 1.f : slope);
+      dw += g * (z > 0.f ? z : z * slope);
+    }
+    out[(int64_t)q * hid + c] = s * wv;
+  }
+  out[(int64_t)num_q * hid + c] = dw;
+}
+
+}  // namespace desco
+
+using namespace desco;
+
+extern "C" size_t desco_gemm_tn_workspace(int64_t m, int k, int n, int* splits_out) {
+  // enough M slabs to fill the chip a few times over, each at least 512 rows
+  const int64_t tiles = (int64_t)(k / TK) * (n / TN);
+  int64_t splits = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  const int64_t max_splits = (m + 511) / 512;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits_out) *splits_out = (int)splits;
+  return sizeof(float) * (size_t)splits * (size_t)k * (size_t)n;
+}
+
+extern "C" int desco_gemm_tn_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m,
+                                 int k, int n, float* out, int64_t ldo, int accumulate,
+                                 float* workspace, desco_stream_t stream) {
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (!a || !b || !out || !workspace || m < 0 || k <= 0 || n <= 0 || k % TK || n % TN || lda % 4 ||
+      ldb % 4 || mis16(a) || mis16(b))
+    return fail(DESCO_EINVAL, "desco_gemm_tn_f32: bad argument (k%64, n%64, 16-byte alignment)");
+  int splits = 1;
+  desco_gemm_tn_workspace(m, k, n, &splits);
+  int64_t slab = (m + splits - 1) / splits;
+  slab = (slab + TMC - 1) / TMC * TMC;
+  if (slab < TMC) slab = TMC;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_partial_kernel, dim3(k / TK, n / TN, splits), dim3(256), 0, st, a, lda, b,
+                     ldb, m, k, n, slab, workspace);
+  const int64_t count = (int64_t)k * n;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                     workspace, count, splits, out, ldo, n, accumulate);
+  return launch_status("desco_gemm_tn_f32");
+}
+
+extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out,
+                                int accumulate, float* workspace, desco_stream_t stream) {
+  if (!x || !out || !workspace || m < 0 || n <= 0)
+    return fail(DESCO_EINVAL, "desco_colsum_f32: bad argument");
+  int64_t splits = (m + 2047) / 2048;
+  if (splits > 512) splits = 512;
+  if (splits < 1) splits = 1;
+  const int64_t slab = (m + splits - 1) / splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, (unsigned)splits), dim3(256), 0, st, x,
+                     ldx, m, n, slab > 0 ? slab : 1, workspace);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     workspace, (int64_t)n, (int)splits, out, (int64_t)n, n, accumulate);
+  return launch_status("desco_colsum_f32");
+}
+
+extern "C" int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,
+                                  int64_t count, desco_stream_t stream) {
+  if (count == 0) return 0;
+  if (!dc || !c || !dz || count < 0) return fail(DESCO_EINVAL, "desco_act_grad_f32: bad argument");
+  const int64_t blocks = (count + 255) / 256;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_act_grad_f32: too many elements");
+  hipLaunchKernelGGL(act_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dc, c,
+                     act, slope, dz, count);
+  return launch_status("desco_act_grad_f32");
+}
+
+extern "C" int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq,
+                                        int hid, const float* w2, float slope, const float* dl,
+                                        int64_t lddl, int64_t num_b, int num_q, float* dt,
+                                        int64_t lddt, float* dqh, float* dw2, float* workspace,
+                                        desco_stream_t stream) {
+  if (!t || !qh || !w2 || !dl || !dt || !dqh || !dw2 || !workspace || num_b < 0 || num_q < 1 ||
+      hid <= 0)
+    return fail(DESCO_EINVAL, "desco_count_head_bwd_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (num_b > 0)
+    hipLaunchKernelGGL(count_head_bwd_t_kernel, dim3((unsigned)((num_b + 3) / 4)), dim3(256), 0, st, t,
+                       ldt, qh, ldq, hid, w2, slope, dl, lddl, dt, lddt, num_b, num_q);
+  int64_t splits = (num_b + 255) / 256;
+  if (splits > 256) splits = 256;
+  if (splits < 1) splits = 1;
+  const int64_t slab = (num_b + splits - 1) / splits;
+  hipLaunchKernelGGL(count_head_bwd_q_kernel, dim3((hid + 63) / 64, (unsigned)splits), dim3(64), 0, st,
+                     t, ldt, qh, ldq, hid, w2, slope, dl, lddl, num_b, num_q, slab > 0 ? slab : 1,
+                     workspace);
+  // partial layout [slab][num_q+1][hid]: rows 0..num_q-1 -> dQh, row num_q -> dw2
+  const int64_t cq = (int64_t)num_q * hid, stride = (int64_t)(num_q + 1) * hid;
+  hipLaunchKernelGGL(reduce_strided_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, st,
+                     workspace, stride, (int64_t)0, cq, (int)splits, dqh);
+  hipLaunchKernelGGL(reduce_strided_kernel, dim3((unsigned)((hid + 255) / 256)), dim3(256), 0, st,
+                     workspace, stride, cq, (int64_t)hid, (int)splits, dw2);
+  return launch_status("desco_count_head_bwd_f32");
+}

@@ -234,6 +234,8 @@ class BaseGNN(nn.Module):
             raise NotImplementedError(
                 "homogeneous SAGE (ablation, hetero_graph=False) is out of the hot path; call "
                 "to_hetero_old()/to_hetero() first (main.py:221-224)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return shmp_forward_train(self, data)
         return shmp_forward(self, data)
 
 
@@ -337,6 +339,53 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         for l, xl in enumerate(X):                 # query graphs: no canonical node, no anchor
             ops.segment_sum(xl, batch.graph_ptr, B, out=pooled[:, l * H:(l + 1) * H])
     return _post_mp(pk, pooled)                                            # :108
+
+
+def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
+    """Differentiable twin of ``shmp_forward`` (same math, un-fused kernels, autograd Functions from
+    desco_amd.autograd; every forward and backward op is a C-ABI kernel launch)."""
+    from . import autograd as AG
+    pk = pack_shmp(gnn)                      # differentiable folding: grads reach the raw parameters
+    core = gnn.gnn_core
+    dev = batch.vrowptr.device
+    N, S = batch.num_rows, batch.slots
+    ti = batch.train_index()
+    if isinstance(batch, NeighborhoodBatch):
+        Nc = batch.num_count
+        groups = [("count", 0, Nc, 4), ("canonical", Nc, N, 2)]
+        seg_ptr = batch.count_ptr
+    else:
+        Nc = N
+        groups = [("union_node", 0, N, 2)]
+        seg_ptr = batch.graph_ptr
+    feat = batch.node_feature
+    if feat is None:
+        feat = torch.zeros((N, core.input_dim), device=dev)
+    x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *pk["pre"][t]) for t, r0, r1, _ in groups], 0)
+    X = [x]
+    for l in range(core.layer_num):
+        agg = AG.GatherSum.apply(X[-1], batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col"], N, S)
+        parts = []
+        for t, r0, r1, su in groups:
+            e = pk["layers"][l][t]
+            parts.append(AG.Linear.apply(agg[r0:r1, :su * H], X[-1][r0:r1], e["wt"], e["b"],
+                                         ops.ACT_RELU, 0.0))
+        X.append(torch.cat(parts, 0))
+    if isinstance(batch, NeighborhoodBatch):
+        canon = torch.cat([xl[Nc:] for xl in X], dim=1)
+        aw, ab = pk["anchor"]
+        anch = AG.Linear.apply(canon, None, aw, ab, ops.ACT_LEAKY, 0.1)
+        pooled = torch.cat([AG.SegmentSum.apply(xl[:Nc], seg_ptr, ti["seg_id"], ti["ident_ptr"],
+                                                anch[:, l * H:(l + 1) * H].contiguous())
+                            for l, xl in enumerate(X)], dim=1)
+    else:
+        pooled = torch.cat([AG.SegmentSum.apply(xl, seg_ptr, ti["seg_id"], ti["ident_ptr"], None)
+                            for xl in X], dim=1)
+    (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
+    h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_LEAKY, 0.1)
+    h = AG.Linear.apply(h, None, w3, b3, ops.ACT_RELU, 0.0)
+    h = AG.Linear.apply(h, None, w5, b5, ops.ACT_RELU, 0.0)
+    return AG.Linear.apply(h, None, w7, b7, ops.ACT_NONE, 0.0)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -180,6 +180,49 @@ class NeighborhoodCountingModel(_LightningLike):
     def criterion(self, count, truth):                                       # :285-289
         return F.smooth_l1_loss(count, truth)
 
+    def train_forward(self, batch, batch_idx=0) -> torch.Tensor:            # :228-254
+        """mean_q smooth_l1(logit[:, q], log2(y[:, q] + 1)); forward and backward on the HIP
+        kernels (desco_amd.autograd)."""
+        from . import autograd as AG
+        batch = batch.to(self.device)
+        if batch.y is None:
+            raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
+        emb_q = self.emb_model_query(self._queries())
+        emb_t = self.emb_model(batch)
+        W1, b1 = self.count_model[0].weight, self.count_model[0].bias
+        T = AG.Linear.apply(emb_t, None, W1[:, :H].t(), None, ops.ACT_NONE, 0.0)
+        Qh = AG.Linear.apply(emb_q, None, W1[:, H:].t(), b1, ops.ACT_NONE, 0.0)
+        logits = AG.CountHead.apply(T, Qh, self.count_model[2].weight[0], self.count_model[2].bias[0],
+                                    self.count_model[1].negative_slope)
+        truth = torch.log2(batch.y.to(logits.dtype) + 1)
+        # mean over queries of per-query means == mean over all [B, Q] entries
+        return self.criterion(logits, truth)
+
+    def training_step(self, batch, batch_idx):                               # :133-136
+        loss = self.train_forward(batch, batch_idx)
+        self.log("neighborhood_counting_train_loss", loss, batch_size=batch.num_graphs)
+        return loss
+
+    def validation_step(self, batch, batch_idx):                             # :147-154
+        with torch.no_grad():
+            loss = self.test_forward(batch, batch_idx, train_space=True)
+        self.log("neighborhood_counting_val_loss", loss, batch_size=batch.num_graphs, sync_dist=True)
+        return loss
+
+    def test_step(self, batch, batch_idx):                                   # :138-145
+        with torch.no_grad():
+            loss = self.test_forward(batch, batch_idx)
+        self.log("neighborhood_counting_test_loss", loss, batch_size=batch.num_graphs, sync_dist=True)
+        return loss
+
+    def test_forward(self, batch, batch_idx=0, train_space: bool = False) -> torch.Tensor:   # :256-283
+        batch = batch.to(self.device)
+        logits = self._logits(batch, exp2=False)
+        y = batch.y.to(logits.dtype)
+        if train_space:
+            return self.criterion(logits, torch.log2(y + 1))
+        return self.criterion(F.relu(2 ** (logits - 1)), y)
+
     def configure_optimizers(self):                                          # :160-173
         optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
         sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,

@@ -311,3 +311,77 @@ def rowdot_add(y: torch.Tensor, w: torch.Tensor, b: float, add: Optional[torch.T
                                           _opt(add, "add"), _dev(out, "out"), R, _stream()),
                    "rowdot_add")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# backward-pass entry points (csrc/train_ops.hip)
+# ------------------------------------------------------------------------------------------------
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
+            accumulate: bool = False) -> torch.Tensor:
+    """out[k, n] (+)= a[m, k]^T @ b[m, n]  (weight gradient; deterministic split-M reduction)."""
+    import ctypes
+    m, k = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((k, n), device=a.device, dtype=torch.float32)
+        accumulate = False
+    ap, lda = _rows(a, "a")
+    bp, ldb = _rows(b, "b")
+    op, ldo = _rows(out, "out")
+    L = _lib.lib()
+    splits = ctypes.c_int(0)
+    nbytes = L.desco_gemm_tn_workspace(m, k, n, ctypes.byref(splits))
+    ws = torch.empty((max(nbytes // 4, 1),), device=a.device, dtype=torch.float32)
+    with _Timed("gemm_tn_partial_kernel", 2.0 * m * k * n, 4.0 * (m * k + m * n)):
+        _lib.check(L.desco_gemm_tn_f32(ap, lda, bp, ldb, m, k, n, op, ldo, int(accumulate),
+                                       _dev(ws, "ws"), _stream()), "gemm_tn")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out[n] (+)= sum_m x[m, n]  (bias gradient)."""
+    m, n = x.shape
+    if out is None:
+        out = torch.empty((n,), device=x.device, dtype=torch.float32)
+        accumulate = False
+    xp, ldx = _rows(x, "x")
+    ws = torch.empty((512 * n,), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    with _Timed("colsum_partial_kernel", float(m) * n, 4.0 * m * n):
+        _lib.check(L.desco_colsum_f32(xp, ldx, m, n, _dev(out, "out"), int(accumulate),
+                                      _dev(ws, "ws"), _stream()), "colsum")
+    return out
+
+
+def act_grad(dc: torch.Tensor, c: torch.Tensor, act: int, slope: float) -> torch.Tensor:
+    """dz = dc * act'(c) with c the activation OUTPUT (contiguous tensors of equal shape)."""
+    if act == ACT_NONE:
+        return dc
+    dc, c = dc.contiguous(), c.contiguous()
+    dz = torch.empty_like(dc)
+    L = _lib.lib()
+    with _Timed("act_grad_kernel", float(dc.numel()), 12.0 * dc.numel()):
+        _lib.check(L.desco_act_grad_f32(_dev(dc, "dc"), _dev(c, "c"), act, slope, _dev(dz, "dz"),
+                                        dc.numel(), _stream()), "act_grad")
+    return dz
+
+
+def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: float,
+                   dl: torch.Tensor):
+    """Backward of count_head (logit mode): returns (dT [B,hid], dQh [Q,hid], dw2 [hid])."""
+    B, hid = t.shape
+    Q = qh.shape[0]
+    dl = dl.contiguous()
+    dt = torch.empty((B, hid), device=t.device, dtype=torch.float32)
+    dqh = torch.empty((Q, hid), device=t.device, dtype=torch.float32)
+    dw2 = torch.empty((hid,), device=t.device, dtype=torch.float32)
+    ws = torch.empty((256 * (Q + 1) * hid,), device=t.device, dtype=torch.float32)
+    tp, ldt = _rows(t, "t")
+    qp, ldq = _rows(qh, "qh")
+    L = _lib.lib()
+    with _Timed("count_head_bwd", 6.0 * B * Q * hid, 4.0 * (2 * B * hid + Q * hid + B * Q)):
+        _lib.check(L.desco_count_head_bwd_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"),
+                                              slope, _dev(dl, "dl"), Q, B, Q, _dev(dt, "dt"), hid,
+                                              _dev(dqh, "dqh"), _dev(dw2, "dw2"), _dev(ws, "ws"),
+                                              _stream()), "count_head_bwd")
+    return dt, dqh, dw2

@@ -186,6 +186,37 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
 int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, const float* w, float b,
                          const float* add, float* out, int64_t num_rows, desco_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward pass (training, lightning_model.py:228-254 train_forward + autograd in the reference).
+ * Input gradients reuse the forward entry points (dA = dZ * W is desco_gemm_f32 with the
+ * un-transposed weight; the transpose of a CSR gather is desco_csr_gather_sum_f32 over the
+ * transposed index).  All reductions are deterministic (workspace partials, fixed order).
+ * ------------------------------------------------------------------------------------------ */
+
+/* bytes of workspace desco_gemm_tn_f32 needs for this shape (and the number of M slabs it uses) */
+size_t desco_gemm_tn_workspace(int64_t m, int k, int n, int* splits_out);
+
+/* weight gradient: out[k, n] (+)= A[m, k]^T * B[m, n];  k % 64 == 0, n % 64 == 0 */
+int desco_gemm_tn_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int k,
+                      int n, float* out, int64_t ldo, int accumulate, float* workspace,
+                      desco_stream_t stream);
+
+/* bias gradient: out[n] (+)= sum_m x[m, n];  workspace: 512 * n floats */
+int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out, int accumulate,
+                     float* workspace, desco_stream_t stream);
+
+/* dz = dc * act'(c) for c = act(z) (contiguous, count elements) */
+int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,
+                       int64_t count, desco_stream_t stream);
+
+/* backward of desco_count_head_f32 (logit mode): given dl[b,q] = dLoss/dlogit,
+ * dt[b,c], dqh[q,c] (contiguous [num_q, hid]), dw2[c];  (db2 = sum dl is left to the caller)
+ * workspace: 256 * (num_q+1) * hid floats */
+int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq, int hid,
+                             const float* w2, float slope, const float* dl, int64_t lddl,
+                             int64_t num_b, int num_q, float* dt, int64_t lddt, float* dqh,
+                             float* dw2, float* workspace, desco_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
