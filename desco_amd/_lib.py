@@ -46,6 +46,9 @@ SIGNATURES = {
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),
     "desco_count_head_bwd_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, i64, i64, i32, vp, i64,
                                          vp, vp, vp, vp]),
+    "desco_affine_rows_f32": (c_int, [vp, vp, i32, vp, i32, i32, f32, vp, i64, vp]),
+    "desco_affine_rows_bwd_f32": (c_int, [vp, i32, vp, i32, i64, vp, vp, vp]),
+    "desco_rowdot2_f32": (c_int, [vp, vp, i32, vp, i64, vp]),
     "desco_rowdot_add_f32": (c_int, [vp, i64, i32, vp, f32, vp, vp, i64, vp]),
 }
 

@@ -116,3 +116,44 @@ class CountHead(torch.autograd.Function):
         dt, dqh, dw2 = ops.count_head_bwd(t, qh, w2, ctx.slope, dl)
         db2 = ops.colsum(dl.contiguous().view(-1, 1)).view(())
         return dt, dqh, dw2, db2, None
+
+
+class AffineRows(torch.autograd.Function):
+    """out = act(base + sum_k c[:,k] * v[row % QV, k, :]); c is a constant, v (and base) learn."""
+
+    @staticmethod
+    def forward(ctx, base, c, v, act, slope):
+        out = ops.affine_rows(base, c, v, act, slope)
+        ctx.save_for_backward(c, out)
+        ctx.qv, ctx.act, ctx.slope, ctx.has_base = v.shape[0], act, slope, base is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        c, out = ctx.saved_tensors
+        dz = ops.act_grad(dout.contiguous(), out, ctx.act, ctx.slope)
+        dv = ops.affine_rows_bwd(c, dz, ctx.qv) if ctx.needs_input_grad[2] else None
+        return (dz if ctx.has_base else None), None, dv, None, None
+
+
+class GossipGather(torch.autograd.Function):
+    """out[i,q] = sum_j (j<i ? g[q] : 1-g[q]) * h[j,q]  (GossipConv message+aggregate,
+    gnn_model.py:335-344, aggregate-then-transform); differentiable in h and in the gate g."""
+
+    @staticmethod
+    def forward(ctx, h, rowptr, col, num_nodes, num_q, g):
+        ctx.save_for_backward(h, rowptr, col, g)
+        ctx.n, ctx.q = num_nodes, num_q
+        return ops.gossip_gather(h.contiguous(), rowptr, col, num_nodes, num_q, g)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, rowptr, col, g = ctx.saved_tensors
+        dout = dout.contiguous()
+        dh = dg = None
+        if ctx.needs_input_grad[0]:     # transpose of the gated sum: the same kernel with 1 - g
+            dh = ops.gossip_gather(dout, rowptr, col, ctx.n, ctx.q, (1.0 - g).contiguous())
+        if ctx.needs_input_grad[5]:     # d out / d g = sum_{j<i} h_j - sum_{j>i} h_j
+            d = ops.gossip_gather(h.contiguous(), rowptr, col, ctx.n, ctx.q, None)
+            dg = ops.colsum(ops.rowdot2(dout, d).view(ctx.n, ctx.q))
+        return dh, None, None, None, None, dg

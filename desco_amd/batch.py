@@ -163,6 +163,11 @@ class GossipBatch:
         self.x = None if x is None else x.to(device).float().contiguous()
         self.y = None if y is None else y.to(device)
 
+    def to(self, device):
+        if torch.device(device) == self.device:
+            return self
+        return GossipBatch(self.graphs, device, self.x, self.y)
+
     @property
     def edge_index(self):
         rp = self.graphs.rowptr

@@ -61,13 +61,14 @@ __global__ __launch_bounds__(256) void gossip_gather_kernel(const float* __restr
                                                             const int32_t* __restrict__ col,
                                                             int64_t num_nodes, int Q,
                                                             const float* __restrict__ g,
+                                                            int signed_mode,
                                                             float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
   const int64_t i = idx / Q;
   if (i >= num_nodes) return;
   const int q = (int)(idx % Q);
-  const float gq = g[q];
+  const float gq = signed_mode ? 0.f : g[q];
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   float lo = 0.f, hi = 0.f;
   for (int e = e0; e < e1; ++e) {
@@ -78,7 +79,75 @@ __global__ __launch_bounds__(256) void gossip_gather_kernel(const float* __restr
     else
       hi += v;
   }
-  out[idx * 64 + lane] = gq * lo + (1.f - gq) * hi;
+  // signed_mode: lo - hi (d/dg of the gated sum), else g*lo + (1-g)*hi
+  out[idx * 64 + lane] = signed_mode ? lo - hi : gq * lo + (1.f - gq) * hi;
+}
+
+// out[r,:] = act( base[r,:] + sum_{k<KS} C[r,k] * V[r % QV][k][:] )   (rank-KS per-query affine term)
+__global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restrict__ base,
+                                                          const float* __restrict__ C, int KS,
+                                                          const float* __restrict__ V, int QV,
+                                                          int act, float slope,
+                                                          float* __restrict__ out, int64_t R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float* v = V + (int64_t)(r % QV) * KS * 64 + lane;
+  float acc = base ? base[r * 64 + lane] : 0.f;
+  for (int k = 0; k < KS; ++k) acc += C[r * KS + k] * v[k * 64];
+  out[r * 64 + lane] = apply_act(acc, act, slope);
+}
+
+// partial[slab][qv][k][c] = sum over rows r = i*QV + qv of the slab of C[r,k] * dZ[r,c]
+__global__ __launch_bounds__(256) void affine_rows_bwd_kernel(const float* __restrict__ C, int KS,
+                                                              const float* __restrict__ dZ, int QV,
+                                                              int64_t num_i, int64_t slab,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[4][8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qv = blockIdx.x;
+  const int64_t i_beg = (int64_t)blockIdx.y * slab;
+  const int64_t i_end = (i_beg + slab) < num_i ? (i_beg + slab) : num_i;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int64_t i = i_beg + wave; i < i_end; i += 4) {
+    const int64_t r = i * QV + qv;
+    const float d = dZ[r * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < KS) acc[k] += C[r * KS + k] * d;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wave][k][lane] = acc[k];
+  __syncthreads();
+  if (wave == 0) {
+    float* o = partial + (((int64_t)blockIdx.y * QV + qv) * KS) * 64 + lane;
+    for (int k = 0; k < KS; ++k)
+      o[k * 64] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ partial,
+                                                           int64_t count, int splits,
+                                                           float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * count + i];
+  out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void rowdot2_kernel(const float* __restrict__ a,
+                                                      const float* __restrict__ b, int ncols,
+                                                      float* __restrict__ out, int64_t R) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  float acc = 0.f;
+  for (int c = lane; c < ncols; c += 64) acc += a[r * ncols + c] * b[r * ncols + c];
+  acc = wave_sum(acc);
+  if (lane == 0) out[r] = acc;
 }
 
 }  // namespace desco
@@ -106,11 +175,56 @@ extern "C" int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, co
                                        int64_t num_nodes, int num_q, const float* g, float* out,
                                        desco_stream_t stream) {
   if (num_nodes == 0) return 0;
-  if (!h || !rowptr || !g || !out || num_nodes < 0 || num_q < 1)
+  if (!h || !rowptr || !out || num_nodes < 0 || num_q < 1)
     return fail(DESCO_EINVAL, "desco_gossip_gather_f32: bad argument");
   const int64_t blocks = (num_nodes * num_q + 3) / 4;
   if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_gather_f32: too many rows");
   hipLaunchKernelGGL(gossip_gather_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, h, rowptr, col, num_nodes, num_q, g, out);
+                     (hipStream_t)stream, h, rowptr, col, num_nodes, num_q, g, g ? 0 : 1, out);
   return launch_status("desco_gossip_gather_f32");
+}
+
+extern "C" int desco_affine_rows_f32(const float* base, const float* c, int ks, const float* v,
+                                     int qv, int act, float slope, float* out, int64_t num_rows,
+                                     desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  if (!c || !v || !out || ks < 1 || ks > 8 || qv < 1 || num_rows < 0)
+    return fail(DESCO_EINVAL, "desco_affine_rows_f32: bad argument (1 <= ks <= 8)");
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_affine_rows_f32: too many rows");
+  hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     base, c, ks, v, qv, act, slope, out, num_rows);
+  return launch_status("desco_affine_rows_f32");
+}
+
+extern "C" int desco_affine_rows_bwd_f32(const float* c, int ks, const float* dz, int qv,
+                                         int64_t num_rows, float* dv, float* workspace,
+                                         desco_stream_t stream) {
+  if (!c || !dz || !dv || !workspace || ks < 1 || ks > 8 || qv < 1 || num_rows < 0 ||
+      num_rows % qv)
+    return fail(DESCO_EINVAL, "desco_affine_rows_bwd_f32: bad argument");
+  const int64_t num_i = num_rows / qv;
+  int64_t splits = (num_i + 1023) / 1024;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  const int64_t slab = (num_i + splits - 1) / splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(affine_rows_bwd_kernel, dim3((unsigned)qv, (unsigned)splits), dim3(256), 0, st, c,
+                     ks, dz, qv, num_i, slab > 0 ? slab : 1, workspace);
+  const int64_t count = (int64_t)qv * ks * 64;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                     workspace, count, (int)splits, dv);
+  return launch_status("desco_affine_rows_bwd_f32");
+}
+
+extern "C" int desco_rowdot2_f32(const float* a, const float* b, int ncols, float* out,
+                                 int64_t num_rows, desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  if (!a || !b || !out || ncols < 1 || num_rows < 0)
+    return fail(DESCO_EINVAL, "desco_rowdot2_f32: bad argument");
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_rowdot2_f32: too many rows");
+  hipLaunchKernelGGL(rowdot2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+                     ncols, out, num_rows);
+  return launch_status("desco_rowdot2_f32");
 }

@@ -259,6 +259,33 @@ class GossipCountingModel(_LightningLike):
     def criterion(self, count, truth):                                      # :630-635
         return torch.log2(torch.abs(count - truth) + 1)
 
+    def train_forward(self, batch: GossipBatch, batch_idx=0) -> torch.Tensor:   # :585-608
+        """sum over queries and nodes of log2(|neigh_pred + gossip_pred - truth| + 1)."""
+        if self.query_emb is None:
+            raise RuntimeError("call set_query_emb() first (main.py:334)")
+        batch = batch.to(self.device)
+        if batch.y is None:
+            raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
+        pred = self.emb_model(batch, query_emb=self.query_emb.to(self.device))
+        return torch.sum(self.criterion(pred, batch.y.to(pred.dtype)))
+
+    def training_step(self, batch, batch_idx):                              # :553-556
+        loss = self.train_forward(batch, batch_idx)
+        self.log("gossip_counting_train_loss", loss, batch_size=batch.num_graphs)
+        return loss
+
+    def validation_step(self, batch, batch_idx):                            # :562-564
+        with torch.no_grad():
+            loss = self.train_forward(batch, batch_idx)
+        self.log("gossip_counting_val_loss", loss, batch_size=batch.num_graphs)
+        return loss
+
+    def test_step(self, batch, batch_idx):                                  # :558-560
+        with torch.no_grad():
+            loss = self.train_forward(batch, batch_idx)
+        self.log("gossip_counting_test_loss", loss, batch_size=batch.num_graphs)
+        return loss
+
     def _gate_value(self, query_emb) -> torch.Tensor:                       # :640-649
         assert self.conv_type == "GOSSIP"
         with torch.no_grad():

@@ -247,8 +247,9 @@ def gossip_layer0(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, 
 
 
 def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
-                  num_q: int, g: torch.Tensor) -> torch.Tensor:
-    """out[i,q,:] = sum_j (j<i ? g[q] : 1-g[q]) * h[j,q,:]   (h: [N*Q, 64] contiguous)."""
+                  num_q: int, g: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[i,q,:] = sum_j (j<i ? g[q] : 1-g[q]) * h[j,q,:]   (h: [N*Q, 64] contiguous);
+    g=None: the signed form sum_{j<i} h[j] - sum_{j>i} h[j]."""
     assert h.is_contiguous()
     out = torch.empty_like(h)
     L = _lib.lib()
@@ -256,7 +257,8 @@ def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_
                 512.0 * num_nodes * num_q + 4.0 * (col.numel() + num_nodes)):
       _lib.check(L.desco_gossip_gather_f32(_dev(h, "h"), _dev(rowptr, "rowptr", torch.int32),
                                          _dev(col, "col", torch.int32), num_nodes, num_q,
-                                         _dev(g.contiguous(), "g"), _dev(out, "out"), _stream()),
+                                         None if g is None else _dev(g.contiguous(), "g"),
+                                         _dev(out, "out"), _stream()),
                "gossip_gather")
     return out
 
@@ -385,3 +387,47 @@ def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: f
                                               _dev(dqh, "dqh"), _dev(dw2, "dw2"), _dev(ws, "ws"),
                                               _stream()), "count_head_bwd")
     return dt, dqh, dw2
+
+
+def affine_rows(base: Optional[torch.Tensor], c: torch.Tensor, v: torch.Tensor, act: int,
+                slope: float) -> torch.Tensor:
+    """out[r,:] = act(base[r,:] + sum_k c[r,k] * v[r % QV, k, :]);  v: [QV, KS, 64], c: [R, KS]."""
+    R, ks = c.shape
+    qv = v.shape[0]
+    assert v.shape == (qv, ks, 64) and c.is_contiguous()
+    v = v.contiguous()
+    out = torch.empty((R, 64), device=c.device, dtype=torch.float32)
+    if base is not None:
+        base = base.contiguous()
+    L = _lib.lib()
+    with _Timed("affine_rows_kernel", 2.0 * R * ks * 64, 4.0 * R * (ks + 128)):
+        _lib.check(L.desco_affine_rows_f32(_opt(base, "base"), _dev(c, "c"), ks, _dev(v, "v"), qv,
+                                           act, slope, _dev(out, "out"), R, _stream()),
+                   "affine_rows")
+    return out
+
+
+def affine_rows_bwd(c: torch.Tensor, dz: torch.Tensor, qv: int) -> torch.Tensor:
+    """dv[q, k, :] = sum_{r = i*qv + q} c[r, k] * dz[r, :]."""
+    R, ks = c.shape
+    dz = dz.contiguous()
+    dv = torch.empty((qv, ks, 64), device=c.device, dtype=torch.float32)
+    ws = torch.empty((64 * qv * ks * 64,), device=c.device, dtype=torch.float32)
+    L = _lib.lib()
+    with _Timed("affine_rows_bwd_kernel", 2.0 * R * ks * 64, 4.0 * R * (ks + 64)):
+        _lib.check(L.desco_affine_rows_bwd_f32(_dev(c, "c"), ks, _dev(dz, "dz"), qv, R,
+                                               _dev(dv, "dv"), _dev(ws, "ws"), _stream()),
+                   "affine_rows_bwd")
+    return dv
+
+
+def rowdot2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out[r] = a[r,:] . b[r,:]"""
+    a, b = a.contiguous(), b.contiguous()
+    R, n = a.shape
+    out = torch.empty((R,), device=a.device, dtype=torch.float32)
+    L = _lib.lib()
+    with _Timed("rowdot2_kernel", 2.0 * R * n, 8.0 * R * n):
+        _lib.check(L.desco_rowdot2_f32(_dev(a, "a"), _dev(b, "b"), n, _dev(out, "out"), R,
+                                       _stream()), "rowdot2")
+    return out

@@ -155,7 +155,8 @@ int desco_gossip_layer0_f32(const float* x, int64_t ldx, const int32_t* rowptr, 
                             float* h1, float* scal, desco_stream_t stream);
 
 /* K18/K19 for layers >= 1, aggregate-then-transform form:
- * out[i,q,:] = sum_{j~i} (j<i ? g[q] : 1-g[q]) * h[j,q,:]      (h, out: [num_nodes, num_q, 64]) */
+ * out[i,q,:] = sum_{j~i} (j<i ? g[q] : 1-g[q]) * h[j,q,:]      (h, out: [num_nodes, num_q, 64])
+ * g == NULL selects the signed form sum_{j<i} h[j] - sum_{j>i} h[j] (= d out / d g, training). */
 int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t* col,
                             int64_t num_nodes, int num_q, const float* g, float* out,
                             desco_stream_t stream);
@@ -216,6 +217,19 @@ int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float* qh, int64
                              const float* w2, float slope, const float* dl, int64_t lddl,
                              int64_t num_b, int num_q, float* dt, int64_t lddt, float* dqh,
                              float* dw2, float* workspace, desco_stream_t stream);
+
+/* Training-path helpers of the gossip stage (the fused inference kernel has the same terms folded
+ * into its epilogues): a rank-ks affine term with per-query coefficient vectors,
+ *   out[r,:] = act( base[r,:] + sum_{k<ks} c[r,k] * v[r % qv][k][:] ),   rows of 64, ks <= 8,
+ * its weight gradient dv[qv][k][:] = sum_{r = i*qv+q} c[r,k] * dz[r,:]
+ * (workspace: 64 * qv * ks * 64 floats), and a row-wise dot product out[r] = a[r,:] . b[r,:]. */
+int desco_affine_rows_f32(const float* base, const float* c, int ks, const float* v, int qv,
+                          int act, float slope, float* out, int64_t num_rows,
+                          desco_stream_t stream);
+int desco_affine_rows_bwd_f32(const float* c, int ks, const float* dz, int qv, int64_t num_rows,
+                              float* dv, float* workspace, desco_stream_t stream);
+int desco_rowdot2_f32(const float* a, const float* b, int ncols, float* out, int64_t num_rows,
+                      desco_stream_t stream);
 
 #ifdef __cplusplus
 }

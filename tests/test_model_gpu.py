@@ -209,3 +209,44 @@ def test_neighborhood_adam_steps_reduce_loss(setup):
     with torch.no_grad():
         val = nm.test_forward(batch, 0, train_space=True)
     assert abs(float(val) - float(nm.train_forward(batch, 0))) < 1e-3
+
+
+def test_gossip_training_loss_and_gradients(setup):
+    """GossipCountingModel.train_forward + backward vs torch autograd through the CPU oracle
+    (lightning_model.py:585-608, 630-635)."""
+    nm, gm0, qids, queries = setup
+    _, gm = make_models(seed=0)
+    gm = gm.to(DEV)
+    graphs = golden_graphs(max_n=41)[:12]
+    gs = GraphSet.from_edge_lists(graphs)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(gs.num_nodes, len(queries), generator=g) * 20
+    y = torch.floor(torch.rand(gs.num_nodes, len(queries), generator=g) * 25)
+    qemb = nm.get_query_emb()
+    gm.set_query_emb(qemb)
+    batch = GossipBatch(gs, DEV, x=x, y=y)
+    gm.zero_grad()
+    loss = gm.train_forward(batch, 0)
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in gm.state_dict().items()}
+    ref_loss = OM.gossip_loss(sd, x, y, batch.edge_index.numpy(), qemb.cpu(), 2)
+    ref_loss.backward()
+    report("gossip train loss", loss.detach().reshape(1), ref_loss.detach().reshape(1))
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-4, atol=1e-2)
+    worst = 0.0
+    for name, p in gm.named_parameters():
+        ref = sd[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:   # pre_mp (detached input) and anchor_mlp
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        scale = float(ref.abs().max())
+        err = float((p.grad.cpu() - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 5e-3, (name, err, scale)
+    print(f"[parity] gossip worst relative gradient error: {worst:.3e}")
+    # inference path and training path agree on the forward
+    with torch.no_grad():
+        pred = gm.graph_to_count(batch)
+    pred_t = gm.emb_model(batch, query_emb=qemb)
+    torch.testing.assert_close(pred, pred_t.detach(), rtol=1e-4, atol=1e-3)
