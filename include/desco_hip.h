@@ -79,6 +79,17 @@ int desco_partition_export(const desco_partition* p, int64_t* neigh_index, uint8
                            int32_t* vcol);
 void desco_partition_free(desco_partition* p);
 
+/* HOST: exact canonical (induced, symmetry-normalised) counts of connected query graphs with
+ * 2..6 nodes for every node of every graph: out[v][q] = #{S : max(S) = v, G[S] isomorphic to q}.
+ * Replaces the VF2 ground truth (workload.py:327-348 MatchSubgraphWorker divided by
+ * data.py:61-88 SymmetricFactor; driver workload.py:551-726).  Query q has q_nodes[q] nodes and the
+ * undirected edges q_edges[2*e], q_edges[2*e+1] for e in [q_edge_ptr[q], q_edge_ptr[q+1]).
+ * out: int64 [num_nodes][num_queries]. */
+int desco_canonical_counts(const int64_t* graph_ptr, int64_t num_graphs, const int64_t* rowptr,
+                           const int32_t* col, const int32_t* q_nodes, const int32_t* q_edge_ptr,
+                           const int32_t* q_edges, int num_queries, int num_threads,
+                           int64_t* out);
+
 /* ------------------------------------------------------------------------------------------
  * DEVICE kernels
  * ------------------------------------------------------------------------------------------ */
