@@ -161,6 +161,32 @@ __global__ __launch_bounds__(256) void rowdot_add_kernel(const float* __restrict
   if (lane == 0) out[r] = (add ? add[r] : 0.f) + acc + b;
 }
 
+// First SHMP layer when every node of a type carries the same input row (all-zero node features:
+// pre_mp output = its bias, workload.py:431-440): the aggregate of slot s is deg_s(i) * x0_src(s),
+// so the layer is  out[i] = act( coef[S] + sum_s deg_s(i) * coef[s] ) (+ extra[i]) -- no gather, no GEMM.
+__global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __restrict__ vrowptr,
+                                                            int64_t row0, int64_t num_rows, int S,
+                                                            const float* __restrict__ coef, int act,
+                                                            float slope,
+                                                            const float* __restrict__ extra,
+                                                            int64_t ld_extra,
+                                                            float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= num_rows) return;
+  const int64_t v = (row0 + i) * S;
+  float acc = coef[S * 64 + lane];
+  int prev = vrowptr[v];
+  for (int s = 0; s < S; ++s) {
+    const int nxt = vrowptr[v + s + 1];
+    acc += (float)(nxt - prev) * coef[s * 64 + lane];
+    prev = nxt;
+  }
+  acc = apply_act(acc, act, slope);
+  if (extra) acc += extra[i * ld_extra + lane];
+  out[(row0 + i) * ldo + lane] = acc;
+}
+
 inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= INT32_MAX; }
 
 }  // namespace desco
@@ -255,4 +281,18 @@ extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, cons
   hipLaunchKernelGGL(rowdot_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      y, ldy, ncols, w, b, add, out, num_rows);
   return launch_status("desco_rowdot_add_f32");
+}
+
+extern "C" int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_rows,
+                                       int slots, const float* coef, int act, float slope,
+                                       const float* extra, int64_t ld_extra, float* out,
+                                       int64_t ldo, desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  if (!vrowptr || !coef || !out || row0 < 0 || num_rows < 0 || slots < 1 || slots > 8)
+    return fail(DESCO_EINVAL, "desco_degree_affine_f32: bad argument");
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_degree_affine_f32: too many rows");
+  hipLaunchKernelGGL(degree_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     vrowptr, row0, num_rows, slots, coef, act, slope, extra, ld_extra, out, ldo);
+  return launch_status("desco_degree_affine_f32");
 }

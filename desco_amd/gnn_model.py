@@ -298,14 +298,36 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         Nc = N
         groups = [("union_node", 0, N, 2)]
     feat = batch.node_feature
-    if feat is None:   # ZeroNodeFeat (workload.py:431-440)
-        feat = torch.zeros((N, core.input_dim), device=dev)
-    x = torch.empty((N, H), device=dev)
-    for t, r0, r1, _ in groups:
-        wt, b = pk["pre"][t]
-        ops.linear_smallk(feat[r0:r1], wt, b, out=x[r0:r1])               # :231
-    X = [x]
-    for l in range(core.layer_num):
+    const_input = feat is None and FUSED_SHMP_LAYER and core.layer_num >= 1
+    if const_input:
+        # ZeroNodeFeat (workload.py:431-440): pre_mp(x) is its bias, identical for every node of a
+        # type, so X_0 is never materialised and layer 0 is a degree-affine map (desco_hip.h).
+        x0 = {t: pk["pre"][t][1] for t, *_ in groups}
+        src_of_slot = (lambda t, s: ("count" if s < 2 else "canonical")) if len(groups) == 2 else \
+            (lambda t, s: t)
+        xn = torch.empty((N, H), device=dev)
+        for t, r0, r1, su in groups:
+            if r1 <= r0:
+                continue
+            e = pk["layers"][0][t]
+            wt = e["wt"]                                        # [(su+1)*64, 64]
+            rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
+            rows += [torch.zeros(H, device=dev)] * (S - su)     # unused slots of this type
+            rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
+            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, torch.stack(rows).contiguous(),
+                              ops.ACT_RELU, 0.0, xn)
+        X = [None, xn]
+        first = 1
+    else:
+        if feat is None:
+            feat = torch.zeros((N, core.input_dim), device=dev)
+        x = torch.empty((N, H), device=dev)
+        for t, r0, r1, _ in groups:
+            wt, b = pk["pre"][t]
+            ops.linear_smallk(feat[r0:r1], wt, b, out=x[r0:r1])               # :231
+        X = [x]
+        first = 0
+    for l in range(first, core.layer_num):
         xn = torch.empty((N, H), device=dev)
         if FUSED_SHMP_LAYER:
             for t, r0, r1, su in groups:                                   # :262-264, :273, :389-395
@@ -331,15 +353,23 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     P = H * (core.layer_num + 1)
     pooled = torch.empty((B, P), device=dev)
     if isinstance(batch, NeighborhoodBatch):
-        canon = torch.cat([xl[Nc:] for xl in X], dim=1)                    # emb["canonical"] [B,P]
+        c0 = x0["canonical"].expand(B, H) if const_input else X[0][Nc:]
+        canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)            # emb["canonical"] [B,P]
         aw, ab = pk["anchor"]
         anch = ops.gemm(canon, aw, ab, act=ops.ACT_LEAKY, slope=0.1)       # :69-73
-        for l, xl in enumerate(X):                                         # :88-89, :107
-            ops.segment_sum(xl[:Nc], batch.count_ptr, B, extra=anch[:, l * H:(l + 1) * H],
-                            out=pooled[:, l * H:(l + 1) * H])
+        seg_ptr = batch.count_ptr
     else:
-        for l, xl in enumerate(X):                 # query graphs: no canonical node, no anchor
-            ops.segment_sum(xl, batch.graph_ptr, B, out=pooled[:, l * H:(l + 1) * H])
+        anch = None                                  # query graphs: no canonical node, no anchor
+        seg_ptr = batch.graph_ptr
+    for l, xl in enumerate(X):                                             # :88-89, :107
+        extra = None if anch is None else anch[:, l * H:(l + 1) * H]
+        out_l = pooled[:, l * H:(l + 1) * H]
+        if xl is None:       # constant X_0: the segment sum is (rows in segment) * x0
+            t0 = groups[0][0]
+            coef = torch.stack([x0[t0], torch.zeros(H, device=dev)]).contiguous()
+            ops.degree_affine(seg_ptr, 0, B, 1, coef, ops.ACT_NONE, 0.0, out_l, extra=extra)
+        else:
+            ops.segment_sum(xl[:Nc], seg_ptr, B, extra=extra, out=out_l)
     return _post_mp(pk, pooled)                                            # :108
 
 

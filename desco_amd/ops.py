@@ -181,6 +181,22 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     return out
 
 
+def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, coef: torch.Tensor,
+                  act: int, slope: float, out: torch.Tensor,
+                  extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[row0+i] = act(coef[slots] + sum_s deg_s(i) * coef[s]) + extra[i]   (see desco_hip.h)."""
+    assert coef.is_contiguous() and coef.shape == (slots + 1, 64)
+    op, ldo = _rows(out, "out")
+    ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
+    L = _lib.lib()
+    with _Timed("degree_affine_kernel", 2.0 * num_rows * slots * 64,
+                256.0 * num_rows + 4.0 * num_rows * (slots + 1)):
+        _lib.check(L.desco_degree_affine_f32(_dev(vrowptr, "vrowptr", torch.int32), row0, num_rows,
+                                             slots, _dev(coef, "coef"), act, slope, ep, lde, op, ldo,
+                                             _stream()), "degree_affine")
+    return out
+
+
 def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
                 extra: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -134,6 +134,16 @@ int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* vrowptr, co
                          int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                          desco_stream_t stream);
 
+/* First SHMP layer (and first pooling block) when every node of a type has the same input row --
+ * the default pipeline's all-zero node features (workload.py:431-440, transforms.py:380-384) make
+ * pre_mp's output its bias.  Then agg_s[i] = deg_s(i) * x0_src(s) and, for rows [row0, row0+num_rows):
+ *   out[i, 0:64] = act( coef[slots] + sum_{s<slots} (vrowptr[i*slots+s+1] - vrowptr[i*slots+s]) * coef[s] )
+ *                  + extra[i - row0]                       (coef: [slots+1, 64]; extra optional)
+ * mathematically identical to desco_shmp_layer_f32 on the constant input; no gather, no GEMM. */
+int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_rows, int slots,
+                            const float* coef, int act, float slope, const float* extra,
+                            int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream);
+
 /* K9  global_add_pool (gnn_model.py:107) over contiguous row segments, plus one optional extra row
  * per segment (the anchored canonical embedding, gnn_model.py:69-73, 88-89):
  * out[b, 0:ncols] = sum_{r in [seg_ptr[b], seg_ptr[b+1])} x[r, 0:ncols] + extra[b, 0:ncols]

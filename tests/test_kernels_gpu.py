@@ -213,3 +213,18 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg):
     _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
     rest = torch.cat([out[:row0], out[row0 + num_rows:]])
     assert (rest == -7.0).all()          # rows outside the range are untouched
+
+
+def test_degree_affine():
+    g = torch.Generator().manual_seed(11)
+    n, S, row0 = 500, 4, 37
+    ptr, col, cnt = _random_vcsr(n + row0, S, 6, n, g)
+    coef = torch.randn(S + 1, 64, generator=g)
+    extra = torch.randn(n, 576, generator=g)
+    deg = cnt.view(n + row0, S).double()[row0:]
+    ref = torch.nn.functional.leaky_relu(deg @ coef[:S].double() + coef[S].double(), 0.1) + extra[:, 64:128].double()
+    out = torch.full((n + row0, 64), -3.0, device=DEV)
+    ops.degree_affine(ptr.to(DEV), row0, n, S, coef.to(DEV), ops.ACT_LEAKY, 0.1, out,
+                      extra=extra.to(DEV)[:, 64:128])
+    _close(out[row0:], ref, atol=1e-4)
+    assert (out[:row0] == -3.0).all()
