@@ -250,3 +250,40 @@ def test_gossip_training_loss_and_gradients(setup):
         pred = gm.graph_to_count(batch)
     pred_t = gm.emb_model(batch, query_emb=qemb)
     torch.testing.assert_close(pred, pred_t.detach(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("workload", ["syn_1827", "msrc_imdb"])
+def test_heavy_tailed_shapes(setup, workload):
+    """Syn_1827-shaped (large, dense neighborhoods: long edge lists, hub canonical rows) and
+    MSRC/IMDB-shaped (clique unions: every edge a triangle edge) graphs: neighborhood logits and
+    the gossip stage vs the oracle (log space / bounded inputs: the widened test weights overflow
+    2**logit on 100+-node neighborhoods on both sides alike)."""
+    from desco_amd import synthetic
+    nm, gm, qids, queries = setup
+    full = synthetic.syn_1827_shaped(60) if workload == "syn_1827" else synthetic.msrc_imdb_mixed(3, 6)
+    sizes = np.diff(full.graph_ptr)
+    keep = [g for g in np.argsort(sizes)[::-1] if sizes[g] <= 160][:5]
+    graphs = [full.edge_lists()[g] for g in sorted(keep)]
+    gs = GraphSet.from_edge_lists(graphs)
+    part = build_partition(gs, 4)
+    idx, ind, neighs = OP.neighborhood_dataset(graphs, 4)
+    assert (part.neigh_index == idx).all() and (part.indicator == ind).all()
+    rows = np.diff(part.count_ptr) + 1
+    print(f"[shape] {workload}: {gs.num_graphs} graphs, {part.num_neigh} neighborhoods, "
+          f"max {rows.max()} nodes, {part.num_edges} directed edges")
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs), OP.query_batch(queries),
+                                    emulate_quirk=False)
+    with torch.no_grad():
+        got = nm._logits(NeighborhoodBatch(part, DEV), exp2=False)
+    report(f"{workload} neigh_logits", got, ref)
+    scale = float(ref.abs().max())
+    assert float((got.cpu() - ref).abs().max()) <= 1e-4 * max(1.0, scale)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(gs.num_nodes, len(queries), generator=g) * 25
+    qemb = nm.get_query_emb()
+    gm.set_query_emb(qemb)
+    batch = GossipBatch(gs, DEV, x=x)
+    gref = OM.gossip_graph_to_count(cpu_sd(gm), x, batch.edge_index.numpy(), qemb.cpu(), 2) - x
+    ggot = gm.graph_to_count(batch).cpu() - x
+    report(f"{workload} gossip_corr", ggot, gref)
+    assert float((ggot - gref).abs().max()) <= 1e-4 * max(1.0, float(gref.abs().max()))
