@@ -99,25 +99,47 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   out[b * ldo + c] = acc0;
 }
 
-// count head, separable form of lightning_model.py:176-193, 210-221
+// count head, separable form of lightning_model.py:176-193, 210-221.
+// One thread per (b, q), 256-long dot product.  The Qh table is staged TRANSPOSED in LDS
+// ([c][32], consecutive q on consecutive banks: conflict-free), w2 is wave-uniform, the T row is a
+// (mostly broadcast) float4 global load.  Blocks stride over chunks of 256 (b, q) pairs so the
+// table is staged once per block.
+constexpr int HEAD_MAXQ = 32, HEAD_MAXHID = 256;
 __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
                                                          const float* __restrict__ qh, int64_t ldq,
                                                          int hid, const float* __restrict__ w2,
                                                          float b2, float slope, int exp2m1,
                                                          float* __restrict__ out, int64_t ldo,
                                                          int64_t num_b, int num_q) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  if (b >= num_b) return;
-  for (int q = 0; q < num_q; ++q) {
-    float acc = 0.f;
-    for (int c = lane; c < hid; c += 64) {
-      float v = t[b * ldt + c] + qh[(int64_t)q * ldq + c];
-      v = v > 0.f ? v : v * slope;
-      acc += v * w2[c];
+  __shared__ float qt[HEAD_MAXHID * HEAD_MAXQ];
+  for (int i = threadIdx.x; i < hid * num_q; i += 256) {
+    const int q = i / hid, c = i % hid;
+    qt[c * HEAD_MAXQ + q] = qh[(int64_t)q * ldq + c];
+  }
+  __syncthreads();
+  const int64_t total = num_b * num_q;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t b = idx / num_q;
+    const int q = (int)(idx % num_q);
+    const float4* tp = reinterpret_cast<const float4*>(t + b * ldt);
+    const float* qp = qt + q;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < hid / 4; ++c) {
+      const float4 tv = tp[c];
+      float z0 = tv.x + qp[(4 * c + 0) * HEAD_MAXQ], z1 = tv.y + qp[(4 * c + 1) * HEAD_MAXQ];
+      float z2 = tv.z + qp[(4 * c + 2) * HEAD_MAXQ], z3 = tv.w + qp[(4 * c + 3) * HEAD_MAXQ];
+      z0 = z0 > 0.f ? z0 : z0 * slope;
+      z1 = z1 > 0.f ? z1 : z1 * slope;
+      z2 = z2 > 0.f ? z2 : z2 * slope;
+      z3 = z3 > 0.f ? z3 : z3 * slope;
+      a0 = fmaf(z0, w2[4 * c + 0], a0);
+      a1 = fmaf(z1, w2[4 * c + 1], a1);
+      a2 = fmaf(z2, w2[4 * c + 2], a2);
+      a3 = fmaf(z3, w2[4 * c + 3], a3);
     }
-    acc = wave_sum(acc) + b2;
-    if (lane == 0) out[b * ldo + q] = exp2m1 ? exp2f(acc) - 1.f : acc;
+    const float acc = (a0 + a1) + (a2 + a3) + b2;
+    out[b * ldo + q] = exp2m1 ? exp2f(acc) - 1.f : acc;
   }
 }
 
@@ -235,9 +257,11 @@ extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh
                                     int exp2_minus_1, float* out, int64_t ldo, int64_t num_b,
                                     int num_q, desco_stream_t stream) {
   if (num_b == 0 || num_q == 0) return 0;
-  if (!t || !qh || !w2 || !out || num_b < 0 || num_q < 0 || hid <= 0 || hid % 64)
-    return fail(DESCO_EINVAL, "desco_count_head_f32: bad argument");
-  const int64_t blocks = (num_b + 3) / 4;
+  if (!t || !qh || !w2 || !out || num_b < 0 || num_q < 0 || num_q > HEAD_MAXQ || hid <= 0 ||
+      hid % 64 || hid > HEAD_MAXHID || ldt % 4 || (reinterpret_cast<uintptr_t>(t) & 15))
+    return fail(DESCO_EINVAL, "desco_count_head_f32: bad argument (num_q <= 32, hid%64, hid <= 256)");
+  int64_t blocks = (num_b * num_q + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_count_head_f32: too many rows");
   hipLaunchKernelGGL(count_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo, num_b, num_q);

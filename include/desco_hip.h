@@ -154,7 +154,8 @@ int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols, const int32_t*
 
 /* K12/K13  count head (lightning_model.py:176-193, 210-221) in separable form:
  * logit[b,q] = sum_c w2[c] * leaky(T[b,c] + Qh[q,c]) + b2;  out = exp2 ? 2^logit - 1 : logit
- * T: [B, hid] (target half of count_model.0), Qh: [Q, hid] (query half + bias), hid % 64 == 0 */
+ * T: [B, hid] (target half of count_model.0), Qh: [Q, hid] (query half + bias);
+ * hid % 64 == 0, hid <= 256, Q <= 32 */
 int desco_count_head_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq, int hid,
                          const float* w2, float b2, float slope, int exp2_minus_1, float* out,
                          int64_t ldo, int64_t num_b, int num_q, desco_stream_t stream);
