@@ -21,6 +21,8 @@
 //   * a K block is processed as two 32-column halves: 8-lane groups x float4 gather one 128-B
 //     half row per neighbour (8 rows in flight per pass, 4 passes kept in flight together) into a
 //     private [32][33] A image, then 32 MFMAs (32x64 output, two accumulators share the A fragment);
+//   * rows with more than 4 sources in a slot (hub rows, canonical rows of dense neighborhoods)
+//     are finished cooperatively by the whole wave (8 lane groups stride over one row's sources);
 //   * table slots run as one extra pseudo K block: their pre-transformed source rows are gathered
 //     the same way, staged in the A image and ADDED to the accumulators in the C/D layout
 //     (16 LDS reads per half instead of 32 MFMAs);
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   }
         DESCO_CUR(c0, n0, 0) DESCO_CUR(c1, n1, 1) DESCO_CUR(c2, n2, 2) DESCO_CUR(c3, n3, 3)
 #undef DESCO_CUR
-        while (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
+        // rows with few sources: one source per row and pass, 4 rows per lane group in flight
+        for (int pass = 0; pass < 4 && __any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3)); ++pass) {
 #define DESCO_STEP(av_, c_, n_)                                                          \
   if (c_ < n_) {                                                                         \
     const int64_t j_ = c_ < WCAP ? ec[c_] : g.vcol[ebase + c_];                          \
@@ -205,6 +208,36 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
           DESCO_STEP(a3, c3, n3)
 #undef DESCO_STEP
         }
+        // heavy rows (hub / canonical rows of dense neighborhoods): the whole wave cooperates on
+        // one row at a time -- lane group k takes sources c+k, c+k+8, ... and the 8 partial sums
+        // are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
+#define DESCO_COOP(av_, c_, n_)                                                          \
+  {                                                                                      \
+    unsigned long long m_ = __ballot(c_ < n_);                                           \
+    while (m_) {                                                                         \
+      const int sl_ = __builtin_ctzll(m_);                                               \
+      const int og_ = sl_ >> 3;                                                          \
+      const int cc_ = __shfl(c_, sl_, 64), nn_ = __shfl(n_, sl_, 64);                    \
+      float4 p_ = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+      for (int e_ = cc_ + g8; e_ < nn_; e_ += 8) {                                       \
+        const int64_t j_ = e_ < WCAP ? ec[e_] : g.vcol[ebase + e_];                      \
+        f4add(p_, *reinterpret_cast<const float4*>(xb + j_ * g.ldx));                    \
+      }                                                                                  \
+      _Pragma("unroll") for (int o_ = 8; o_ < 64; o_ <<= 1) {                            \
+        p_.x += __shfl_xor(p_.x, o_, 64);                                                \
+        p_.y += __shfl_xor(p_.y, o_, 64);                                                \
+        p_.z += __shfl_xor(p_.z, o_, 64);                                                \
+        p_.w += __shfl_xor(p_.w, o_, 64);                                                \
+      }                                                                                  \
+      if (g8 == og_) {                                                                   \
+        f4add(av_, p_);                                                                  \
+        c_ = n_;                                                                         \
+      }                                                                                  \
+      m_ &= ~(0xffULL << (og_ * 8));                                                     \
+    }                                                                                    \
+  }
+        DESCO_COOP(a0, c0, n0) DESCO_COOP(a1, c1, n1) DESCO_COOP(a2, c2, n2) DESCO_COOP(a3, c3, n3)
+#undef DESCO_COOP
       }
       if (kh == 0 && has_next) {
         // next tile's row pointers have landed: publish them, then fetch its source ids

@@ -75,6 +75,8 @@ class InferencePipeline:
     def run(self, gossip: bool = True) -> Dict[str, torch.Tensor]:
         nm, gm = self.nm, self.gm
         counts = [nm.graph_to_count(b) for b in self.neigh_batches]            # main.py:296-301
+        if not counts:      # no node has a non-empty canonical neighborhood
+            counts = [torch.zeros((0, len(nm.queries_flat)), device=self.device)]
         neigh_count = counts[0] if len(counts) == 1 else torch.cat(counts)
         Q = neigh_count.shape[1]
         G, N = self.graphs.num_graphs, self.graphs.num_nodes

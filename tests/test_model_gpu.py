@@ -287,3 +287,24 @@ def test_heavy_tailed_shapes(setup, workload):
     ggot = gm.graph_to_count(batch).cpu() - x
     report(f"{workload} gossip_corr", ggot, gref)
     assert float((ggot - gref).abs().max()) <= 1e-4 * max(1.0, float(gref.abs().max()))
+
+
+def test_degenerate_inputs(setup):
+    """Edge cases: graphs without edges (no neighborhoods at all), single-node graphs, one edge."""
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    graphs = [(3, []), (1, []), (2, [(0, 1)]), (4, []), (5, [(0, 4)])]
+    gs = GraphSet.from_edge_lists(graphs)
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV)
+    out = pipe.run()
+    ref = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), graphs, queries, emulate_quirk=False)
+    assert out["neigh_count"].shape == (2, 29) and out["node_count"].shape == (15, 29)
+    for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-4, atol=1e-4)
+    # nothing but isolated nodes: zero neighborhoods, gossip still runs on x = 0
+    gs0 = GraphSet.from_edge_lists([(3, []), (2, [])])
+    out0 = InferencePipeline(nm, gm, gs0, depth=4, device=DEV).run()
+    ref0 = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), [(3, []), (2, [])], queries, emulate_quirk=False)
+    assert out0["neigh_count"].shape == (0, 29)
+    torch.testing.assert_close(out0["node_count"].cpu(), ref0["node_count"], rtol=1e-4, atol=1e-4)
+    assert float(out0["graph_neigh_count"].abs().max()) == 0.0

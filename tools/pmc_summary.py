@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json.
+
+usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>"
+Per kernel and launch: raw counters (KB) and HBM bytes corrected as MI355X_MICROARCH.md (HBM
+section) prescribes for gfx950: FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced
+reads -> x2; WRITE_SIZE is exact for 16-B-per-lane stores.  Other access widths are uncalibrated,
+so the corrected read figure is an upper bound for kernels that mix widths (noted per kernel)."""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path, cname):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != cname:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
+        k = k.split("<")[0]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {"command": sys.argv[4] if len(sys.argv) > 4 else "", "unit_note": "FETCH_SIZE/WRITE_SIZE in KB per launch; "
+           "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction for 16 B/lane reads)",
+           "kernels": {}}
+    for k in sorted(f, key=lambda k: -f[k][1]):
+        if not k.endswith("_kernel"):
+            continue
+        fk = f[k][1] / f[k][0]
+        wk = w[k][1] / w[k][0] if k in w and w[k][0] else 0.0
+        out["kernels"][k] = {"launches": f[k][0], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+                             "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+                             "hbm_bytes_per_launch_uncorrected": (fk + wk) * 1024}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out["kernels"], indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
