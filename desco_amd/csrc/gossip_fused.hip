@@ -13,14 +13,17 @@
 // Nothing but the 16-byte scalar records and the [N,Q] result crosses HBM (the unfused path moves
 // ~2.3 KB per (node,query)); the kernel is bound by the f32 MFMA rate (288 MFMAs per wave and tile).
 // Block = 4 waves, output tiles 64x64 as 2x2 wave tiles of 32x32 (v_mfma_f32_32x32x2_f32); three
-// 64x65 activation images + one 64x64 weight image in LDS (66 KB -> 2 blocks per CU); weight
-// blocks are prefetched into registers under the previous block's MFMAs.  Algebra: DESIGN.md 4.2.
+// 64x68 activation images + one 64x68 weight image in LDS (71 KB -> 2 blocks per CU); weight
+// blocks are prefetched into registers under the previous block's MFMAs.  Blocks are persistent
+// (2 per CU) and walk (tile, query) items; the next item's CSR slice and scalar records are
+// prefetched through registers in three stages under the current item's GEMMs.
+// Algebra: DESIGN.md 4.2.
 #include "common_device.hpp"
 
 namespace desco {
 
 constexpr int GT = 64;      // rows (nodes) per tile
-constexpr int GAS = 65;     // activation image row stride (floats)
+constexpr int GAS = 68;     // image row stride (floats): 16-B aligned rows, conflict-free b128 reads
 constexpr int ECAP = 768;   // neighbour records staged per pass (aliases the third image)
 
 struct GossipFusedArgs {
@@ -38,11 +41,11 @@ struct GossipFusedArgs {
   const float* u;           // [64]  D1a c1
   const float* tp;          // [64]  P0[:,64:128] w_pre
   const float* d1;          // [64]
-  const float* w1;          // [128,64]
-  const float* wp;          // [128,64]
+  const float* w1;          // [64,128]  (n-major = transposed: row n holds the 128 k)
+  const float* wp;          // [64,128]
   const float* w3;          // [64,64]
   const float* b3;          // [64]
-  const float* w5;          // [64,256]
+  const float* w5;          // [256,64]
   const float* b5;          // [256]
   const float* w7;          // [256]
   float b7;
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
                                      b * flo + (1.f - b) * fhi, x[i * ldx + q]);
 }
 
+// weight block staging: 64 output columns n x 64 k, source is n-major (row n, leading dim ld_);
+// thread t moves 4 float4: n = t>>4 (+16,+32,+48), k = 4*(t&15)
 #define DESCO_WLOAD(src_, ld_)                                                          \
   {                                                                                     \
     const float* s_ = (src_) + (int64_t)(tid >> 4) * (ld_) + 4 * (tid & 15);            \
@@ -91,108 +96,159 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
   }
 #define DESCO_WSTORE()                                                                  \
   {                                                                                     \
-    float* d_ = Bs + (tid >> 4) * 64 + 4 * (tid & 15);                                  \
+    float* d_ = Bs + (tid >> 4) * GAS + 4 * (tid & 15);                                 \
     *reinterpret_cast<float4*>(d_) = w0;                                                \
-    *reinterpret_cast<float4*>(d_ + 16 * 64) = w1;                                      \
-    *reinterpret_cast<float4*>(d_ + 32 * 64) = w2;                                      \
-    *reinterpret_cast<float4*>(d_ + 48 * 64) = w3;                                      \
+    *reinterpret_cast<float4*>(d_ + 16 * GAS) = w1;                                     \
+    *reinterpret_cast<float4*>(d_ + 32 * GAS) = w2;                                     \
+    *reinterpret_cast<float4*>(d_ + 48 * GAS) = w3;                                     \
   }
-// 32 MFMAs of one 64-deep K block: A image rows 32wr.., B image cols 32wc..
-#define DESCO_MFMA_BLOCK(Aimg_)                                                         \
-  {                                                                                     \
-    const float* as_ = (Aimg_) + (wr * 32 + (lane & 31)) * GAS + (lane >> 5);           \
-    const float* bs_ = Bs + (lane >> 5) * 64 + wc * 32 + (lane & 31);                   \
-    _Pragma("unroll") for (int kk = 0; kk < 32; ++kk) acc =                             \
-        __builtin_amdgcn_mfma_f32_32x32x2f32(as_[2 * kk], bs_[2 * kk * 64], acc, 0, 0, 0); \
+// 32 MFMAs of one 64-deep K block.  Lane (r = lane&31, h = lane>>5) owns k = 32h .. 32h+31 of
+// its A row and of its B column (the sum over k is order-free, so the MFMA's k pairing can be
+// chosen per lane half): 8 ds_read_b128 per operand instead of 32 ds_read_b32.
+#define DESCO_MFMA_BLOCK(Aimg_)                                                                   \
+  {                                                                                               \
+    const float4* ap_ = reinterpret_cast<const float4*>((Aimg_) + (wr * 32 + (lane & 31)) * GAS + \
+                                                        32 * (lane >> 5));                        \
+    const float4* bp_ = reinterpret_cast<const float4*>(Bs + (wc * 32 + (lane & 31)) * GAS +      \
+                                                        32 * (lane >> 5));                        \
+    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                            \
+      const float4 a_ = ap_[t_], b_ = bp_[t_];                                                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, b_.x, acc, 0, 0, 0);                       \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, b_.y, acc, 0, 0, 0);                       \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, b_.z, acc, 0, 0, 0);                       \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc, 0, 0, 0);                       \
+    }                                                                                             \
   }
 #define DESCO_ACC_ZERO() \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[i_] = 0.f;
 
-__global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g) {
-  __shared__ float lds[3 * GT * GAS + 64 * 64 + 4 * GT + 68];
+constexpr int PCAP = 256;   // neighbour records prefetched (one per thread) for the next tile
+
+__global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * GT * GAS + 64 * GAS + 4 * GT + 68];
   float* A0 = lds;                      // h1, later y2
   float* A1 = lds + GT * GAS;           // hh, later y1
   float* A2 = lds + 2 * GT * GAS;       // neighbour staging, later h2, later head partials
-  float* Bs = lds + 3 * GT * GAS;       // 64x64 weight block
-  float4* srow = reinterpret_cast<float4*>(Bs + 64 * 64);   // scalars of the tile rows
-  int* rp = reinterpret_cast<int*>(Bs + 64 * 64 + 4 * GT);  // rowptr[n0 .. n0+64]
+  float* Bs = lds + 3 * GT * GAS;       // weight block, n-major [64 n][64 k], stride GAS
+  float4* srow = reinterpret_cast<float4*>(Bs + 64 * GAS);   // scalars of the tile rows
+  int* rp = reinterpret_cast<int*>(Bs + 64 * GAS + 4 * GT);  // rowptr[n0 .. n0+64]
   int* ecol = reinterpret_cast<int*>(A2);                   // [ECAP]
   float4* escal = reinterpret_cast<float4*>(A2 + ECAP);     // [ECAP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int q = blockIdx.y, Q = g.Q;
-  const int64_t n0 = (int64_t)blockIdx.x * GT;
-  const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
+  const int Q = g.Q;
+  const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
+  int64_t item = blockIdx.x;
+  if (item >= nitems) return;
 
-  // first weight block (W1 rows 0..63) in flight while the tile is being assembled
-  float4 w0, w1, w2, w3;
-  DESCO_WLOAD(g.w1, 64)
-
-  // ---- phase 0: tile scalars + rowptr ------------------------------------------------------
-  if (tid < GT) {
-    const int64_t node = n0 + (tid < nrows ? tid : nrows - 1);
-    srow[tid] = g.scal[node * Q + q];
+  // The (rowptr -> col -> scalar record) chain of the NEXT item is fetched into these registers
+  // in three stages spread over the current item's GEMMs and published to LDS when the current
+  // item is done: a tile no longer starts with three dependent global-memory latencies.
+  float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow;
+  int n_rp = 0, n_col = 0, n_ebeg = 0, n_cnt = 0;
+#define DESCO_STAGE1(it_)                                                                  \
+  {                                                                                        \
+    const int q_ = (int)((it_) % Q);                                                       \
+    const int64_t t0_ = ((it_) / Q) * GT;                                                  \
+    const int nr_ = (int)((g.num_nodes - t0_) < GT ? (g.num_nodes - t0_) : GT);            \
+    if (tid < GT) n_srow = g.scal[(t0_ + (tid < nr_ ? tid : nr_ - 1)) * Q + q_];           \
+    if (tid <= GT) n_rp = g.rowptr[t0_ + (tid < nr_ ? tid : nr_)];                         \
+    n_ebeg = g.rowptr[t0_];                                                                \
+    n_cnt = g.rowptr[t0_ + nr_] - n_ebeg;                                                  \
+    n_cnt = n_cnt < PCAP ? n_cnt : PCAP;                                                   \
   }
-  if (tid <= GT) rp[tid] = g.rowptr[n0 + (tid < nrows ? tid : nrows)];
-  const float gq = g.g1[q];
-  const float pc = g.p[q * 64 + lane], zc = g.z[q * 64 + lane];
-  const float rc = g.r[lane], tc = g.t[lane];
-  __syncthreads();
+#define DESCO_STAGE2() \
+  if (tid < n_cnt) n_col = g.col[n_ebeg + tid];
+#define DESCO_STAGE3(it_) \
+  if (tid < n_cnt) n_scal = g.scal[(int64_t)n_col * Q + (int)((it_) % Q)];
 
-  // ---- phase 1: h1 of the tile rows, gated neighbour sum hh ---------------------------------
-  float hh[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) hh[k] = 0.f;
-  const int ebeg = rp[0], eend = rp[GT];
-  for (int base = ebeg; base < eend || base == ebeg; base += ECAP) {
-    const int cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
-    for (int e = tid; e < cnt; e += 256) {
-      const int j = g.col[base + e];
-      ecol[e] = j;
-      escal[e] = g.scal[(int64_t)j * Q + q];
+  DESCO_STAGE1(item)
+  DESCO_STAGE2()
+  DESCO_STAGE3(item)
+  const float rc = g.r[lane], tc = g.t[lane];
+  const int col = wc * 32 + (lane & 31);
+
+  for (;;) {
+    // ---- publish the prefetched tile data ------------------------------------------------------
+    if (tid < GT) srow[tid] = n_srow;
+    if (tid <= GT) rp[tid] = n_rp;
+    if (tid < n_cnt) {
+      ecol[tid] = n_col;
+      escal[tid] = n_scal;
     }
+    const int cnt0 = n_cnt;
+    const int q = (int)(item % Q);
+    const int64_t n0 = (item / Q) * GT;
+    const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
+    const int64_t next = item + gridDim.x;
+    const bool has_next = next < nitems;
     __syncthreads();
+    if (has_next) DESCO_STAGE1(next)
+
+    // first weight block (W1 columns for hh) in flight while the tile is being assembled
+    float4 w0, w1, w2, w3;
+    DESCO_WLOAD(g.w1, 128)
+    const float gq = g.g1[q];
+    const float pc = g.p[q * 64 + lane], zc = g.z[q * 64 + lane];
+
+    // ---- phase 1: h1 of the tile rows, gated neighbour sum hh -----------------------------------
+    float hh[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hh[k] = 0.f;
+    const int ebeg = rp[0], eend = rp[GT];
+    // pass 0: the prefetched records [ebeg, ebeg+cnt0); later passes (tiles with more than PCAP
+    // neighbour records) stage ECAP records at a time from global memory
+    int base = ebeg, cnt = cnt0;
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = wave * 16 + k;
+        const int node = (int)n0 + row;
+        int lo = rp[row] - base, hi = rp[row + 1] - base;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > cnt ? cnt : hi;
+        float a = hh[k];
+        for (int e = lo; e < hi; ++e) {
+          const float4 sj = escal[e];
+          float h = sj.x * pc + sj.y * rc + sj.w * tc + zc;
+          h = h > 0.f ? h : 0.f;
+          a += (ecol[e] < node ? gq : 1.f - gq) * h;
+        }
+        hh[k] = a;
+      }
+      base += cnt;
+      if (base >= eend) break;
+      __syncthreads();          // everyone is done with the staged records
+      cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
+      for (int e = tid; e < cnt; e += 256) {
+        const int j = g.col[base + e];
+        ecol[e] = j;
+        escal[e] = g.scal[(int64_t)j * Q + q];
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int row = wave * 16 + k;
-      const int node = (int)n0 + row;
-      int lo = rp[row] - base, hi = rp[row + 1] - base;
-      lo = lo < 0 ? 0 : lo;
-      hi = hi > cnt ? cnt : hi;
-      float a = hh[k];
-      for (int e = lo; e < hi; ++e) {
-        const float4 sj = escal[e];
-        float h = sj.x * pc + sj.y * rc + sj.w * tc + zc;
-        h = h > 0.f ? h : 0.f;
-        a += (ecol[e] < node ? gq : 1.f - gq) * h;
-      }
-      hh[k] = a;
+      const float4 si = srow[row];
+      float h = si.x * pc + si.y * rc + si.w * tc + zc;
+      A0[row * GAS + lane] = h > 0.f ? h : 0.f;
+      A1[row * GAS + lane] = hh[k];
     }
-    __syncthreads();
-    if (eend == ebeg) break;
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int row = wave * 16 + k;
-    const float4 si = srow[row];
-    float h = si.x * pc + si.y * rc + si.w * tc + zc;
-    A0[row * GAS + lane] = h > 0.f ? h : 0.f;
-    A1[row * GAS + lane] = hh[k];
-  }
 
-  f32x16 acc;
-  const int col = wc * 32 + (lane & 31);
+    f32x16 acc;
+
   // ---- G1: h2 = relu([hh|h1] W1 + a1*u + d1) -> A2 -----------------------------------------
   DESCO_ACC_ZERO()
   DESCO_WSTORE()
   __syncthreads();
-  DESCO_WLOAD(g.w1 + 64 * 64, 64)
+  DESCO_WLOAD(g.w1 + 64, 128)
   DESCO_MFMA_BLOCK(A1)
   __syncthreads();
   DESCO_WSTORE()
   __syncthreads();
-  DESCO_WLOAD(g.wp, 64)
+  DESCO_WLOAD(g.wp, 128)
   DESCO_MFMA_BLOCK(A0)
   {
     const float uc = g.u[col], dc = g.d1[col];
@@ -204,11 +260,12 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g)
     }
   }
   __syncthreads();
+  if (has_next) DESCO_STAGE2()
   // ---- G2: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> A1 ----------------------------------
   DESCO_ACC_ZERO()
   DESCO_WSTORE()
   __syncthreads();
-  DESCO_WLOAD(g.wp + 64 * 64, 64)
+  DESCO_WLOAD(g.wp + 64, 128)
   DESCO_MFMA_BLOCK(A0)
   __syncthreads();
   DESCO_WSTORE()
@@ -225,11 +282,12 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g)
     }
   }
   __syncthreads();
+  if (has_next) DESCO_STAGE3(next)
   // ---- G3: y2 = relu(y1 W3 + b3) -> A0 ------------------------------------------------------
   DESCO_ACC_ZERO()
   DESCO_WSTORE()
   __syncthreads();
-  DESCO_WLOAD(g.w5, 256)
+  DESCO_WLOAD(g.w5, 64)
   DESCO_MFMA_BLOCK(A1)
   {
     const float bc = g.b3[col];
@@ -250,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g)
     DESCO_ACC_ZERO()
     DESCO_WSTORE()
     __syncthreads();
-    if (cg < 3) DESCO_WLOAD(g.w5 + 64 * (cg + 1), 256)
+    if (cg < 3) DESCO_WLOAD(g.w5 + 64 * 64 * (cg + 1), 64)
     DESCO_MFMA_BLOCK(A0)
     const float bc = g.b5[cg * 64 + col], wv = g.w7[cg * 64 + col];
 #pragma unroll
@@ -276,6 +334,13 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g)
     s += __shfl_xor(s, 2, 64);
     if (qt == 0 && row < nrows) g.out[(n0 + row) * Q + q] = s + g.b7 + srow[row].w;
   }
+    if (!has_next) break;
+    item = next;
+    __syncthreads();            // A2 / srow / rp are free again
+  }
+#undef DESCO_STAGE1
+#undef DESCO_STAGE2
+#undef DESCO_STAGE3
 }
 
 #undef DESCO_WLOAD
@@ -321,7 +386,14 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
   if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f32: too many nodes");
   GossipFusedArgs a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z,
                     zp, r, t, u, tp, d1, w1, wp, w3, b3, w5, b5, w7, b7, out};
-  hipLaunchKernelGGL(gossip_fused_kernel, dim3((unsigned)bx, (unsigned)num_q), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  const int64_t nitems = bx * num_q;
+  const unsigned grid = (unsigned)(nitems < 2 * (int64_t)cus ? nitems : 2 * (int64_t)cus);
+  hipLaunchKernelGGL(gossip_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bx);
   return launch_status("desco_gossip_fused_f32");
 }

@@ -446,6 +446,10 @@ def pack_gossip(gnn: BaseGNN) -> dict:
     pk["post"] = [_lin_t(gnn.post_mp[i]) for i in (3, 5)]
     pk["w7"] = gnn.post_mp[7].weight[0].contiguous()
     pk["b7"] = float(gnn.post_mp[7].bias[0])
+    pk["fused_w1"] = pk["wt1"].t().contiguous()                 # [64,128]
+    pk["fused_wp"] = pk["wtp"].t().contiguous()                 # [64,128]
+    pk["fused_w3"] = gnn.post_mp[3].weight.contiguous()         # [64,64]  (already [out, in])
+    pk["fused_w5"] = gnn.post_mp[5].weight.contiguous()         # [256,64]
     pk["qcache"] = None
     return pk
 
@@ -490,8 +494,10 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
         scal4 = ops.gossip_scalars(x, batch.rowptr, batch.col, q["g0"], q["g1"])
         (w3, b3), (w5, b5) = pk["post"]
         v = {"g1": q["g1"], "p": q["p"], "z": q["z"], "zp": q["zp"], "r": q["r"], "t": q["t"],
-             "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"], "w1": pk["wt1"], "wp": pk["wtp"],
-             "w3": w3, "b3": b3, "w5": w5, "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
+             "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"],
+             # the fused kernel takes n-major ([out, in]) weight blocks
+             "w1": pk["fused_w1"], "wp": pk["fused_wp"], "w3": pk["fused_w3"], "b3": b3,
+             "w5": pk["fused_w5"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
         return ops.gossip_fused(scal4, batch.rowptr, batch.col, N, Q, v)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0

@@ -190,7 +190,8 @@ int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t
  *      h1 = relu(a0*p_q + b0*r + x*t + z_q);  hh = sum_j (j<i ? g1 : 1-g1)*h1_j;
  *      h2 = relu([hh|h1] w1 + a1*u + d1);  y1 = leaky_0.1([h1|h2] wp + x*tp + zp_q);
  *      y2 = relu(y1 w3 + b3);  out[i,q] = x + b7 + sum_c relu(y2 w5 + b5)[c]*w7[c]
- *      (w1, wp: [128,64]; w3: [64,64]; w5: [64,256]; row major = torch weights transposed/folded).
+ *      Weights are passed n-major (= torch's [out, in] layout of the folded matrices):
+ *      w1, wp: [64,128]; w3: [64,64]; w5: [256,64].
  * Replaces BaseGNN.forward (gossip) for every query: gnn_model.py:58-103, 230-260, 303-350 and the
  * loop of lightning_model.py:613-628; equals layer0 + gather + 4 GEMMs + rowdot of the unfused path. */
 int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
