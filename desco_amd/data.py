@@ -77,3 +77,91 @@ def get_neigh_hetero(graph: nx.Graph, node, radius: int) -> nx.Graph:
     mset = set(members)
     out.add_edges_from((a, b2) for a, b2 in graph.edges() if a in mset and b2 in mset)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dataset loading (subgraph_counting/data.py:91-232)
+# ------------------------------------------------------------------------------------------------
+_SYNTHETIC_BY_NAME = {"MUTAG": "mutag", "COX2": "cox2", "Syn_1827": "syn_1827",
+                      "MSRC_21+IMDB-BINARY": "msrc_imdb"}
+
+
+def _read_tu_raw(raw_dir: str, name: str) -> GraphSet:
+    """TU dataset text format: <name>_A.txt ("i, j", 1-based global ids, both directions) and
+    <name>_graph_indicator.txt (graph id of node i, 1-based)."""
+    import os
+    a = np.loadtxt(os.path.join(raw_dir, name + "_A.txt"), delimiter=",", dtype=np.int64).reshape(-1, 2) - 1
+    gi = np.loadtxt(os.path.join(raw_dir, name + "_graph_indicator.txt"), dtype=np.int64).reshape(-1) - 1
+    if not (np.diff(gi) >= 0).all():
+        raise ValueError("graph_indicator must be sorted")
+    graph_ptr = np.concatenate([[0], np.cumsum(np.bincount(gi))])
+    return GraphSet._from_global_pairs(graph_ptr, a[:, 0], a[:, 1])
+
+
+def relabel(graphs: GraphSet, mode: str) -> GraphSet:
+    """Per-graph node re-indexing (transforms.py:415-442 Relabel): "decreasing_degree",
+    "increasing_degree" (stable w.r.t. the original order) or "random" (seed 0)."""
+    rng = np.random.default_rng(0)
+    out = []
+    for (n, edges) in graphs.edge_lists():
+        deg = np.zeros(n, dtype=np.int64)
+        for a, b in edges:
+            deg[a] += 1
+            deg[b] += 1
+        if mode == "random":
+            order = rng.permutation(n)
+        else:
+            order = np.argsort(-deg if mode == "decreasing_degree" else deg, kind="stable")
+        new = np.empty(n, dtype=np.int64)
+        new[order] = np.arange(n)
+        out.append((n, [(int(new[a]), int(new[b])) for a, b in edges]))
+    return GraphSet.from_edge_lists(out)
+
+
+def load_data(dataset_name: str, root_folder="data", n_neighborhoods=-1, transform=None,
+              train_split=0.25, val_split=0.25, test_split=0.5) -> GraphSet:
+    """Target graphs by name, with the reference's name mini-DSL (data.py:104-137, 206-227):
+    ``_train`` / ``_val`` / ``_test`` select the 25/25/50 % split of ``random.seed(0);
+    random.shuffle`` and ``_decreaseByDegree`` / ``_increaseByDegree`` / ``_random`` relabel nodes.
+
+    Source, in order: TU text files under ``<root_folder>/<name>/raw`` (no download is attempted:
+    there is no network), else a seeded shape-matched synthetic stand-in (desco_amd.synthetic)."""
+    import os
+    import random
+    import warnings
+    split = None
+    for tag in ("train", "val", "test"):
+        if tag in dataset_name:
+            split = tag
+            dataset_name = dataset_name.replace("_" + tag, "")
+            break
+    mode = None
+    for suffix, m in (("_decreaseByDegree", "decreasing_degree"), ("_increaseByDegree", "increasing_degree"),
+                      ("_random", "random")):
+        if suffix in dataset_name:
+            mode = m
+            dataset_name = dataset_name.replace(suffix, "")
+    raw = os.path.join(root_folder, dataset_name, "raw")
+    if os.path.exists(os.path.join(raw, dataset_name + "_A.txt")):
+        graphs = _read_tu_raw(raw, dataset_name)
+    elif dataset_name in _SYNTHETIC_BY_NAME:
+        from . import synthetic
+        warnings.warn(f"{dataset_name}: no raw files under {raw}; using the seeded shape-matched "
+                      "synthetic stand-in (desco_amd.synthetic)")
+        graphs = synthetic.WORKLOADS[_SYNTHETIC_BY_NAME[dataset_name]]()
+    else:
+        raise FileNotFoundError(f"{dataset_name}: place TU-format text files under {raw} "
+                                "(datasets are not downloaded: no network)")
+    if mode is not None:
+        graphs = relabel(graphs, mode)
+    if split is None:
+        return graphs
+    G = graphs.num_graphs
+    idx = list(range(G))
+    random.seed(0)
+    random.shuffle(idx)                                  # same permutation as shuffling the graphs
+    train_len, val_len = int(G * train_split), int(G * val_split)
+    sel = {"train": idx[:train_len], "val": idx[train_len:train_len + val_len],
+           "test": idx[train_len + val_len:]}[split]
+    lists = graphs.edge_lists()
+    return GraphSet.from_edge_lists([lists[i] for i in sel])
