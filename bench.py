@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the pass from a captured hipGraph (implies --no-profile)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,14 +136,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    if args.graph:
+        args.no_profile = True
+        pipe.capture()
+    step = pipe.run_graph if args.graph else pipe.run
     for _ in range(args.warmup):
-        out = pipe.run()
+        out = step()
     sync()
     ops.PROFILER.enabled = not args.no_profile
     ops.PROFILER.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.run()
+        out = step()
     sync()
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
@@ -170,6 +176,7 @@ def main():
             "neighborhood_directed_edges_per_gpu": part.num_edges,
             "parallelism": f"dp{world} (graph sharding, no data-path collective)",
             "host_partition_build_s": round(t_build, 3),
+            "launch_mode": "hipGraph replay" if args.graph else "eager launches",
         },
     }
 

@@ -16,6 +16,14 @@ from .graphs import GraphSet
 from .partition import NeighborhoodPartition
 
 
+def _norm_device(device) -> torch.device:
+    """torch.device("cuda") and torch.device("cuda:0") compare unequal; always carry the index."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def _i32(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -56,7 +64,8 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def __init__(self, part: NeighborhoodPartition, device, node_feature: Optional[torch.Tensor] = None,
                  y: Optional[torch.Tensor] = None, input_dim: int = 1):
         self.part = part
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
+        device = self.device
         self.num_graphs = part.num_neigh
         self.num_count = part.num_count
         self.num_rows = part.num_rows
@@ -69,7 +78,7 @@ class NeighborhoodBatch(_TrainIndexMixin):
         self.y = None if y is None else y.to(device)
 
     def to(self, device):
-        if torch.device(device) == self.device:
+        if _norm_device(device) == self.device:
             return self
         return NeighborhoodBatch(self.part, device, self.node_feature, self.y, self.input_dim)
 
@@ -117,7 +126,8 @@ class QueryBatch(_TrainIndexMixin):
     def __init__(self, queries: Sequence[Tuple[int, Sequence[Tuple[int, int]]]], device,
                  input_dim: int = 1):
         self.queries = [(int(n), [tuple(e) for e in es]) for n, es in queries]
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
+        device = self.device
         self.input_dim = input_dim
         sizes = np.array([n for n, _ in self.queries], dtype=np.int64)
         gp = np.concatenate([[0], np.cumsum(sizes)])
@@ -152,7 +162,8 @@ class GossipBatch:
     def __init__(self, graphs: GraphSet, device, x: Optional[torch.Tensor] = None,
                  y: Optional[torch.Tensor] = None):
         self.graphs = graphs
-        self.device = torch.device(device)
+        self.device = _norm_device(device)
+        device = self.device
         self.num_graphs = graphs.num_graphs
         self.num_nodes = graphs.num_nodes
         if graphs.num_directed_edges >= 2 ** 31:
@@ -164,7 +175,7 @@ class GossipBatch:
         self.y = None if y is None else y.to(device)
 
     def to(self, device):
-        if torch.device(device) == self.device:
+        if _norm_device(device) == self.device:
             return self
         return GossipBatch(self.graphs, device, self.x, self.y)
 

@@ -140,7 +140,7 @@ class NeighborhoodCountingModel(_LightningLike):
     def _queries(self) -> QueryBatch:
         if self.query_loader is None:
             raise RuntimeError("call set_queries() first (main.py:231-233)")
-        if self.query_loader.device != self.device:
+        if self.query_loader.device != self.device and self.device.type == "cuda":
             self.query_loader = QueryBatch(self.queries_flat, self.device, self.input_dim)
         return self.query_loader
 
@@ -157,14 +157,25 @@ class NeighborhoodCountingModel(_LightningLike):
         return self._qemb_cache[1]
 
     # ---- forward ---------------------------------------------------------------------------------
+    def _head_pack(self):
+        """count_model operands in kernel form, cached per weight version (no host sync per call)."""
+        ver = tuple((p.data_ptr(), p._version) for p in self.count_model.parameters())
+        if getattr(self, "_head_cache", None) is None or self._head_cache[0] != ver:
+            with torch.no_grad():
+                W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
+                self._head_cache = (ver, {
+                    "wt_t": W1[:, :H].t().contiguous(), "wt_q": W1[:, H:].t().contiguous(),
+                    "b1": b1.contiguous(), "w2": self.count_model[2].weight[0].contiguous(),
+                    "b2": float(self.count_model[2].bias[0])})
+        return self._head_cache[1]
+
     def _logits(self, batch: NeighborhoodBatch, exp2: bool) -> torch.Tensor:
         emb_q = self.get_query_emb()
         emb_t = self.emb_model(batch)
-        W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
-        T = ops.gemm(emb_t, W1[:, :H].t().contiguous())                      # target half
-        Qh = ops.gemm(emb_q, W1[:, H:].t().contiguous(), b1)                 # query half + bias
-        w2, b2 = self.count_model[2].weight[0], float(self.count_model[2].bias[0])
-        return ops.count_head(T, Qh, w2, b2, self.count_model[1].negative_slope, exp2)
+        hp = self._head_pack()
+        T = ops.gemm(emb_t, hp["wt_t"])                                     # target half
+        Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])                          # query half + bias
+        return ops.count_head(T, Qh, hp["w2"], hp["b2"], self.count_model[1].negative_slope, exp2)
 
     def graph_to_count(self, batch) -> torch.Tensor:                         # :198-222
         with torch.no_grad():

@@ -308,3 +308,17 @@ def test_degenerate_inputs(setup):
     assert out0["neigh_count"].shape == (0, 29)
     torch.testing.assert_close(out0["node_count"].cpu(), ref0["node_count"], rtol=1e-4, atol=1e-4)
     assert float(out0["graph_neigh_count"].abs().max()) == 0.0
+
+
+def test_hipgraph_replay_equals_eager(setup):
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    gs = GraphSet.from_edge_lists(golden_graphs(max_n=60))
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV)
+    eager = {k: v.clone() for k, v in pipe.run().items()}
+    pipe.capture()
+    for _ in range(3):
+        out = pipe.run_graph()
+    torch.cuda.synchronize()
+    for k in ("neigh_count", "node_count", "graph_gossip_count"):
+        assert torch.equal(out[k], eager[k]), k
