@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Training-step throughput of the neighborhood model (config C3 shape: Syn_1827-shaped
+neighborhoods, batch 512, fp32) and of the gossip model (batch 256 graphs) -- developer tool.
+Forward and backward run on the C-ABI kernels via desco_amd.autograd; Adam is torch's."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from desco_amd import synthetic
+from desco_amd.batch import GossipBatch, NeighborhoodBatch
+from desco_amd.data import STANDARD_QUERY_IDS
+from desco_amd.partition import build_partition
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="syn_1827")
+    ap.add_argument("--graphs", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    nm, gm = bench.build_models(dev)
+    nm.set_queries(STANDARD_QUERY_IDS)
+    gs = synthetic.WORKLOADS[args.workload]()
+    gs = gs.subset(0, min(args.graphs, gs.num_graphs))
+    part = build_partition(gs, 4)
+    g = torch.Generator().manual_seed(0)
+    Q = len(STANDARD_QUERY_IDS)
+    batches = []
+    for b0 in range(0, part.num_neigh, 512):
+        p = part.slice(b0, b0 + 512)
+        y = torch.floor(torch.rand(p.num_neigh, Q, generator=g) ** 3 * 50)     # surrogate labels
+        batches.append(NeighborhoodBatch(p, dev, y=y))
+    batches = batches[:args.steps + 2]
+    opt = nm.configure_optimizers()["optimizer"]
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = nm.training_step(b, 0)
+        loss.backward()
+        opt.step()
+        return loss
+    for b in batches[:2]:
+        step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = rows = 0
+    for b in batches[2:]:
+        step(b)
+        n += b.num_graphs
+        rows += b.num_rows
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"neighborhood training ({args.workload}-shaped, batch 512, fp32): {len(batches) - 2} steps, "
+          f"{n / dt:.0f} neighborhoods/s, {rows / dt / 1e6:.2f} M rows/s, {1e3 * dt / (len(batches) - 2):.1f} ms/step")
+    # gossip
+    x = torch.rand(gs.num_nodes, Q, generator=g) * 20
+    yg = torch.floor(torch.rand(gs.num_nodes, Q, generator=g) * 25)
+    gm.set_query_emb(nm.get_query_emb())
+    gb = [GossipBatch(gs.subset(g0, min(g0 + 256, gs.num_graphs)), dev) for g0 in range(0, gs.num_graphs, 256)]
+    off = 0
+    for b in gb:
+        b.x, b.y = x[off:off + b.num_nodes].to(dev), yg[off:off + b.num_nodes].to(dev)
+        off += b.num_nodes
+    gopt = gm.configure_optimizers()["optimizer"]
+    def gstep(b):
+        gopt.zero_grad(set_to_none=True)
+        loss = gm.training_step(b, 0)
+        loss.backward()
+        gopt.step()
+    gstep(gb[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nodes = 0
+    for _ in range(3):
+        for b in gb:
+            gstep(b)
+            nodes += b.num_nodes
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"gossip training (batch 256 graphs, 29 queries, fp32): {nodes / dt:.0f} nodes/s, "
+          f"{1e3 * dt / (3 * len(gb)):.1f} ms/step")
+
+
+if __name__ == "__main__":
+    main()
