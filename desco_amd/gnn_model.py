@@ -258,11 +258,13 @@ def pack_shmp(gnn: BaseGNN) -> dict:
         for t in core.node_types:
             U, c = core.updates[l][t].weight, core.updates[l][t].bias
             Un, Ux = U[:, :H], U[:, H:]
-            blocks, bsum = [], 0
+            blocks, bsum, seen = [], 0, set()
             for key in core.slot_keys(t):
                 conv = core.convs[l][key]
                 blocks.append((Un @ conv.lin.weight).t())        # (U_n W_s)^T
-                bsum = bsum + conv.lin.bias
+                if key not in seen:      # one bias per edge TYPE (use_tconv=False ties two slots)
+                    bsum = bsum + conv.lin.bias
+                    seen.add(key)
             blocks.append(Ux.t())
             entry = {"wt": torch.cat(blocks, 0).contiguous(), "b": (Un @ bsum + c).contiguous()}
             if len(blocks) == 5:

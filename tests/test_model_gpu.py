@@ -322,3 +322,37 @@ def test_hipgraph_replay_equals_eager(setup):
     torch.cuda.synchronize()
     for k in ("neigh_count", "node_count", "graph_gossip_count"):
         assert torch.equal(out[k], eager[k]), k
+
+
+def test_without_tconv_matches_oracle(setup):
+    """--use_tconv off: 3 "union" edge types (lightning_model.py:388-400, 414-419); the kernels keep
+    the triangle/tride slots and tie both to the single union weight."""
+    from desco_amd.lightning_model import NeighborhoodCountingModel
+    from helpers import neigh_args
+    _, _, qids, queries = setup
+    torch.manual_seed(5)
+    nm = NeighborhoodCountingModel(1, 64, neigh_args(use_tconv=False)).to_hetero_old(False, False)
+    with torch.no_grad():
+        for p in nm.parameters():
+            if p.dim() == 2:
+                p.mul_(1.3)
+    nm = nm.to(DEV)
+    nm.set_queries(qids)
+    assert "emb_model.gnn_core.convs.0.count__union__canonical.lin.weight" in nm.state_dict()
+    graphs = golden_graphs(max_n=41)[:12]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    sd = cpu_sd(nm)
+    union_types = (("count", "union", "canonical"), ("canonical", "union", "count"), ("count", "union", "count"))
+    ob = OP.neighborhood_batch(neighs, tconv=False)
+    qb = OP.query_batch(queries, tconv=False)
+    emb_q = OM.base_gnn_hetero(sd, "emb_model_query", qb, ("union_node",),
+                               (("union_node", "union", "union_node"),), 8)
+    emb_t = OM.base_gnn_hetero(sd, "emb_model", ob, OP.NODE_TYPES, union_types, 8, emulate_quirk=False)
+    with torch.no_grad():
+        got_q = nm.get_query_emb()
+        got_t = nm.emb_model(NeighborhoodBatch(part, DEV))
+    report("no-tconv query_emb", got_q, emb_q)
+    report("no-tconv target_emb", got_t, emb_t)
+    torch.testing.assert_close(got_q.cpu(), emb_q, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got_t.cpu(), emb_t, rtol=1e-4, atol=1e-4)
