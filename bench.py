@@ -107,13 +107,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DESCO_BENCH_SHARE_GPU=1 (testing only): all ranks on device 0 with the gloo backend, to
+    # exercise the multi-rank control flow on a 1-GPU box; the driver's runs use one GPU per rank
+    # and RCCL ("nccl").
+    share = os.environ.get("DESCO_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    comm_dev = torch.device("cpu") if share else device
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -152,12 +161,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only exchange of the inference path: graph-level counts to rank 0
-        gathered = [torch.empty_like(out["graph_gossip_count"]) for _ in range(world)] if rank == 0 else None
-        dist.gather(out["graph_gossip_count"], gathered, dst=0)
+        mine = out["graph_gossip_count"].to(comm_dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+        if rank == 0:
+            assert all(torch.isfinite(gt).all() for gt in gathered)
 
     graphs_per_step = graphs.num_graphs * world
     value = graphs_per_step * args.steps / elapsed
