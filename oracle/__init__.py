@@ -8,10 +8,14 @@ Pinning status:
   * integer path (``oracle.partition``): PINNED.  Checked against golden vectors produced by
     importing the reference's own pure-Python functions in the build container
     (``tests/golden/make_golden.py`` -> ``tests/golden/*.json|npz``).
-  * float path (``oracle.model``): PARITY UNPINNED by the reference.  The reference ships no tests
-    or golden vectors and its float path cannot be imported here (torch_geometric /
-    pytorch_lightning / torch_scatter are absent and not installable).  ``oracle.model`` is a
-    pure-torch CPU restatement of the reference semantics (file:line cited per function) that is
-    cross-checked only against independent dense-algebra formulas on tiny graphs
-    (``tests/test_oracle_model.py``).
+  * float path (``oracle.model``): PARTLY PINNED.  The reference ships no tests or golden vectors
+    and its float path cannot be imported as a whole (torch_geometric / pytorch_lightning /
+    torch_scatter are absent and not installable).  Pinned by vectors the reference's OWN code
+    produced (its pure-torch methods called unbound with a stand-in ``self``,
+    ``tests/golden/float_pieces.npz``, bit-exact): the count head (``embed_to_count``), both
+    criteria, ``GossipConv.message`` / ``update`` / ``_gate_value``.  PARITY UNPINNED for what only
+    PyG can execute: ``MessagePassing.propagate`` (scatter-add), ``to_hetero`` (per-type copies,
+    pairwise sum), ``global_add_pool``, ``remove_self_loops`` / ``to_undirected`` -- restated from
+    PyG 2.2.0 semantics and cross-checked against independent dense-algebra
+    formulas on tiny graphs (``tests/test_oracle_model.py``).
 """

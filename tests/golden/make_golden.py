@@ -169,3 +169,73 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def float_pieces():
+    """Golden vectors for the pieces of the FLOAT path that the reference's own code can execute
+    without PyG: methods that are pure torch once ``self`` carries the right nn.Modules are called
+    UNBOUND with a stand-in ``self`` (no reference source is copied or modified):
+      lightning_model.py:176-193  NeighborhoodCountingModel.embed_to_count (concat + count_model)
+      lightning_model.py:285-289  NeighborhoodCountingModel.criterion
+      lightning_model.py:630-635  GossipCountingModel.criterion
+      gnn_model.py:335-344        GossipConv.message  (lin_com, direction-gated scaling)
+      gnn_model.py:346-350        GossipConv.update   (cat + lin_update)
+      gnn_model.py:357-359        GossipConv._gate_value
+    MessagePassing.propagate / to_hetero / global_add_pool stay [EXT] (not executable here)."""
+    import types
+    import torch
+    import torch.nn as nn
+    _ref_import.install()
+    import subgraph_counting.gnn_model as ref_gnn
+    import subgraph_counting.lightning_model as ref_lm
+
+    torch.manual_seed(1234)
+    out = {}
+    # ---- count head -------------------------------------------------------------------------
+    count_model = nn.Sequential(nn.Linear(128, 256), nn.LeakyReLU(), nn.Linear(256, 1))
+    fake = types.SimpleNamespace(kwargs={}, count_model=count_model)
+    emb_t = torch.randn(37, 64)
+    emb_q = torch.randn(5, 64)
+    cols = []
+    with torch.no_grad():
+        for q in range(5):      # the loop of lightning_model.py:210-219
+            cols.append(ref_lm.NeighborhoodCountingModel.embed_to_count(
+                fake, (emb_t, emb_q[q].expand_as(emb_t))))
+    out.update(head_w0=count_model[0].weight, head_b0=count_model[0].bias, head_w2=count_model[2].weight,
+               head_b2=count_model[2].bias, head_emb_t=emb_t, head_emb_q=emb_q, head_out=torch.cat(cols, -1))
+    # ---- criteria -----------------------------------------------------------------------------
+    cnt, tru = torch.randn(41, 1) * 3, torch.rand(41, 1) * 6
+    out.update(crit_count=cnt, crit_truth=tru,
+               crit_neigh=ref_lm.NeighborhoodCountingModel.criterion(fake, cnt, tru),
+               crit_gossip=ref_lm.GossipCountingModel.criterion(fake, cnt, tru))
+    # ---- GossipConv message / update / gate ---------------------------------------------------
+    for name, cin in (("g0", 128), ("g1", 64)):
+        conv = types.SimpleNamespace(
+            lin_com=nn.Linear(cin, 64), lin_update=nn.Linear(64 + cin, 64),
+            lin_gate=nn.Sequential(nn.Linear(64, 64), nn.Sigmoid(), nn.Linear(64, 1), nn.Sigmoid(),
+                                   nn.LeakyReLU()))
+        n, e = 23, 57
+        x = torch.randn(n, cin)
+        src, dst = torch.randint(0, n, (e,)), torch.randint(0, n, (e,))
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        edge_weight = src < dst                                  # gnn_model.py:248
+        qe = torch.randn(1, 64)
+        with torch.no_grad():
+            msg = ref_gnn.GossipConv.message(conv, x[dst], x[src], edge_weight, qe)
+            aggr = torch.zeros(n, 64).index_add_(0, dst, msg)     # aggr="add" at edge_index[1] [EXT]
+            upd = ref_gnn.GossipConv.update(conv, aggr, x, None)
+            gate = ref_gnn.GossipConv._gate_value(conv, qe)
+        out.update({f"{name}_com_w": conv.lin_com.weight, f"{name}_com_b": conv.lin_com.bias,
+                    f"{name}_upd_w": conv.lin_update.weight, f"{name}_upd_b": conv.lin_update.bias,
+                    f"{name}_gate0_w": conv.lin_gate[0].weight, f"{name}_gate0_b": conv.lin_gate[0].bias,
+                    f"{name}_gate2_w": conv.lin_gate[2].weight, f"{name}_gate2_b": conv.lin_gate[2].bias,
+                    f"{name}_x": x, f"{name}_src": src, f"{name}_dst": dst, f"{name}_qe": qe,
+                    f"{name}_msg": msg, f"{name}_upd": upd, f"{name}_gate": gate})
+    np.savez_compressed(os.path.join(HERE, "float_pieces.npz"),
+                        **{k: v.detach().numpy() for k, v in out.items()})
+    print("float_pieces.npz written")
+
+
+if __name__ == "__main__":
+    float_pieces()
