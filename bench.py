@@ -32,7 +32,7 @@ import torch
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s, ~6.3 achievable)
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (same guide)
-MFMA_KERNELS = {"gemm_f32_kernel", "shmp_layer_f32_kernel", "gossip_fused_kernel"}
+MFMA_KERNELS = {"gemm_f32_kernel", "gemm_split_kernel", "shmp_layer_f32_kernel", "gossip_fused_kernel"}
 
 
 def build_models(device, seed=0):

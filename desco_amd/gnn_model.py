@@ -27,6 +27,9 @@ H = 64
 FUSED_SHMP_LAYER = True
 # scalars pre-pass + one on-chip kernel for the whole gossip network (False: 7 launches via HBM)
 FUSED_GOSSIP = True
+# inference GEMMs (anchor, post MLP, head, canonical table) on the bf16 matrix pipe with fp32-level
+# accuracy (bf16x6 split, csrc/gemm_split.hip); False: v_mfma_f32_32x32x2_f32 (gemm_f32.hip)
+GEMM_BF16X6 = True
 
 TARGET_NODE_TYPES = ["count", "canonical"]
 # metadata of to_hetero_old(tconv_target=True), lightning_model.py:376-383
@@ -272,14 +275,25 @@ def pack_shmp(gnn: BaseGNN) -> dict:
                 # per row; apply them from a pre-transformed table (K 320 -> 192)
                 entry["wt_mfma"] = torch.cat([blocks[0], blocks[1], blocks[4]], 0).contiguous()
                 entry["wt_tab"] = torch.cat([blocks[2], blocks[3]], 1).contiguous()      # [64,128]
+                entry["wt_tab_nk"] = entry["wt_tab"].t().contiguous()                     # [128,64]
             per_type[t] = entry
         pk["layers"].append(per_type)
     pk["anchor"] = _lin_t(gnn.anchor_mlp[0])
     pk["post"] = [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]
+    # n-major ([out, in]) operands of the bf16x6 GEMM
+    pk["anchor_nk"] = (gnn.anchor_mlp[0].weight.contiguous(), gnn.anchor_mlp[0].bias.contiguous())
+    pk["post_nk"] = [(gnn.post_mp[i].weight.contiguous(), gnn.post_mp[i].bias.contiguous())
+                     for i in (0, 3, 5, 7)]
     return pk
 
 
 def _post_mp(pk, pooled):
+    if GEMM_BF16X6 and "post_nk" in pk:
+        (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post_nk"]
+        h = ops.gemm_split(pooled, w0, b0, act=ops.ACT_LEAKY, slope=0.1)
+        h = ops.gemm_split(h, w3, b3, act=ops.ACT_RELU)
+        h = ops.gemm_split(h, w5, b5, act=ops.ACT_RELU)
+        return ops.gemm_split(h, w7, b7)
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
     h = ops.gemm(pooled, w0, b0, act=ops.ACT_LEAKY, slope=0.1)
     h = ops.gemm(h, w3, b3, act=ops.ACT_RELU)
@@ -337,7 +351,8 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                     continue
                 e = pk["layers"][l][t]
                 if "wt_tab" in e:
-                    ytab = ops.gemm(X[-1][Nc:], e["wt_tab"])               # canonical rows x [W2|W3]
+                    ytab = (ops.gemm_split(X[-1][Nc:], e["wt_tab_nk"]) if GEMM_BF16X6 else
+                            ops.gemm(X[-1][Nc:], e["wt_tab"]))            # canonical rows x [W2|W3]
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2, e["wt_mfma"],
                                    e["b"], xn, ytab=ytab, ytab_row0=Nc)
                 else:
@@ -358,7 +373,10 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         c0 = x0["canonical"].expand(B, H) if const_input else X[0][Nc:]
         canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)            # emb["canonical"] [B,P]
         aw, ab = pk["anchor"]
-        anch = ops.gemm(canon, aw, ab, act=ops.ACT_LEAKY, slope=0.1)       # :69-73
+        if GEMM_BF16X6:
+            anch = ops.gemm_split(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
+        else:
+            anch = ops.gemm(canon, aw, ab, act=ops.ACT_LEAKY, slope=0.1)   # :69-73
         seg_ptr = batch.count_ptr
     else:
         anch = None                                  # query graphs: no canonical node, no anchor

@@ -165,6 +165,7 @@ class NeighborhoodCountingModel(_LightningLike):
                 W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
                 self._head_cache = (ver, {
                     "wt_t": W1[:, :H].t().contiguous(), "wt_q": W1[:, H:].t().contiguous(),
+                    "w_t_nk": W1[:, :H].contiguous(), "w_q_nk": W1[:, H:].contiguous(),
                     "b1": b1.contiguous(), "w2": self.count_model[2].weight[0].contiguous(),
                     "b2": float(self.count_model[2].bias[0])})
         return self._head_cache[1]
@@ -173,8 +174,13 @@ class NeighborhoodCountingModel(_LightningLike):
         emb_q = self.get_query_emb()
         emb_t = self.emb_model(batch)
         hp = self._head_pack()
-        T = ops.gemm(emb_t, hp["wt_t"])                                     # target half
-        Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])                          # query half + bias
+        from . import gnn_model as GM
+        if GM.GEMM_BF16X6:
+            T = ops.gemm_split(emb_t, hp["w_t_nk"])                         # target half
+            Qh = ops.gemm_split(emb_q, hp["w_q_nk"], hp["b1"])              # query half + bias
+        else:
+            T = ops.gemm(emb_t, hp["wt_t"])
+            Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])
         return ops.count_head(T, Qh, hp["w2"], hp["b2"], self.count_model[1].negative_slope, exp2)
 
     def graph_to_count(self, batch) -> torch.Tensor:                         # :198-222

@@ -197,6 +197,33 @@ def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, c
     return out
 
 
+def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act([a1 | a2] @ w.T + bias) with fp32-level accuracy on the bf16 matrix pipe (bf16x6).
+    ``w`` is N-MAJOR: [n, k1+k2] (torch's [out, in])."""
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = w.shape[0]
+    assert w.shape[1] == k1 + k2 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), device=a1.device, dtype=torch.float32)
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    op, ldo = _rows(out, "out")
+    bias_rows = 1
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_rows = 1 if bias.dim() == 1 else bias.shape[0]
+    L = _lib.lib()
+    kk = k1 + k2
+    with _Timed("gemm_split_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n)):
+        _lib.check(L.desco_gemm_bf16x6_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(w, "w"), n,
+                                           _opt(bias, "bias"), bias_rows, None, 0, None, act, slope,
+                                           op, ldo, m, _stream()), "gemm_split")
+    return out
+
+
 def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
                 extra: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

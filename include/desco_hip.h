@@ -119,6 +119,15 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
                    int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
                    int64_t m, desco_stream_t stream);
 
+/* Same contract as desco_gemm_f32 but computed on the bf16 matrix pipe with fp32-level accuracy
+ * ("bf16x6": each fp32 operand is split into three bf16 terms, the six products of weight >= 2^-16
+ * are accumulated in fp32; error ~2^-23 per product).  The weight is passed N-MAJOR:
+ * w[n][k1+k2] row major (torch's native [out, in] layout), not transposed. */
+int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2,
+                          int k2, const float* w, int n, const float* bias, int bias_rows,
+                          const float* s, int ns, const float* ws, int act, float slope, float* c,
+                          int64_t ldc, int64_t m, desco_stream_t stream);
+
 /* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip).  For destination rows i in
  * [row0, row0+num_rows), with sm = slots_mfma <= 3, st = slots_table <= 2, S = slots_stored (sm+st <= S <= 4):
  *   out[i] = relu( sum_{s<sm} (sum_{e in vrow(i*S+s)} x[vcol[e]]) * Wt_s + x[i] * Wt_sm + bias

@@ -228,3 +228,23 @@ def test_degree_affine():
                       extra=extra.to(DEV)[:, 64:128])
     _close(out[row0:], ref, atol=1e-4)
     assert (out[:row0] == -3.0).all()
+
+
+@pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (129, 128, 64, 64), (1000, 576, 0, 576), (4097, 64, 0, 256)])
+def test_gemm_bf16x6_is_fp32_accurate(m, k1, k2, n):
+    g = torch.Generator().manual_seed(m + n)
+    a1 = torch.randn(m, k1, generator=g) * torch.rand(m, 1, generator=g) * 30
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    bias = torch.randn(n, generator=g)
+    A = a1 if a2 is None else torch.cat([a1, a2], 1)
+    ref = torch.nn.functional.leaky_relu(A.double() @ w.double().T + bias.double(), 0.1)
+    got = ops.gemm_split(a1.to(DEV), w.to(DEV), bias.to(DEV), a2=None if a2 is None else a2.to(DEV),
+                         act=ops.ACT_LEAKY, slope=0.1)
+    f32 = ops.gemm(a1.to(DEV), w.t().contiguous().to(DEV), bias.to(DEV),
+                   a2=None if a2 is None else a2.to(DEV), act=ops.ACT_LEAKY, slope=0.1)
+    e_split = (got.cpu().double() - ref).abs().max().item()
+    e_f32 = (f32.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"[accuracy] m={m} k={k1}+{k2} n={n}: bf16x6 err {e_split:.2e}  f32-MFMA err {e_f32:.2e}  scale {scale:.1f}")
+    assert e_split <= max(4 * e_f32, 2e-6 * scale)
