@@ -13,7 +13,8 @@
 // Nothing but the 16-byte scalar records and the [N,Q] result crosses HBM (the unfused path moves
 // ~2.3 KB per (node,query)); the kernel is bound by the f32 MFMA rate (288 MFMAs per wave and tile).
 // Block = 4 waves, output tiles 64x64 as 2x2 wave tiles of 32x32 (v_mfma_f32_32x32x2_f32); three
-// 64x68 activation images + one 64x68 weight image in LDS (71 KB -> 2 blocks per CU); weight
+// 64x68 activation images + one 64x68 weight image in LDS (71 KB -> 2 blocks per CU); the last GEMM
+// (64 -> 256) runs as a 6-product bf16 split (fp32-accurate) whose planes overlay dead images; weight
 // blocks are prefetched into registers under the previous block's MFMAs.  Blocks are persistent
 // (2 per CU) and walk (tile, query) items; the next item's CSR slice and scalar records are
 // prefetched through registers in three stages under the current item's GEMMs.
@@ -45,7 +46,8 @@ struct GossipFusedArgs {
   const float* wp;          // [64,128]
   const float* w3;          // [64,64]
   const float* b3;          // [64]
-  const float* w5;          // [256,64]
+  const float* w5;          // [256,64]  (kept for reference / un-split builds)
+  const short* w5s;         // [3][256][64] bf16 planes (hi, mid, lo) of w5, split on the host
   const float* b5;          // [256]
   const float* w7;          // [256]
   float b7;
@@ -119,16 +121,23 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc, 0, 0, 0);                       \
     }                                                                                             \
   }
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
 #define DESCO_ACC_ZERO() \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[i_] = 0.f;
 
+constexpr int PST = 72;     // bf16 plane row stride (144 B): 16-B aligned, conflict-free b128 reads
 constexpr int PCAP = 256;   // neighbour records prefetched (one per thread) for the next tile
 
 __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
   __shared__ __attribute__((aligned(16))) float lds[3 * GT * GAS + 64 * GAS + 4 * GT + 68];
   float* A0 = lds;                      // h1, later y2
-  float* A1 = lds + GT * GAS;           // hh, later y1
-  float* A2 = lds + 2 * GT * GAS;       // neighbour staging, later h2, later head partials
+  float* A2 = lds + GT * GAS;           // neighbour staging, later h2, later head partials
+  float* A1 = lds + 2 * GT * GAS;       // hh, later y1
+  // post_mp.5 (64 -> 256, 44 % of the tile's MFMA work) runs fp32-accurately on the bf16 pipe
+  // (bf16x6, see gemm_split.hip): y2 is written as three bf16 planes over A0 + the head of A2, the
+  // pre-split W5 block planes go over the tail of A2 + A1 + the head of Bs (all dead by then).
+  short* Y2P = reinterpret_cast<short*>(lds);            // [3][64][PST]
+  short* W5P = Y2P + 3 * GT * PST;                       // [3][64][PST]
   float* Bs = lds + 3 * GT * GAS;       // weight block, n-major [64 n][64 k], stride GAS
   float4* srow = reinterpret_cast<float4*>(Bs + 64 * GAS);   // scalars of the tile rows
   int* rp = reinterpret_cast<int*>(Bs + 64 * GAS + 4 * GT);  // rowptr[n0 .. n0+64]
@@ -283,19 +292,50 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g,
   }
   __syncthreads();
   if (has_next) DESCO_STAGE3(next)
-  // ---- G3: y2 = relu(y1 W3 + b3) -> A0 ------------------------------------------------------
+  // ---- G3: y2 = relu(y1 W3 + b3) -> three bf16 planes (hi, mid, lo) -------------------------
   DESCO_ACC_ZERO()
   DESCO_WSTORE()
   __syncthreads();
-  DESCO_WLOAD(g.w5, 64)
+  // first W5 column group (64 n x 64 k, three planes): thread t moves 16 shorts of row n = t>>2
+  uint4 q0, q1, q2, q3, q4, q5;
+#define DESCO_W5LOAD(cg_)                                                                     \
+  {                                                                                           \
+    const short* s_ = g.w5s + ((int64_t)(64 * (cg_) + (tid >> 2))) * 64 + 16 * (tid & 3);     \
+    q0 = *reinterpret_cast<const uint4*>(s_);                                                 \
+    q1 = *reinterpret_cast<const uint4*>(s_ + 8);                                             \
+    q2 = *reinterpret_cast<const uint4*>(s_ + 256 * 64);                                      \
+    q3 = *reinterpret_cast<const uint4*>(s_ + 256 * 64 + 8);                                  \
+    q4 = *reinterpret_cast<const uint4*>(s_ + 2 * 256 * 64);                                  \
+    q5 = *reinterpret_cast<const uint4*>(s_ + 2 * 256 * 64 + 8);                              \
+  }
+#define DESCO_W5STORE()                                                                       \
+  {                                                                                           \
+    short* d_ = W5P + (tid >> 2) * PST + 16 * (tid & 3);                                      \
+    *reinterpret_cast<uint4*>(d_) = q0;                                                       \
+    *reinterpret_cast<uint4*>(d_ + 8) = q1;                                                   \
+    *reinterpret_cast<uint4*>(d_ + GT * PST) = q2;                                            \
+    *reinterpret_cast<uint4*>(d_ + GT * PST + 8) = q3;                                        \
+    *reinterpret_cast<uint4*>(d_ + 2 * GT * PST) = q4;                                        \
+    *reinterpret_cast<uint4*>(d_ + 2 * GT * PST + 8) = q5;                                    \
+  }
+  DESCO_W5LOAD(0)
   DESCO_MFMA_BLOCK(A1)
   {
     const float bc = g.b3[col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const float v = acc[reg] + bc;
-      A0[row * GAS + col] = v > 0.f ? v : 0.f;
+      float v = acc[reg] + bc;
+      v = v > 0.f ? v : 0.f;
+      // truncation split: hi + mid + lo carries all 24 significand bits of v
+      const uint32_t uh = __float_as_uint(v) & 0xffff0000u;
+      const float r1 = v - __uint_as_float(uh);
+      const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(um);
+      short* d = Y2P + row * PST + col;
+      d[0] = (short)(uh >> 16);
+      d[GT * PST] = (short)(um >> 16);
+      d[2 * GT * PST] = (short)(__float_as_uint(r2) >> 16);
     }
   }
   __syncthreads();
@@ -306,10 +346,29 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g,
 #pragma unroll
   for (int cg = 0; cg < 4; ++cg) {
     DESCO_ACC_ZERO()
-    DESCO_WSTORE()
+    DESCO_W5STORE()
     __syncthreads();
-    if (cg < 3) DESCO_WLOAD(g.w5 + 64 * 64 * (cg + 1), 64)
-    DESCO_MFMA_BLOCK(A0)
+    if (cg < 3) DESCO_W5LOAD(cg + 1)
+    {
+      // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
+      const short* ya = Y2P + (wr * 32 + (lane & 31)) * PST + 8 * (lane >> 5);
+      const short* wb = W5P + (wc * 32 + (lane & 31)) * PST + 8 * (lane >> 5);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ya + 16 * s4);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ya + GT * PST + 16 * s4);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ya + 2 * GT * PST + 16 * s4);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb + 16 * s4);
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(wb + GT * PST + 16 * s4);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 2 * GT * PST + 16 * s4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+    }
     const float bc = g.b5[cg * 64 + col], wv = g.w7[cg * 64 + col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -318,6 +377,8 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g,
     }
     __syncthreads();
   }
+#undef DESCO_W5LOAD
+#undef DESCO_W5STORE
   // reduce the 64 column partials of every row through the (now free) A2 image
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
@@ -374,18 +435,18 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                                       const float* t, const float* u, const float* tp,
                                       const float* d1, const float* w1, const float* wp,
                                       const float* w3, const float* b3, const float* w5,
-                                      const float* b5, const float* w7, float b7, float* out,
-                                      desco_stream_t stream) {
+                                      const int16_t* w5_planes, const float* b5, const float* w7,
+                                      float b7, float* out, desco_stream_t stream) {
   if (num_nodes == 0) return 0;
   auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
   if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !w1 || !wp ||
-      !w3 || !b3 || !w5 || !b5 || !w7 || !out || num_nodes < 0 || num_q < 1 || num_q > 65535 ||
-      mis16(scal4) || mis16(w1) || mis16(wp) || mis16(w3) || mis16(w5))
+      !w3 || !b3 || !w5 || !w5_planes || !b5 || !w7 || !out || num_nodes < 0 || num_q < 1 || num_q > 65535 ||
+      mis16(scal4) || mis16(w1) || mis16(wp) || mis16(w3) || mis16(w5) || mis16(w5_planes))
     return fail(DESCO_EINVAL, "desco_gossip_fused_f32: bad argument");
   const int64_t bx = (num_nodes + GT - 1) / GT;
   if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f32: too many nodes");
   GossipFusedArgs a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z,
-                    zp, r, t, u, tp, d1, w1, wp, w3, b3, w5, b5, w7, b7, out};
+                    zp, r, t, u, tp, d1, w1, wp, w3, b3, w5, reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out};
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;

@@ -306,6 +306,20 @@ def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_
     return out
 
 
+def split_bf16_planes(w: torch.Tensor) -> torch.Tensor:
+    """[3, *w.shape] int16: the truncation split w = hi + mid + lo into bf16 bit patterns (operand
+    format of the bf16x6 kernels; plumbing on a weight tensor, done once per weight version)."""
+    w = w.contiguous().float()
+    mask = -65536          # 0xffff0000 as int32
+    hi = torch.bitwise_and(w.view(torch.int32), mask)
+    r1 = w - hi.view(torch.float32)
+    mid = torch.bitwise_and(r1.view(torch.int32), mask)
+    r2 = r1 - mid.view(torch.float32)
+    lo = torch.bitwise_and(r2.view(torch.int32), mask)
+    planes = torch.stack([hi, mid, lo]) >> 16
+    return planes.to(torch.int16).contiguous()
+
+
 def gossip_scalars(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, g1) -> torch.Tensor:
     """scal4[i*Q+q] = (a0, b0, a1, x[i,q]) -- the per-(node, query) scalars of the gossip stage."""
     N, Q = x.shape
@@ -329,12 +343,12 @@ def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, nu
     """One on-chip pass per (64-node tile, query): returns pred [N, Q] (see desco_hip.h)."""
     out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
     L = _lib.lib()
-    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1", "wp", "w3", "b3", "w5", "b5", "w7")
+    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1", "wp", "w3", "b3", "w5", "w5s", "b5", "w7")
     ptrs = []
     for n in names:
         if not v[n].is_contiguous():
             raise ValueError(f"gossip_fused: operand {n} must be contiguous")
-        ptrs.append(_dev(v[n], n))
+        ptrs.append(_dev(v[n], n, torch.int16 if n == "w5s" else torch.float32))
     rows = float(num_nodes) * num_q
     with _Timed("gossip_fused_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
                 rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
