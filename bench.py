@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--graph", action="store_true",
                     help="replay the pass from a captured hipGraph (implies --no-profile)")
+    ap.add_argument("--by-shape", action="store_true",
+                    help="diagnostic: key GEMM launches by shape in the kernel table")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +155,7 @@ def main():
         out = step()
     sync()
     ops.PROFILER.enabled = not args.no_profile
+    ops.PROFILER.by_shape = args.by_shape
     ops.PROFILER.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -4,12 +4,17 @@
 //     a*b ~= hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)            (error ~2^-23 |a||b|)
 // v_mfma_f32_32x32x16_bf16 runs at 16x the f32 MFMA rate, so six of them per 16-deep step cost
 // 192 cycles against 512 for eight v_mfma_f32_32x32x2_f32 -- and the operand fragments are 16-byte
-// LDS reads.  Same contract as desco_gemm_f32 except that the weight is passed n-major
-// (w[n][k], torch's native [out, in] layout).
+// LDS reads.  Same contract as desco_gemm_f32 except for the weight operand: it is passed already
+// split, as three n-major bf16 planes w_planes[3][n][k] (desco_split_bf16x3_f32 makes them once per
+// weight version), so only the activation operand is split in the kernel.
 //
-// Tiling: 256 threads = 4 waves, block tile 128 rows x 64 cols, wave w owns rows 32w..32w+31 and both
-// 32-wide column halves.  K chunks of 32: global float4 -> split in registers -> three bf16 planes
-// per operand in LDS ([row][32+8] bf16, 80-byte rows: conflict-free ds_read_b128).
+// The split is VALU work (~6 instructions per float) and VALU does not overlap MFMA on a SIMD, so
+// the tile is made wide: 256 threads = 2x2 waves, block tile 128 rows x 64*WN cols (WN = 3, 2, 1 ->
+// 192, 128, 64), wave tile 64 x 32*WN = 2 x WN accumulators; one split of an A chunk then feeds
+// 6*WN MFMAs per 16-deep step.  K chunks of 32: A global float4 -> split in registers -> three bf16
+// planes in LDS; W planes are copied global -> registers -> LDS; rows are 80 bytes ([32+8] bf16):
+// conflict-free ds_read_b128.  Block ids are laid out XCD-aware with the column tile fastest, so the
+// n-tiles that share an A row panel run back to back on the same XCD and re-read it from its L2.
 #include "common_device.hpp"
 
 namespace desco {
@@ -21,7 +26,7 @@ struct GemmSplitArgs {
   const float* a2;
   int64_t lda2;
   int k2;
-  const float* w;     // [n][k1+k2]
+  const short* w;     // planes [3][n][k1+k2] (hi, mid, lo)
   int n;
   const float* bias;
   int bias_rows;
@@ -37,39 +42,46 @@ struct GemmSplitArgs {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-constexpr int SBM = 128, SBN = 64, SBK = 32, SST = 40;   // SST: plane row stride in bf16 (80 B)
-constexpr int APLANE = SBM * SST, BPLANE = SBN * SST;    // elements per plane
+constexpr int SBM = 128, SBK = 32, SST = 40;   // SST: plane row stride in bf16 (80 B)
+constexpr int APLANE = SBM * SST;              // elements per A plane
 
-// split 4 floats into three planes of 4 packed bf16 (8 bytes each)
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
-  uint32_t h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t u = __float_as_uint(f[i]);
-    h[i] = u & 0xffff0000u;
-    const float r1 = f[i] - __uint_as_float(h[i]);
-    m[i] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m[i]);
-    l[i] = __float_as_uint(r2) & 0xffff0000u;
-  }
-  hi = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-  mid = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-  lo = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
+// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane
+__device__ __forceinline__ void split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
+                                       uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
+  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
+  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
+  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
+  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
+  // v_perm_b32: bytes {2,3} of the first float, bytes {2,3} of the second
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
 }
 
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g) {
-  __shared__ __attribute__((aligned(16))) short lds[3 * APLANE + 3 * BPLANE];
+template <int WN>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
+  constexpr int BN = 64 * WN, BPLANE = BN * SST;
+  extern __shared__ __attribute__((aligned(16))) short lds[];
   short* Ap = lds;                  // planes hi, mid, lo of the A chunk [128][40]
-  short* Bp = lds + 3 * APLANE;     // planes hi, mid, lo of the W chunk [64][40]
+  short* Bp = lds + 3 * APLANE;     // planes hi, mid, lo of the W chunk [BN][40]
+
+  // block id -> (m tile, n tile): ids id, id+8, id+16, ... share an XCD (round-robin dispatch);
+  // within an XCD the n tile runs fastest so an A row panel is fetched from HBM once per XCD.
+  const int64_t id = blockIdx.x;
+  const int64_t local = id >> 3;
+  const int64_t mt = (local / ny) * 8 + (id & 7);
+  if (mt >= gm) return;
+  const int n0 = (int)(local % ny) * BN;
+  const int64_t m0 = mt * SBM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * SBM;
-  const int n0 = blockIdx.y * SBN;
+  const int wr = wave >> 1, wc = wave & 1;
   const int K = g.k1 + g.k2;
   const int nchunks = K / SBK;
 
-  // staging maps: A 128 rows x 8 float4 -> 4 per thread; W 64 rows x 8 float4 -> 2 per thread
+  // staging maps: A 128 rows x 8 float4 -> 4 per thread; W planes BN rows x 4 uint4 -> WN per plane
   const int arow = tid >> 3, ac4 = tid & 7;
   int64_t r0 = m0 + arow, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
   const int64_t mlast = g.m - 1;
@@ -85,46 +97,75 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g) {
   const float* p21 = g.k2 ? g.a2 + r1 * g.lda2 + 4 * ac4 - g.k1 : p11;
   const float* p22 = g.k2 ? g.a2 + r2 * g.lda2 + 4 * ac4 - g.k1 : p12;
   const float* p23 = g.k2 ? g.a2 + r3 * g.lda2 + 4 * ac4 - g.k1 : p13;
-  const float* pw0 = g.w + (int64_t)(n0 + arow) * K + 4 * ac4;
-  const float* pw1 = pw0 + (int64_t)32 * K;
+  const int brow = tid >> 2, bpart = tid & 3;
+  const short* pw = g.w + (int64_t)(n0 + brow) * K + 8 * bpart;
+  const int64_t wplane = (int64_t)g.n * K;
 
-  float4 ra0, ra1, ra2, ra3, rb0, rb1;
-#define DESCO_LOAD_CHUNK(kk_)                                         \
-  {                                                                   \
-    const int k_ = (kk_);                                             \
-    const bool s1_ = k_ < g.k1;                                       \
-    ra0 = *reinterpret_cast<const float4*>((s1_ ? p10 : p20) + k_);   \
-    ra1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);   \
-    ra2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);   \
-    ra3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);   \
-    rb0 = *reinterpret_cast<const float4*>(pw0 + k_);                 \
-    rb1 = *reinterpret_cast<const float4*>(pw1 + k_);                 \
+  float4 ra0, ra1, ra2, ra3;
+  uint4 rb00, rb01, rb02, rb10, rb11, rb12, rb20, rb21, rb22;   // W planes of the next chunk
+  const int64_t wj = (int64_t)64 * K;
+#define DESCO_LOAD_CHUNK(kk_)                                                                 \
+  {                                                                                           \
+    const int k_ = (kk_);                                                                     \
+    const bool s1_ = k_ < g.k1;                                                               \
+    ra0 = *reinterpret_cast<const float4*>((s1_ ? p10 : p20) + k_);                           \
+    ra1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);                           \
+    ra2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);                           \
+    ra3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);                           \
+    const short* w_ = pw + k_;                                                                \
+    rb00 = *reinterpret_cast<const uint4*>(w_);                                               \
+    rb01 = *reinterpret_cast<const uint4*>(w_ + wplane);                                      \
+    rb02 = *reinterpret_cast<const uint4*>(w_ + 2 * wplane);                                  \
+    if constexpr (WN > 1) {                                                                   \
+      rb10 = *reinterpret_cast<const uint4*>(w_ + wj);                                        \
+      rb11 = *reinterpret_cast<const uint4*>(w_ + wj + wplane);                               \
+      rb12 = *reinterpret_cast<const uint4*>(w_ + wj + 2 * wplane);                           \
+    }                                                                                         \
+    if constexpr (WN > 2) {                                                                   \
+      rb20 = *reinterpret_cast<const uint4*>(w_ + 2 * wj);                                    \
+      rb21 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + wplane);                           \
+      rb22 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + 2 * wplane);                       \
+    }                                                                                         \
   }
-#define DESCO_PUT(base_, plane_, row_, v_)                                                        \
-  {                                                                                               \
-    uint2 h_, m_, l_;                                                                             \
-    split4(v_, h_, m_, l_);                                                                       \
-    short* d_ = (base_) + (row_)*SST + 4 * ac4;                                                   \
-    *reinterpret_cast<uint2*>(d_) = h_;                                                           \
-    *reinterpret_cast<uint2*>(d_ + (plane_)) = m_;                                                \
-    *reinterpret_cast<uint2*>(d_ + 2 * (plane_)) = l_;                                            \
+#define DESCO_PUT(row_, v_)                                                                   \
+  {                                                                                           \
+    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                    \
+    split2(v_.x, v_.y, h0_, m0_, l0_);                                                        \
+    split2(v_.z, v_.w, h1_, m1_, l1_);                                                        \
+    short* d_ = Ap + (row_)*SST + 4 * ac4;                                                    \
+    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                     \
+    *reinterpret_cast<uint2*>(d_ + APLANE) = make_uint2(m0_, m1_);                            \
+    *reinterpret_cast<uint2*>(d_ + 2 * APLANE) = make_uint2(l0_, l1_);                        \
   }
-#define DESCO_STORE_CHUNK()                       \
-  {                                               \
-    DESCO_PUT(Ap, APLANE, arow, ra0)              \
-    DESCO_PUT(Ap, APLANE, arow + 32, ra1)         \
-    DESCO_PUT(Ap, APLANE, arow + 64, ra2)         \
-    DESCO_PUT(Ap, APLANE, arow + 96, ra3)         \
-    DESCO_PUT(Bp, BPLANE, arow, rb0)              \
-    DESCO_PUT(Bp, BPLANE, arow + 32, rb1)         \
+#define DESCO_STORE_CHUNK()                                                                   \
+  {                                                                                           \
+    DESCO_PUT(arow, ra0)                                                                      \
+    DESCO_PUT(arow + 32, ra1)                                                                 \
+    DESCO_PUT(arow + 64, ra2)                                                                 \
+    DESCO_PUT(arow + 96, ra3)                                                                 \
+    short* b_ = Bp + brow * SST + 8 * bpart;                                                  \
+    *reinterpret_cast<uint4*>(b_) = rb00;                                                     \
+    *reinterpret_cast<uint4*>(b_ + BPLANE) = rb01;                                            \
+    *reinterpret_cast<uint4*>(b_ + 2 * BPLANE) = rb02;                                        \
+    if constexpr (WN > 1) {                                                                   \
+      *reinterpret_cast<uint4*>(b_ + 64 * SST) = rb10;                                        \
+      *reinterpret_cast<uint4*>(b_ + 64 * SST + BPLANE) = rb11;                               \
+      *reinterpret_cast<uint4*>(b_ + 64 * SST + 2 * BPLANE) = rb12;                           \
+    }                                                                                         \
+    if constexpr (WN > 2) {                                                                   \
+      *reinterpret_cast<uint4*>(b_ + 128 * SST) = rb20;                                       \
+      *reinterpret_cast<uint4*>(b_ + 128 * SST + BPLANE) = rb21;                              \
+      *reinterpret_cast<uint4*>(b_ + 128 * SST + 2 * BPLANE) = rb22;                          \
+    }                                                                                         \
   }
 
-  f32x16 acc0, acc1;
+  f32x16 acc[2][WN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    acc0[i] = 0.f;
-    acc1[i] = 0.f;
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   DESCO_LOAD_CHUNK(0)
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -134,30 +175,36 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g) {
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
     DESCO_LOAD_CHUNK(chn * SBK)            // in flight under the MFMAs
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
-    const short* ap = Ap + (wave * 32 + (lane & 31)) * SST + 8 * (lane >> 5);
-    const short* bp = Bp + (lane & 31) * SST + 8 * (lane >> 5);
+    const short* ap = Ap + (wr * 64 + (lane & 31)) * SST + 8 * (lane >> 5);
+    const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST + 8 * (lane >> 5);
 #pragma unroll
     for (int s = 0; s < SBK / 16; ++s) {
-      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + 16 * s);
-      const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + APLANE + 16 * s);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * APLANE + 16 * s);
+      bf16x8 ah[2], am[2], al[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const short* bt = bp + t * 32 * SST + 16 * s;
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 16 * s);
+        am[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + APLANE + 16 * s);
+        al[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 2 * APLANE + 16 * s);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const short* bt = bp + j * 32 * SST + 16 * s;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bt);
         const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bt + BPLANE);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bt + 2 * BPLANE);
-        f32x16 a = t == 0 ? acc0 : acc1;
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a, 0, 0, 0);
-        if (t == 0)
-          acc0 = a;
-        else
-          acc1 = a;
+        // smallest terms first; the two row tiles alternate so dependent MFMAs are never adjacent
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bm, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bm, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bh, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bh, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bm, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bm, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1][j], 0, 0, 0);
       }
     }
   }
@@ -168,49 +215,99 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g) {
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col = lane & 31;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int gcol = n0 + 32 * t + col;
+  for (int j = 0; j < WN; ++j) {
+    const int gcol = n0 + wc * 32 * WN + 32 * j + col;
     float wsv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < g.ns; ++j) wsv[j] = g.ws[(int64_t)j * g.n + gcol];
+    for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
     const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const int64_t grow = m0 + row;
-      if (grow < g.m) {
-        float v = t == 0 ? acc0[reg] : acc1[reg];
-        if (g.bias) {
-          if (g.bias_rows == 1)
-            v += b_single;
-          else
-            v += g.bias[(grow % g.bias_rows) * g.n + gcol];
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wr * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int64_t grow = m0 + row;
+        if (grow < g.m) {
+          float v = acc[i][j][reg];
+          if (g.bias) {
+            if (g.bias_rows == 1)
+              v += b_single;
+            else
+              v += g.bias[(grow % g.bias_rows) * g.n + gcol];
+          }
+          for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
+          g.c[grow * g.ldc + gcol] = apply_act(v, g.act, g.slope);
         }
-        for (int j = 0; j < g.ns; ++j) v += g.s[grow * g.ns + j] * wsv[j];
-        g.c[grow * g.ldc + gcol] = apply_act(v, g.act, g.slope);
       }
     }
   }
 }
 
+// w[count] -> planes[3][count] (hi, mid, lo bf16 bit patterns of the truncation split)
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ w, int64_t count,
+                                                            short* __restrict__ planes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float f = w[i];
+  const uint32_t uh = __float_as_uint(f) & 0xffff0000u;
+  const float r1 = f - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  planes[i] = (short)(uh >> 16);
+  planes[count + i] = (short)(um >> 16);
+  planes[2 * count + i] = (short)(__float_as_uint(r2) >> 16);
+}
+
+template <int WN>
+static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
+  constexpr int BN = 64 * WN;
+  constexpr size_t lds_bytes = (size_t)(3 * APLANE + 3 * BN * SST) * sizeof(short);
+  static bool configured = false;     // benign race: the attribute is idempotent
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_f32: cannot size LDS");
+    configured = true;
+  }
+  const int64_t gm = (g.m + SBM - 1) / SBM;
+  const int ny = g.n / BN;
+  const int64_t blocks = ((gm + 7) / 8) * 8 * ny;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: m too large");
+  hipLaunchKernelGGL(gemm_split_kernel<WN>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, g,
+                     gm, ny);
+  return launch_status("desco_gemm_bf16x6_f32");
+}
+
 }  // namespace desco
 
 extern "C" int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2,
-                                     int64_t lda2, int k2, const float* w, int n, const float* bias,
-                                     int bias_rows, const float* s, int ns, const float* ws, int act,
-                                     float slope, float* c, int64_t ldc, int64_t m,
-                                     desco_stream_t stream) {
+                                     int64_t lda2, int k2, const int16_t* w_planes, int n,
+                                     const float* bias, int bias_rows, const float* s, int ns,
+                                     const float* ws, int act, float slope, float* c, int64_t ldc,
+                                     int64_t m, desco_stream_t stream) {
   using namespace desco;
   if (m == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (m < 0 || !a1 || !w || !c || k1 <= 0 || k1 % SBK || k2 < 0 || k2 % SBK || n <= 0 || n % SBN ||
-      (k2 > 0 && !a2) || ns < 0 || ns > 4 || (ns > 0 && (!s || !ws)) || (bias && bias_rows < 1) ||
-      lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) || (k2 > 0 && mis16(a2)) || mis16(w))
+  if (m < 0 || !a1 || !w_planes || !c || k1 <= 0 || k1 % SBK || k2 < 0 || k2 % SBK || n <= 0 ||
+      n % 64 || (k2 > 0 && !a2) || ns < 0 || ns > 4 || (ns > 0 && (!s || !ws)) ||
+      (bias && bias_rows < 1) || lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) ||
+      (k2 > 0 && mis16(a2)) || mis16(w_planes))
     return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: bad argument (k%32, n%64, 16-byte alignment)");
-  GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, w, n, bias, bias ? bias_rows : 1, s, ns, ws, act, slope,
-                  c, ldc, m};
-  const int64_t gm = (m + SBM - 1) / SBM;
-  if (gm > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: m too large");
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)gm, (unsigned)(n / SBN)), dim3(256), 0,
-                     (hipStream_t)stream, g);
-  return launch_status("desco_gemm_bf16x6_f32");
+  GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w_planes), n, bias,
+                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m};
+  if (n % 192 == 0) return launch_gemm_split<3>(g, (hipStream_t)stream);
+  if (n % 128 == 0) return launch_gemm_split<2>(g, (hipStream_t)stream);
+  return launch_gemm_split<1>(g, (hipStream_t)stream);
+}
+
+extern "C" int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes,
+                                      desco_stream_t stream) {
+  using namespace desco;
+  if (count == 0) return 0;
+  if (count < 0 || !w || !planes)
+    return fail(DESCO_EINVAL, "desco_split_bf16x3_f32: bad argument");
+  const int64_t blocks = (count + 255) / 256;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_split_bf16x3_f32: count too large");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     w, count, reinterpret_cast<short*>(planes));
+  return launch_status("desco_split_bf16x3_f32");
 }

@@ -251,7 +251,8 @@ def _lin_t(lin: nn.Linear):
     return lin.weight.t().contiguous(), lin.bias.contiguous()
 
 
-def pack_shmp(gnn: BaseGNN) -> dict:
+def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
+    """bf16_planes: also emit the pre-split weight planes of the bf16x6 GEMMs (inference only)."""
     core = gnn.gnn_core
     pk = {"pre": {}, "layers": []}
     for t in core.node_types:
@@ -275,14 +276,17 @@ def pack_shmp(gnn: BaseGNN) -> dict:
                 # per row; apply them from a pre-transformed table (K 320 -> 192)
                 entry["wt_mfma"] = torch.cat([blocks[0], blocks[1], blocks[4]], 0).contiguous()
                 entry["wt_tab"] = torch.cat([blocks[2], blocks[3]], 1).contiguous()      # [64,128]
-                entry["wt_tab_nk"] = entry["wt_tab"].t().contiguous()                     # [128,64]
+                if bf16_planes and GEMM_BF16X6:
+                    entry["wt_tab_nk"] = ops.split_bf16_planes(entry["wt_tab"].t())    # [3,128,64]
             per_type[t] = entry
         pk["layers"].append(per_type)
     pk["anchor"] = _lin_t(gnn.anchor_mlp[0])
     pk["post"] = [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]
-    # n-major ([out, in]) operands of the bf16x6 GEMM
-    pk["anchor_nk"] = (gnn.anchor_mlp[0].weight.contiguous(), gnn.anchor_mlp[0].bias.contiguous())
-    pk["post_nk"] = [(gnn.post_mp[i].weight.contiguous(), gnn.post_mp[i].bias.contiguous())
+    if not (bf16_planes and GEMM_BF16X6):
+        return pk
+    # n-major ([out, in]) pre-split operands of the bf16x6 GEMM
+    pk["anchor_nk"] = (ops.split_bf16_planes(gnn.anchor_mlp[0].weight), gnn.anchor_mlp[0].bias.contiguous())
+    pk["post_nk"] = [(ops.split_bf16_planes(gnn.post_mp[i].weight), gnn.post_mp[i].bias.contiguous())
                      for i in (0, 3, 5, 7)]
     return pk
 
@@ -397,7 +401,7 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     """Differentiable twin of ``shmp_forward`` (same math, un-fused kernels, autograd Functions from
     desco_amd.autograd; every forward and backward op is a C-ABI kernel launch)."""
     from . import autograd as AG
-    pk = pack_shmp(gnn)                      # differentiable folding: grads reach the raw parameters
+    pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
     core = gnn.gnn_core
     dev = batch.vrowptr.device
     N, S = batch.num_rows, batch.slots
@@ -443,7 +447,7 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
 # -------------------------------------------------------------------------------------------------
 # gossip path
 # -------------------------------------------------------------------------------------------------
-def pack_gossip(gnn: BaseGNN) -> dict:
+def pack_gossip(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     core = gnn.gnn_core
     if core.layer_num != 2 or not core.input_pattern_emb or core.input_dim != 1:
         raise NotImplementedError(
@@ -470,7 +474,8 @@ def pack_gossip(gnn: BaseGNN) -> dict:
     pk["fused_wp"] = pk["wtp"].t().contiguous()                 # [64,128]
     pk["fused_w3"] = gnn.post_mp[3].weight.contiguous()         # [64,64]  (already [out, in])
     pk["fused_w5"] = gnn.post_mp[5].weight.contiguous()         # [256,64]
-    pk["fused_w5s"] = ops.split_bf16_planes(pk["fused_w5"])     # [3,256,64] bf16 planes (bf16x6)
+    if bf16_planes:
+        pk["fused_w5s"] = ops.split_bf16_planes(pk["fused_w5"])  # [3,256,64] bf16 planes (bf16x6)
     pk["qcache"] = None
     return pk
 

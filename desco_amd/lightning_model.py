@@ -165,7 +165,7 @@ class NeighborhoodCountingModel(_LightningLike):
                 W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
                 self._head_cache = (ver, {
                     "wt_t": W1[:, :H].t().contiguous(), "wt_q": W1[:, H:].t().contiguous(),
-                    "w_t_nk": W1[:, :H].contiguous(), "w_q_nk": W1[:, H:].contiguous(),
+                    "w_t_nk": ops.split_bf16_planes(W1[:, :H]), "w_q_nk": ops.split_bf16_planes(W1[:, H:]),
                     "b1": b1.contiguous(), "w2": self.count_model[2].weight[0].contiguous(),
                     "b2": float(self.count_model[2].bias[0])})
         return self._head_cache[1]

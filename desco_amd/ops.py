@@ -23,6 +23,7 @@ class LaunchProfiler:
 
     def __init__(self):
         self.enabled = False
+        self.by_shape = False  # tools: key GEMM launches by shape as well ("kernel[m x k x n]")
         self.records = []      # (kernel, flops, bytes, start_event, end_event)
 
     def reset(self):
@@ -46,7 +47,9 @@ PROFILER = LaunchProfiler()
 class _Timed:
     __slots__ = ("name", "flops", "bytes", "e0")
 
-    def __init__(self, name, flops=0.0, nbytes=0.0):
+    def __init__(self, name, flops=0.0, nbytes=0.0, shape=None):
+        if shape is not None and PROFILER.by_shape:
+            name = f"{name}[{'x'.join(str(v) for v in shape)}]"
         self.name, self.flops, self.bytes = name, flops, nbytes
 
     def __enter__(self):
@@ -148,7 +151,8 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
         ns = s.shape[1]
     L = _lib.lib()
     kk = k1 + k2
-    with _Timed("gemm_f32_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n + m * ns)):
+    with _Timed("gemm_f32_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n + m * ns),
+                (m, kk, n)):
         _lib.check(L.desco_gemm_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(wt, "wt"), n,
                                     _opt(bias, "bias"), bias_rows, _opt(s, "s"), ns,
                                     _opt(ws, "ws"), act, slope, op, ldo, m, _stream()), "gemm")
@@ -201,11 +205,14 @@ def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act([a1 | a2] @ w.T + bias) with fp32-level accuracy on the bf16 matrix pipe (bf16x6).
-    ``w`` is N-MAJOR: [n, k1+k2] (torch's [out, in])."""
+    ``w`` is the pre-split N-MAJOR weight: ``split_bf16_planes(weight)`` of torch's [n, k1+k2]
+    (a float weight is accepted and split on the fly, for tests)."""
+    if w.dtype != torch.int16:
+        w = split_bf16_planes(w)
     m, k1 = a1.shape
     k2 = 0 if a2 is None else a2.shape[1]
-    n = w.shape[0]
-    assert w.shape[1] == k1 + k2 and w.is_contiguous()
+    n = w.shape[1]
+    assert w.dim() == 3 and w.shape[0] == 3 and w.shape[2] == k1 + k2 and w.is_contiguous()
     if out is None:
         out = torch.empty((m, n), device=a1.device, dtype=torch.float32)
     a1p, lda1 = _rows(a1, "a1")
@@ -217,8 +224,8 @@ def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         bias_rows = 1 if bias.dim() == 1 else bias.shape[0]
     L = _lib.lib()
     kk = k1 + k2
-    with _Timed("gemm_split_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n)):
-        _lib.check(L.desco_gemm_bf16x6_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(w, "w"), n,
+    with _Timed("gemm_split_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n), (m, kk, n)):
+        _lib.check(L.desco_gemm_bf16x6_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(w, "w", torch.int16), n,
                                            _opt(bias, "bias"), bias_rows, None, 0, None, act, slope,
                                            op, ldo, m, _stream()), "gemm_split")
     return out
@@ -307,17 +314,14 @@ def gossip_gather(h: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_
 
 
 def split_bf16_planes(w: torch.Tensor) -> torch.Tensor:
-    """[3, *w.shape] int16: the truncation split w = hi + mid + lo into bf16 bit patterns (operand
-    format of the bf16x6 kernels; plumbing on a weight tensor, done once per weight version)."""
-    w = w.contiguous().float()
-    mask = -65536          # 0xffff0000 as int32
-    hi = torch.bitwise_and(w.view(torch.int32), mask)
-    r1 = w - hi.view(torch.float32)
-    mid = torch.bitwise_and(r1.view(torch.int32), mask)
-    r2 = r1 - mid.view(torch.float32)
-    lo = torch.bitwise_and(r2.view(torch.int32), mask)
-    planes = torch.stack([hi, mid, lo]) >> 16
-    return planes.to(torch.int16).contiguous()
+    """[3, *w.shape] int16: the truncation split w = hi + mid + lo into bf16 bit patterns -- the
+    weight operand format of the bf16x6 kernels (one launch per weight version)."""
+    w = w.contiguous()
+    planes = torch.empty((3,) + tuple(w.shape), device=w.device, dtype=torch.int16)
+    L = _lib.lib()
+    _lib.check(L.desco_split_bf16x3_f32(_dev(w, "w"), w.numel(), _dev(planes, "planes", torch.int16),
+                                        _stream()), "split_bf16x3")
+    return planes
 
 
 def gossip_scalars(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0, g1) -> torch.Tensor:

@@ -121,12 +121,14 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
 
 /* Same contract as desco_gemm_f32 but computed on the bf16 matrix pipe with fp32-level accuracy
  * ("bf16x6": each fp32 operand is split into three bf16 terms, the six products of weight >= 2^-16
- * are accumulated in fp32; error ~2^-23 per product).  The weight is passed N-MAJOR:
- * w[n][k1+k2] row major (torch's native [out, in] layout), not transposed. */
+ * are accumulated in fp32; error ~2^-23 per product).  The weight is passed N-MAJOR and already
+ * split: w_planes[3][n][k1+k2] = (hi, mid, lo) bf16 bit patterns of torch's native [out, in] weight,
+ * produced once per weight version by desco_split_bf16x3_f32 (planes[3][count] of w[count]). */
 int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2,
-                          int k2, const float* w, int n, const float* bias, int bias_rows,
+                          int k2, const int16_t* w_planes, int n, const float* bias, int bias_rows,
                           const float* s, int ns, const float* ws, int act, float slope, float* c,
                           int64_t ldc, int64_t m, desco_stream_t stream);
+int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco_stream_t stream);
 
 /* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip).  For destination rows i in
  * [row0, row0+num_rows), with sm = slots_mfma <= 3, st = slots_table <= 2, S = slots_stored (sm+st <= S <= 4):

@@ -230,7 +230,8 @@ def test_degree_affine():
     assert (out[:row0] == -3.0).all()
 
 
-@pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (129, 128, 64, 64), (1000, 576, 0, 576), (4097, 64, 0, 256)])
+@pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (129, 128, 64, 64), (1000, 576, 0, 576), (4097, 64, 0, 256),
+                                       (1153, 64, 32, 192), (2049, 96, 0, 384), (900, 64, 0, 128), (131, 32, 0, 320)])
 def test_gemm_bf16x6_is_fp32_accurate(m, k1, k2, n):
     g = torch.Generator().manual_seed(m + n)
     a1 = torch.randn(m, k1, generator=g) * torch.rand(m, 1, generator=g) * 30

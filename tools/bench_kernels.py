@@ -38,7 +38,7 @@ def gemm_case(m, k1, k2, n, lda1=None, check=False):
     fl = 2.0 * m * (k1 + k2) * n
     by = 4.0 * (m * (k1 + k2) + m * n)
     msg = f"gemm m={m} k={k1}+{k2} n={n}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s  {by / ms / 1e6:.0f} GB/s"
-    w_nk = wt.t().contiguous()
+    w_nk = ops.split_bf16_planes(wt.t().contiguous())
     ms2 = timeit(lambda: ops.gemm_split(a1, w_nk, b, a2=a2, act=ops.ACT_RELU, out=out))
     msg += f" | bf16x6: {ms2:.3f} ms {fl / ms2 / 1e9:.1f} TF/s(fp32-equiv)"
     if check:
