@@ -33,7 +33,7 @@
 namespace desco {
 
 constexpr int WR = 32;        // rows per wave
-constexpr int NW = 12;        // waves per block (3 per SIMD: <= 168 VGPRs each)
+constexpr int NW = 8;         // waves per block (2 per SIMD: <= 256 VGPRs each)
 constexpr int AH = 33;        // half-K A image row stride (floats): conflict-free ds_read_b32
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
@@ -143,103 +143,224 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
         acc1[i] = bv1;
       }
     }
-#pragma unroll 1
-    for (int kh = 0; kh < 2 * KB + (ST > 0 ? 2 : 0); ++kh) {
-      const int kb = kh >> 1, h = kh & 1;
-      const bool is_tab = ST > 0 && kb == KB;      // table pseudo block: gather ytab rows, add in C layout
-      // ---- gather half h (columns 32h..32h+31) of K block kb: slot kb, or the row itself -----
-      // lane group g8 serves rows it*8 + g8 (it = 0..3), 4 floats at column 32h + 4*l8
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-      const float* xb = g.x + 32 * h + 4 * l8;
-      if (is_tab) {
-        // sources of the table slots sm .. sm+ST-1 (already multiplied by their weight block)
-        const float* yb = g.ytab + 32 * h + 4 * l8 - g.ytab_row0 * g.ldy;
-#pragma unroll
-        for (int ts = 0; ts < ST; ++ts) {
-          int c0, c1, c2, c3, n0, n1, n2, n3;
-#define DESCO_CUR(c_, n_, it_)                          \
-  {                                                     \
-    const int v_ = ((it_) * 8 + g8) * S + g.sm + ts;    \
-    c_ = rp[v_] - ebase;                                \
-    n_ = rp[v_ + 1] - ebase;                            \
+    // K blocks: b < KB-1 = relation slot b (gathered x rows), b == KB-1 = the row itself,
+    // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout).
+    // Lane group g8 serves rows it*8 + g8 (it = 0..3); per row BOTH 128-B halves are fetched
+    // together (columns 4*l8 and 32 + 4*l8).  All loads of a step are unconditional -- absent
+    // sources read a dummy row and are discarded -- so the 16 loads of a step are in flight
+    // together (a conditional load is fenced by its own s_waitcnt), and the first step of block
+    // b+1 is issued BEFORE the MFMAs of block b.
+    constexpr int NB = KB + (ST > 0 ? 1 : 0);
+    const float* xb = g.x + 4 * l8;
+    const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * g.ldy : nullptr;
+    float4 lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;           // gathered sums of the current block
+    float4 u00, u01, u10, u11, u20, u21, u30, u31;           // in flight: first source (lo, hi) of row it
+    float4 w00, w01, w10, w11, w20, w21, w30, w31;           // in flight: second source
+    int c0, c1, c2, c3, n0, n1, n2, n3;                      // source cursors [c, n) relative to ebase
+#define DESCO_CUR(it_, slot_)                              \
+  {                                                        \
+    const int v_ = ((it_) * 8 + g8) * S + (slot_);         \
+    c##it_ = rp[v_] - ebase;                               \
+    n##it_ = rp[v_ + 1] - ebase;                           \
   }
-          DESCO_CUR(c0, n0, 0) DESCO_CUR(c1, n1, 1) DESCO_CUR(c2, n2, 2) DESCO_CUR(c3, n3, 3)
-#undef DESCO_CUR
-          while (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
-#define DESCO_STEP(av_, c_, n_)                                                          \
-  if (c_ < n_) {                                                                         \
-    const int64_t j_ = c_ < WCAP ? ec[c_] : g.vcol[ebase + c_];                          \
-    f4add(av_, *reinterpret_cast<const float4*>(yb + j_ * g.ldy + ts * 64));             \
-    ++c_;                                                                                \
+#define DESCO_CURS(slot_) DESCO_CUR(0, slot_) DESCO_CUR(1, slot_) DESCO_CUR(2, slot_) DESCO_CUR(3, slot_)
+  // two sources of row it_ (staged ids only: e < WCAP), unconditional loads
+#define DESCO_ISSUE2(it_, base_, ld_, dummy_)                                         \
+  {                                                                                   \
+    const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
+    const bool k0_ = c##it_ < m_, k1_ = c##it_ + 1 < m_;                              \
+    const int i0_ = ec[k0_ ? c##it_ : 0], i1_ = ec[k1_ ? c##it_ + 1 : 0];             \
+    const float* p0_ = (base_) + (k0_ ? (int64_t)i0_ : (int64_t)(dummy_)) * (ld_);    \
+    const float* p1_ = (base_) + (k1_ ? (int64_t)i1_ : (int64_t)(dummy_)) * (ld_);    \
+    u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                \
+    u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                           \
+    w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                \
+    w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                           \
   }
-            DESCO_STEP(a0, c0, n0) DESCO_STEP(a1, c1, n1) DESCO_STEP(a2, c2, n2)
-            DESCO_STEP(a3, c3, n3)
-#undef DESCO_STEP
-          }
-        }
-      } else if (kb == KB - 1) {
-        // rows beyond nr re-read the wave's last valid row (never stored)
-#define DESCO_SELF(av_, it_)                                                                   \
+#define DESCO_CONSUME2(it_)                                                           \
+  {                                                                                   \
+    const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
+    const bool k0_ = c##it_ < m_, k1_ = c##it_ + 1 < m_;                              \
+    const float s0_ = k0_ ? 1.f : 0.f, s1_ = k1_ ? 1.f : 0.f;                         \
+    DESCO_FMA4(lo##it_, u##it_##0, k0_) DESCO_FMA4(hi##it_, u##it_##1, k0_)           \
+    DESCO_FMA4(lo##it_, w##it_##0, k1_) DESCO_FMA4(hi##it_, w##it_##1, k1_)           \
+    (void)s0_; (void)s1_;                                                             \
+    c##it_ += (k0_ ? 1 : 0) + (k1_ ? 1 : 0);                                          \
+  }
+#define DESCO_FMA4(a_, v_, k_)          \
+  {                                     \
+    a_.x += (k_) ? v_.x : 0.f;          \
+    a_.y += (k_) ? v_.y : 0.f;          \
+    a_.z += (k_) ? v_.z : 0.f;          \
+    a_.w += (k_) ? v_.w : 0.f;          \
+  }
+#define DESCO_ZERO_SUMS()                                   \
+  {                                                         \
+    lo0 = make_float4(0.f, 0.f, 0.f, 0.f);                  \
+    lo1 = lo0; lo2 = lo0; lo3 = lo0;                        \
+    hi0 = lo0; hi1 = lo0; hi2 = lo0; hi3 = lo0;             \
+  }
+#define DESCO_ANY_STAGED()                                                                    \
+  __any((c0 < (n0 < WCAP ? n0 : WCAP)) | (c1 < (n1 < WCAP ? n1 : WCAP)) |                     \
+        (c2 < (n2 < WCAP ? n2 : WCAP)) | (c3 < (n3 < WCAP ? n3 : WCAP)))
+  // the row itself: rows beyond nr re-read the wave's last valid row (never stored)
+#define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
-    av_ = *reinterpret_cast<const float4*>(xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * g.ldx);    \
+    const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * g.ldx;                          \
+    u##it_##0 = *reinterpret_cast<const float4*>(p_);                                          \
+    u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                                     \
   }
-        DESCO_SELF(a0, 0) DESCO_SELF(a1, 1) DESCO_SELF(a2, 2) DESCO_SELF(a3, 3)
-#undef DESCO_SELF
+  // table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
+#define DESCO_TAB_CUR(it_)                                                                  \
+  const int v_ = ((it_) * 8 + g8) * S + g.sm;                                               \
+  const int ca_ = rp[v_] - ebase, na_ = rp[v_ + 1] - ebase;                                 \
+  const int nb_ = ST > 1 ? rp[v_ + 2] - ebase : na_;                                        \
+  const bool k0_ = ca_ < (na_ < WCAP ? na_ : WCAP);                                         \
+  const bool k1_ = ST > 1 && na_ < (nb_ < WCAP ? nb_ : WCAP);
+#define DESCO_ISSUE_TAB(it_)                                                                \
+  {                                                                                         \
+    DESCO_TAB_CUR(it_)                                                                      \
+    const int i0_ = ec[k0_ ? ca_ : 0], i1_ = ec[k1_ ? na_ : 0];                             \
+    const float* p0_ = yb + (k0_ ? (int64_t)i0_ : g.ytab_row0) * g.ldy;                     \
+    u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                      \
+    u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                                 \
+    if (ST > 1) {                                                                           \
+      const float* p1_ = yb + 64 + (k1_ ? (int64_t)i1_ : g.ytab_row0) * g.ldy;              \
+      w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                    \
+      w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
+    }                                                                                       \
+  }
+  // consume the step; leave the cursor of table slot 0 in (c, n) and of slot 1 in (d, m)
+#define DESCO_CONSUME_TAB(it_)                                                              \
+  {                                                                                         \
+    DESCO_TAB_CUR(it_)                                                                      \
+    DESCO_FMA4(lo##it_, u##it_##0, k0_) DESCO_FMA4(hi##it_, u##it_##1, k0_)                 \
+    if (ST > 1) { DESCO_FMA4(lo##it_, w##it_##0, k1_) DESCO_FMA4(hi##it_, w##it_##1, k1_) } \
+    c##it_ = ca_ + (k0_ ? 1 : 0);                                                           \
+    n##it_ = na_;                                                                           \
+    d##it_ = na_ + (k1_ ? 1 : 0);                                                           \
+    m##it_ = nb_;                                                                           \
+  }
+  // heavy rows (hub / canonical rows of dense neighborhoods, or ids beyond the staged WCAP): the
+  // whole wave cooperates on one row at a time -- lane group k takes sources c+k, c+k+8, ... and
+  // the 8 partial sums are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
+#define DESCO_COOP(it_, base_, ld_)                                                       \
+  {                                                                                       \
+    unsigned long long m_ = __ballot(c##it_ < n##it_);                                    \
+    while (m_) {                                                                          \
+      const int sl_ = __builtin_ctzll(m_);                                                \
+      const int og_ = sl_ >> 3;                                                           \
+      const int cc_ = __shfl(c##it_, sl_, 64), nn_ = __shfl(n##it_, sl_, 64);             \
+      float4 p_ = make_float4(0.f, 0.f, 0.f, 0.f), q_ = p_;                               \
+      for (int e_ = cc_ + g8; e_ < nn_; e_ += 8) {                                        \
+        const int64_t j_ = e_ < WCAP ? ec[e_] : g.vcol[ebase + e_];                       \
+        const float* s_ = (base_) + j_ * (ld_);                                           \
+        const float4 v0_ = *reinterpret_cast<const float4*>(s_);                          \
+        const float4 v1_ = *reinterpret_cast<const float4*>(s_ + 32);                     \
+        f4add(p_, v0_);                                                                   \
+        f4add(q_, v1_);                                                                   \
+      }                                                                                   \
+      _Pragma("unroll") for (int o_ = 8; o_ < 64; o_ <<= 1) {                             \
+        p_.x += __shfl_xor(p_.x, o_, 64);                                                 \
+        p_.y += __shfl_xor(p_.y, o_, 64);                                                 \
+        p_.z += __shfl_xor(p_.z, o_, 64);                                                 \
+        p_.w += __shfl_xor(p_.w, o_, 64);                                                 \
+        q_.x += __shfl_xor(q_.x, o_, 64);                                                 \
+        q_.y += __shfl_xor(q_.y, o_, 64);                                                 \
+        q_.z += __shfl_xor(q_.z, o_, 64);                                                 \
+        q_.w += __shfl_xor(q_.w, o_, 64);                                                 \
+      }                                                                                   \
+      if (g8 == og_) {                                                                    \
+        f4add(lo##it_, p_);                                                               \
+        f4add(hi##it_, q_);                                                               \
+        c##it_ = n##it_;                                                                  \
+      }                                                                                   \
+      m_ &= ~(0xffULL << (og_ * 8));                                                      \
+    }                                                                                     \
+  }
+  // finish a gathered block whose first step is already in flight: consume it, one more batched
+  // step for rows with 3-4 sources, then the cooperative path for what is left
+#define DESCO_FINISH(base_, ld_, dummy_)                                                   \
+  {                                                                                        \
+    DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)                \
+    if (DESCO_ANY_STAGED()) {                                                              \
+      DESCO_ISSUE2(0, base_, ld_, dummy_) DESCO_ISSUE2(1, base_, ld_, dummy_)              \
+      DESCO_ISSUE2(2, base_, ld_, dummy_) DESCO_ISSUE2(3, base_, ld_, dummy_)              \
+      DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)              \
+    }                                                                                      \
+    if (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {                            \
+      DESCO_COOP(0, base_, ld_) DESCO_COOP(1, base_, ld_) DESCO_COOP(2, base_, ld_)        \
+      DESCO_COOP(3, base_, ld_)                                                            \
+    }                                                                                      \
+  }
+  // first step of block b_ (cursors + loads); nothing waits on the loads here
+#define DESCO_ISSUE_BLOCK(b_)                                                              \
+  {                                                                                        \
+    if ((b_) < KB - 1) {                                                                   \
+      DESCO_CURS(b_)                                                                       \
+      DESCO_ISSUE2(0, xb, g.ldx, grow0) DESCO_ISSUE2(1, xb, g.ldx, grow0)                  \
+      DESCO_ISSUE2(2, xb, g.ldx, grow0) DESCO_ISSUE2(3, xb, g.ldx, grow0)                  \
+    } else if ((b_) == KB - 1) {                                                           \
+      DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1) DESCO_ISSUE_SELF(2) DESCO_ISSUE_SELF(3)      \
+    } else {                                                                               \
+      DESCO_ISSUE_TAB(0) DESCO_ISSUE_TAB(1) DESCO_ISSUE_TAB(2) DESCO_ISSUE_TAB(3)          \
+    }                                                                                      \
+  }
+  // write one half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
+#define DESCO_PUT(av_, it_)                             \
+  {                                                     \
+    float* d_ = Aw + ((it_) * 8 + g8) * AH + 4 * l8;    \
+    d_[0] = av_.x;                                      \
+    d_[1] = av_.y;                                      \
+    d_[2] = av_.z;                                      \
+    d_[3] = av_.w;                                      \
+  }
+  // 32 MFMAs on the staged half h_ of K block b_: A[i = lane&31][k = lane>>5], B[k][j = lane&31]
+#define DESCO_MFMA_HALF(b_, h_)                                                            \
+  {                                                                                        \
+    const float* as_ = Aw + (lane & 31) * AH + (lane >> 5);                                \
+    const float* bs_ = Bimg + ((b_) * 64 + (h_) * 32 + (lane >> 5)) * 64 + (lane & 31);    \
+    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk) {                                    \
+      const float a_ = as_[2 * kk];                                                        \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bs_[2 * kk * 64], acc0, 0, 0, 0);    \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bs_[2 * kk * 64 + 32], acc1, 0, 0, 0); \
+    }                                                                                      \
+  }
+  // add the staged table half rows in the C/D layout: acc[reg] += stage[row(reg)][lane&31]
+#define DESCO_TAB_HALF(acc_)                                                               \
+  {                                                                                        \
+    _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)                                   \
+        acc_[reg] += Aw[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * AH + cl];         \
+  }
+
+    DESCO_ISSUE_BLOCK(0)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      // ---- complete the gather of block b ------------------------------------------------------
+      DESCO_ZERO_SUMS()
+      if (b < KB - 1) {
+        DESCO_FINISH(xb, g.ldx, grow0)
+      } else if (b == KB - 1) {
+        lo0 = u00; hi0 = u01; lo1 = u10; hi1 = u11;
+        lo2 = u20; hi2 = u21; lo3 = u30; hi3 = u31;
       } else {
-        int c0, c1, c2, c3, n0, n1, n2, n3;
-#define DESCO_CUR(c_, n_, it_)                        \
-  {                                                   \
-    const int v_ = ((it_) * 8 + g8) * S + kb;         \
-    c_ = rp[v_] - ebase;                              \
-    n_ = rp[v_ + 1] - ebase;                          \
-  }
-        DESCO_CUR(c0, n0, 0) DESCO_CUR(c1, n1, 1) DESCO_CUR(c2, n2, 2) DESCO_CUR(c3, n3, 3)
-#undef DESCO_CUR
-        // rows with few sources: one source per row and pass, 4 rows per lane group in flight
-        for (int pass = 0; pass < 4 && __any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3)); ++pass) {
-#define DESCO_STEP(av_, c_, n_)                                                          \
-  if (c_ < n_) {                                                                         \
-    const int64_t j_ = c_ < WCAP ? ec[c_] : g.vcol[ebase + c_];                          \
-    f4add(av_, *reinterpret_cast<const float4*>(xb + j_ * g.ldx));                       \
-    ++c_;                                                                                \
-  }
-          DESCO_STEP(a0, c0, n0) DESCO_STEP(a1, c1, n1) DESCO_STEP(a2, c2, n2)
-          DESCO_STEP(a3, c3, n3)
-#undef DESCO_STEP
+        // canonical->count relations have at most one source per row: one step covers both table
+        // slots; anything beyond that (general inputs) takes the cooperative path
+        int d0, d1, d2, d3, m0, m1, m2, m3;
+        DESCO_CONSUME_TAB(0) DESCO_CONSUME_TAB(1) DESCO_CONSUME_TAB(2) DESCO_CONSUME_TAB(3)
+        if (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
+          DESCO_COOP(0, yb, g.ldy) DESCO_COOP(1, yb, g.ldy) DESCO_COOP(2, yb, g.ldy)
+          DESCO_COOP(3, yb, g.ldy)
         }
-        // heavy rows (hub / canonical rows of dense neighborhoods): the whole wave cooperates on
-        // one row at a time -- lane group k takes sources c+k, c+k+8, ... and the 8 partial sums
-        // are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
-#define DESCO_COOP(av_, c_, n_)                                                          \
-  {                                                                                      \
-    unsigned long long m_ = __ballot(c_ < n_);                                           \
-    while (m_) {                                                                         \
-      const int sl_ = __builtin_ctzll(m_);                                               \
-      const int og_ = sl_ >> 3;                                                          \
-      const int cc_ = __shfl(c_, sl_, 64), nn_ = __shfl(n_, sl_, 64);                    \
-      float4 p_ = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
-      for (int e_ = cc_ + g8; e_ < nn_; e_ += 8) {                                       \
-        const int64_t j_ = e_ < WCAP ? ec[e_] : g.vcol[ebase + e_];                      \
-        f4add(p_, *reinterpret_cast<const float4*>(xb + j_ * g.ldx));                    \
-      }                                                                                  \
-      _Pragma("unroll") for (int o_ = 8; o_ < 64; o_ <<= 1) {                            \
-        p_.x += __shfl_xor(p_.x, o_, 64);                                                \
-        p_.y += __shfl_xor(p_.y, o_, 64);                                                \
-        p_.z += __shfl_xor(p_.z, o_, 64);                                                \
-        p_.w += __shfl_xor(p_.w, o_, 64);                                                \
-      }                                                                                  \
-      if (g8 == og_) {                                                                   \
-        f4add(av_, p_);                                                                  \
-        c_ = n_;                                                                         \
-      }                                                                                  \
-      m_ &= ~(0xffULL << (og_ * 8));                                                     \
-    }                                                                                    \
-  }
-        DESCO_COOP(a0, c0, n0) DESCO_COOP(a1, c1, n1) DESCO_COOP(a2, c2, n2) DESCO_COOP(a3, c3, n3)
-#undef DESCO_COOP
+        if (ST > 1 && __any((d0 < m0) | (d1 < m1) | (d2 < m2) | (d3 < m3))) {
+          c0 = d0; c1 = d1; c2 = d2; c3 = d3;
+          n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+          DESCO_COOP(0, yb + 64, g.ldy) DESCO_COOP(1, yb + 64, g.ldy) DESCO_COOP(2, yb + 64, g.ldy)
+          DESCO_COOP(3, yb + 64, g.ldy)
+        }
       }
-      if (kh == 0 && has_next) {
+      if (b == 0 && has_next) {
         // next tile's row pointers have landed: publish them, then fetch its source ids
         rpn[lane] = p0;
         if (lane + 64 < nslot) rpn[lane + 64] = p1;
@@ -249,39 +370,31 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
         if (lane < ecntn) qn0 = g.vcol[ebn + lane];
         if (lane + 64 < ecntn) qn1 = g.vcol[ebn + lane + 64];
       }
-      // ---- write the half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8) --------
-#define DESCO_PUT(av_, it_)                             \
-  {                                                     \
-    float* d_ = Aw + ((it_) * 8 + g8) * AH + 4 * l8;    \
-    d_[0] = av_.x;                                      \
-    d_[1] = av_.y;                                      \
-    d_[2] = av_.z;                                      \
-    d_[3] = av_.w;                                      \
-  }
-      DESCO_PUT(a0, 0) DESCO_PUT(a1, 1) DESCO_PUT(a2, 2) DESCO_PUT(a3, 3)
-#undef DESCO_PUT
-      if (is_tab) {
-        // add the staged table half rows in the C/D layout: acc_h[reg] += stage[row(reg)][lane&31]
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float v = Aw[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * AH + cl];
-          if (h == 0)
-            acc0[reg] += v;
-          else
-            acc1[reg] += v;
-        }
-      } else {
-        // 32 MFMAs: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
-        const float* as = Aw + (lane & 31) * AH + (lane >> 5);
-        const float* bs = Bimg + (kb * 64 + h * 32 + (lane >> 5)) * 64 + (lane & 31);
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const float a = as[2 * kk];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[2 * kk * 64], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[2 * kk * 64 + 32], acc1, 0, 0, 0);
-        }
-      }
+      // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
+      //      under this block's MFMAs (after the low halves have left their registers)
+      DESCO_PUT(lo0, 0) DESCO_PUT(lo1, 1) DESCO_PUT(lo2, 2) DESCO_PUT(lo3, 3)
+      if (b + 1 < NB) DESCO_ISSUE_BLOCK(b + 1)
+      if (b < KB) DESCO_MFMA_HALF(b, 0) else DESCO_TAB_HALF(acc0)
+      DESCO_PUT(hi0, 0) DESCO_PUT(hi1, 1) DESCO_PUT(hi2, 2) DESCO_PUT(hi3, 3)
+      if (b < KB) DESCO_MFMA_HALF(b, 1) else DESCO_TAB_HALF(acc1)
     }
+#undef DESCO_CUR
+#undef DESCO_CURS
+#undef DESCO_ISSUE2
+#undef DESCO_CONSUME2
+#undef DESCO_FMA4
+#undef DESCO_ZERO_SUMS
+#undef DESCO_ANY_STAGED
+#undef DESCO_ISSUE_SELF
+#undef DESCO_TAB_CUR
+#undef DESCO_ISSUE_TAB
+#undef DESCO_CONSUME_TAB
+#undef DESCO_COOP
+#undef DESCO_FINISH
+#undef DESCO_ISSUE_BLOCK
+#undef DESCO_PUT
+#undef DESCO_MFMA_HALF
+#undef DESCO_TAB_HALF
 
     if (has_next) {   // publish the next tile's source ids
       if (lane < ecntn) ecn[lane] = qn0;

@@ -68,7 +68,9 @@ def test_neighborhood_batch_slicing_equals_full(setup):
     full = nm.graph_to_count(NeighborhoodBatch(part, DEV))
     parts = [nm.graph_to_count(NeighborhoodBatch(part.slice(b0, b0 + 100), DEV))
              for b0 in range(0, part.num_neigh, 100)]
-    torch.testing.assert_close(torch.cat(parts), full, rtol=1e-5, atol=1e-5)
+    # the in-tile summation order of a row depends on where its source ids fall in the staged id
+    # window, so slices agree to fp32 rounding (amplified by 2**logit), not bit for bit
+    torch.testing.assert_close(torch.cat(parts), full, rtol=1e-4, atol=1e-4)
 
 
 def test_gossip_vs_oracle(setup):
