@@ -40,6 +40,9 @@ constexpr int RPN = WR * MAXS + 1;
 constexpr int WCAP = 128;     // source ids staged per wave (longer slices fall back to global)
 constexpr int WAVE_LDS = WR * AH + 2 * RPN + 2 * WCAP;   // floats per wave
 
+// absent sources of a batched gather step read this row instead of being predicated away
+__device__ __attribute__((aligned(16))) float shmp_zero_row[64];
+
 struct ShmpArgs {
   const float* x;
   int64_t ldx;
@@ -147,12 +150,13 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout).
     // Lane group g8 serves rows it*8 + g8 (it = 0..3); per row BOTH 128-B halves are fetched
     // together (columns 4*l8 and 32 + 4*l8).  All loads of a step are unconditional -- absent
-    // sources read a dummy row and are discarded -- so the 16 loads of a step are in flight
+    // sources read a row of zeros -- so the 16 loads of a step are in flight
     // together (a conditional load is fenced by its own s_waitcnt), and the first step of block
     // b+1 is issued BEFORE the MFMAs of block b.
     constexpr int NB = KB + (ST > 0 ? 1 : 0);
     const float* xb = g.x + 4 * l8;
     const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * g.ldy : nullptr;
+    const float* zrow = shmp_zero_row + 4 * l8;
     float4 lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;           // gathered sums of the current block
     float4 u00, u01, u10, u11, u20, u21, u30, u31;           // in flight: first source (lo, hi) of row it
     float4 w00, w01, w10, w11, w20, w21, w30, w31;           // in flight: second source
@@ -165,34 +169,25 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   }
 #define DESCO_CURS(slot_) DESCO_CUR(0, slot_) DESCO_CUR(1, slot_) DESCO_CUR(2, slot_) DESCO_CUR(3, slot_)
   // two sources of row it_ (staged ids only: e < WCAP), unconditional loads
-#define DESCO_ISSUE2(it_, base_, ld_, dummy_)                                         \
+#define DESCO_ISSUE2(it_, base_, ld_)                                                 \
   {                                                                                   \
     const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
     const bool k0_ = c##it_ < m_, k1_ = c##it_ + 1 < m_;                              \
     const int i0_ = ec[k0_ ? c##it_ : 0], i1_ = ec[k1_ ? c##it_ + 1 : 0];             \
-    const float* p0_ = (base_) + (k0_ ? (int64_t)i0_ : (int64_t)(dummy_)) * (ld_);    \
-    const float* p1_ = (base_) + (k1_ ? (int64_t)i1_ : (int64_t)(dummy_)) * (ld_);    \
+    const float* p0_ = k0_ ? (base_) + (int64_t)i0_ * (ld_) : zrow;                   \
+    const float* p1_ = k1_ ? (base_) + (int64_t)i1_ * (ld_) : zrow;                   \
     u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                \
     u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                           \
     w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                \
     w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                           \
+    c##it_ += (k0_ ? 1 : 0) + (k1_ ? 1 : 0);                                          \
   }
 #define DESCO_CONSUME2(it_)                                                           \
   {                                                                                   \
-    const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
-    const bool k0_ = c##it_ < m_, k1_ = c##it_ + 1 < m_;                              \
-    const float s0_ = k0_ ? 1.f : 0.f, s1_ = k1_ ? 1.f : 0.f;                         \
-    DESCO_FMA4(lo##it_, u##it_##0, k0_) DESCO_FMA4(hi##it_, u##it_##1, k0_)           \
-    DESCO_FMA4(lo##it_, w##it_##0, k1_) DESCO_FMA4(hi##it_, w##it_##1, k1_)           \
-    (void)s0_; (void)s1_;                                                             \
-    c##it_ += (k0_ ? 1 : 0) + (k1_ ? 1 : 0);                                          \
-  }
-#define DESCO_FMA4(a_, v_, k_)          \
-  {                                     \
-    a_.x += (k_) ? v_.x : 0.f;          \
-    a_.y += (k_) ? v_.y : 0.f;          \
-    a_.z += (k_) ? v_.z : 0.f;          \
-    a_.w += (k_) ? v_.w : 0.f;          \
+    f4add(lo##it_, u##it_##0);                                                        \
+    f4add(hi##it_, u##it_##1);                                                        \
+    f4add(lo##it_, w##it_##0);                                                        \
+    f4add(hi##it_, w##it_##1);                                                        \
   }
 #define DESCO_ZERO_SUMS()                                   \
   {                                                         \
@@ -222,11 +217,11 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
     const int i0_ = ec[k0_ ? ca_ : 0], i1_ = ec[k1_ ? na_ : 0];                             \
-    const float* p0_ = yb + (k0_ ? (int64_t)i0_ : g.ytab_row0) * g.ldy;                     \
+    const float* p0_ = k0_ ? yb + (int64_t)i0_ * g.ldy : zrow;                              \
     u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                      \
     u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                                 \
     if (ST > 1) {                                                                           \
-      const float* p1_ = yb + 64 + (k1_ ? (int64_t)i1_ : g.ytab_row0) * g.ldy;              \
+      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * g.ldy : zrow;                       \
       w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                    \
       w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
     }                                                                                       \
@@ -235,8 +230,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 #define DESCO_CONSUME_TAB(it_)                                                              \
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
-    DESCO_FMA4(lo##it_, u##it_##0, k0_) DESCO_FMA4(hi##it_, u##it_##1, k0_)                 \
-    if (ST > 1) { DESCO_FMA4(lo##it_, w##it_##0, k1_) DESCO_FMA4(hi##it_, w##it_##1, k1_) } \
+    f4add(lo##it_, u##it_##0);                                                              \
+    f4add(hi##it_, u##it_##1);                                                              \
+    if (ST > 1) {                                                                           \
+      f4add(lo##it_, w##it_##0);                                                            \
+      f4add(hi##it_, w##it_##1);                                                            \
+    }                                                                                       \
     c##it_ = ca_ + (k0_ ? 1 : 0);                                                           \
     n##it_ = na_;                                                                           \
     d##it_ = na_ + (k1_ ? 1 : 0);                                                           \
@@ -281,12 +280,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   }
   // finish a gathered block whose first step is already in flight: consume it, one more batched
   // step for rows with 3-4 sources, then the cooperative path for what is left
-#define DESCO_FINISH(base_, ld_, dummy_)                                                   \
+#define DESCO_FINISH(base_, ld_)                                                           \
   {                                                                                        \
     DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)                \
     if (DESCO_ANY_STAGED()) {                                                              \
-      DESCO_ISSUE2(0, base_, ld_, dummy_) DESCO_ISSUE2(1, base_, ld_, dummy_)              \
-      DESCO_ISSUE2(2, base_, ld_, dummy_) DESCO_ISSUE2(3, base_, ld_, dummy_)              \
+      DESCO_ISSUE2(0, base_, ld_) DESCO_ISSUE2(1, base_, ld_)                              \
+      DESCO_ISSUE2(2, base_, ld_) DESCO_ISSUE2(3, base_, ld_)                              \
       DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)              \
     }                                                                                      \
     if (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {                            \
@@ -299,8 +298,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   {                                                                                        \
     if ((b_) < KB - 1) {                                                                   \
       DESCO_CURS(b_)                                                                       \
-      DESCO_ISSUE2(0, xb, g.ldx, grow0) DESCO_ISSUE2(1, xb, g.ldx, grow0)                  \
-      DESCO_ISSUE2(2, xb, g.ldx, grow0) DESCO_ISSUE2(3, xb, g.ldx, grow0)                  \
+      DESCO_ISSUE2(0, xb, g.ldx) DESCO_ISSUE2(1, xb, g.ldx)                                \
+      DESCO_ISSUE2(2, xb, g.ldx) DESCO_ISSUE2(3, xb, g.ldx)                                \
     } else if ((b_) == KB - 1) {                                                           \
       DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1) DESCO_ISSUE_SELF(2) DESCO_ISSUE_SELF(3)      \
     } else {                                                                               \
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       // ---- complete the gather of block b ------------------------------------------------------
       DESCO_ZERO_SUMS()
       if (b < KB - 1) {
-        DESCO_FINISH(xb, g.ldx, grow0)
+        DESCO_FINISH(xb, g.ldx)
       } else if (b == KB - 1) {
         lo0 = u00; hi0 = u01; lo1 = u10; hi1 = u11;
         lo2 = u20; hi2 = u21; lo3 = u30; hi3 = u31;
@@ -382,7 +381,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 #undef DESCO_CURS
 #undef DESCO_ISSUE2
 #undef DESCO_CONSUME2
-#undef DESCO_FMA4
 #undef DESCO_ZERO_SUMS
 #undef DESCO_ANY_STAGED
 #undef DESCO_ISSUE_SELF
