@@ -11,34 +11,47 @@
 // the canonical->count relations (at most one source per row), cutting K from 320 to 192.
 //
 // Structure (wave-autonomous, persistent, software-pipelined):
-//   * block = 12 waves = one CU (3 waves per SIMD); all (sm+1) 64x64 weight blocks are loaded into
-//     LDS ONCE per block and stay resident while the block strides over 384-row tiles;
+//   * block = 8 waves = one CU (2 waves per SIMD, <= 256 VGPRs each); all (sm+1) 64x64 weight blocks
+//     are loaded into LDS ONCE per block and stay resident while the block strides over 256-row tiles;
 //   * every wave owns 32 destination rows of a tile end to end and never meets a block barrier in
-//     the tile loop: while two waves of a SIMD wait on gathers the third feeds the MFMA pipe;
+//     the tile loop;
 //   * the CSR slice of the wave's NEXT tile (row pointers, then up to WCAP source ids) is
-//     prefetched into a second private LDS buffer under the current tile's work, so the only
-//     dependent global access on the critical path is the feature row of a neighbour;
-//   * a K block is processed as two 32-column halves: 8-lane groups x float4 gather one 128-B
-//     half row per neighbour (8 rows in flight per pass, 4 passes kept in flight together) into a
-//     private [32][33] A image, then 32 MFMAs (32x64 output, two accumulators share the A fragment);
+//     prefetched into a second private LDS buffer under the current tile's work;
+//   * gathers are batched and branch-free: lane group g8 (8 lanes x float4) serves rows it*8+g8,
+//     it = 0..3, and one step fetches two sources x both 128-B halves for all four rows = 16 loads
+//     in flight together; absent sources read a row of zeros instead of being predicated away (a
+//     load under a divergent branch is fenced by its own s_waitcnt and serialises the round trips);
+//   * the first gather step of K block b+1 is issued BEFORE the MFMAs of block b, and block 0 of the
+//     next tile before the epilogue stores of the current one, so feature-row latency hides under
+//     the matrix work of the same wave;
 //   * rows with more than 4 sources in a slot (hub rows, canonical rows of dense neighborhoods)
 //     are finished cooperatively by the whole wave (8 lane groups stride over one row's sources);
 //   * table slots run as one extra pseudo K block: their pre-transformed source rows are gathered
-//     the same way, staged in the A image and ADDED to the accumulators in the C/D layout
-//     (16 LDS reads per half instead of 32 MFMAs);
+//     the same way, staged in the A image and ADDED to the accumulators in the C/D layout;
 //   * HBM traffic per row and layer: one 256-B read of x, one 256-B write, ~20 B of indices
-//     (neighbour re-reads hit L2: a neighborhood's rows are contiguous).
+//     (neighbour re-reads hit L2 / MALL: a neighborhood's rows are contiguous).
+//
+// Two arithmetic modes share the gather:
+//   f32   v_mfma_f32_32x32x2_f32 on an fp32 A image [32][33] and fp32 weights [K][64];
+//   x6    the fp32-accurate 6-product bf16 split of gemm_split.hip: the gathered sums are split
+//         into three bf16 planes [3][32][40] when they are written to LDS, the weights arrive
+//         pre-split (n-major planes) and v_mfma_f32_32x32x16_bf16 does 24 MFMAs of 32 cycles per
+//         32-deep half block instead of 32 MFMAs of 64 cycles (sm <= 2: the planes of four weight
+//         blocks do not fit beside eight waves).
 #include "common_device.hpp"
 
 namespace desco {
 
 constexpr int WR = 32;        // rows per wave
-constexpr int NW = 8;         // waves per block (2 per SIMD: <= 256 VGPRs each)
-constexpr int AH = 33;        // half-K A image row stride (floats): conflict-free ds_read_b32
+constexpr int NW = 8;         // waves per block (2 per SIMD)
+constexpr int AH = 33;        // half-K fp32 A image row stride (floats): conflict-free ds_read_b32
+constexpr int APS = 40;       // half-K bf16 plane row stride (shorts, 80 B): conflict-free ds_read_b128
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
 constexpr int WCAP = 128;     // source ids staged per wave (longer slices fall back to global)
-constexpr int WAVE_LDS = WR * AH + 2 * RPN + 2 * WCAP;   // floats per wave
+constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(32*33, 3*32*40/2) floats
+constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
+static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
 
 // absent sources of a batched gather step read this row instead of being predicated away
 __device__ __attribute__((aligned(16))) float shmp_zero_row[64];
@@ -50,13 +63,16 @@ struct ShmpArgs {
   const int32_t* vcol;
   int64_t row0, num_rows;
   int S, sm, st;
-  const float* wt;
+  const float* wt;          // f32 mode: [(sm+1)*64][64]
+  const short* wplanes;     // x6 mode: [3][64 n][(sm+1)*64 k] bf16 planes (hi, mid, lo)
   const float* bias;
   const float* ytab;
   int64_t ldy, ytab_row0;
   float* out;
   int64_t ldo;
 };
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   a.x += b.x;
@@ -65,102 +81,23 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   a.w += b.w;
 }
 
-template <int KB, int ST>   // KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2)
-__global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Bimg = lds;                                       // [KB*64][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* Aw = lds + KB * 64 * 64 + wave * WAVE_LDS;        // [32][33]
-  int* rpb = reinterpret_cast<int*>(Aw + WR * AH);         // 2 x [32*S+1] row pointers (absolute)
-  int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids
+// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane (truncation split)
+__device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
+                                            uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
+  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
+  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
+  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
+  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+}
 
-  // ---- resident weights -------------------------------------------------------------------
-  for (int i = tid; i < KB * 1024; i += NW * 64)
-    *reinterpret_cast<float4*>(Bimg + 4 * i) = *reinterpret_cast<const float4*>(g.wt + 4 * i);
-  __syncthreads();
-
-  // The 3 waves of a SIMD (w, w+4, w+8) run the same program; equal priority keeps them in
-  // lockstep (memory phases and MFMA phases line up and add).  Distinct static priorities let one
-  // wave finish its MFMA block first, so its loads/stores overlap the others' MFMAs.
-  {
-    const int pr = __builtin_amdgcn_readfirstlane(wave >> 2);
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else if (pr >= 3) __builtin_amdgcn_s_setprio(3);
-  }
-  const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
-  const int S = g.S;
-  const int nslot = WR * S + 1;                            // <= 129: at most 3 per lane
-  const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
-
-  // prologue: indices of this wave's first tile
-  int64_t tile = blockIdx.x;
-  {
-    const int64_t w0 = tile * (NW * WR) + wave * WR;
-    if (tile < ntiles && w0 < g.num_rows) {
-      const int nr = (int)((g.num_rows - w0) < WR ? (g.num_rows - w0) : WR);
-      const int nptr = nr * S + 1;
-      for (int i = lane; i < nslot; i += 64)
-        rpb[i] = g.vrowptr[(g.row0 + w0) * S + (i < nptr ? i : nptr - 1)];
-      const int eb = rpb[0], ecnt = rpb[WR * S] - eb;
-      for (int i = lane; i < ecnt && i < WCAP; i += 64) ecb[i] = g.vcol[eb + i];
-    }
-  }
-
-  int cur = 0;
-  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-    const int64_t w0 = tile * (NW * WR) + wave * WR;       // first row of this wave (relative)
-    if (w0 >= g.num_rows) continue;
-    const int nr = (int)((g.num_rows - w0) < WR ? (g.num_rows - w0) : WR);
-    const int64_t grow0 = g.row0 + w0;
-    int* rp = rpb + cur * RPN;
-    int* ec = ecb + cur * WCAP;
-    int* rpn = rpb + (cur ^ 1) * RPN;
-    int* ecn = ecb + (cur ^ 1) * WCAP;
-
-    // ---- prefetch the row pointers of the next tile (registers now, LDS later) --------------
-    const int64_t tn = tile + gridDim.x;
-    const int64_t w0n = tn * (NW * WR) + wave * WR;
-    const bool has_next = tn < ntiles && w0n < g.num_rows;
-    int p0 = 0, p1 = 0, p2 = 0;
-    if (has_next) {
-      const int nrn = (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR);
-      const int nptr = nrn * S + 1;
-      const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
-      p0 = src[lane < nptr ? lane : nptr - 1];
-      if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
-      if (lane + 128 < nslot) p2 = src[lane + 128 < nptr ? lane + 128 : nptr - 1];
-    }
-    int qn0 = 0, qn1 = 0;      // source ids of the next tile (registers until the tile ends)
-    int ebn = 0, ecntn = 0;
-
-    const int ebase = rp[0];
-    const int cl = lane & 31;
-    // ---- accumulator init: bias ----------------------------------------------------------------
-    f32x16 acc0, acc1;
-    {
-      const float bv0 = g.bias ? g.bias[cl] : 0.f, bv1 = g.bias ? g.bias[32 + cl] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc0[i] = bv0;
-        acc1[i] = bv1;
-      }
-    }
-    // K blocks: b < KB-1 = relation slot b (gathered x rows), b == KB-1 = the row itself,
-    // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout).
-    // Lane group g8 serves rows it*8 + g8 (it = 0..3); per row BOTH 128-B halves are fetched
-    // together (columns 4*l8 and 32 + 4*l8).  All loads of a step are unconditional -- absent
-    // sources read a row of zeros -- so the 16 loads of a step are in flight
-    // together (a conditional load is fenced by its own s_waitcnt), and the first step of block
-    // b+1 is issued BEFORE the MFMAs of block b.
-    constexpr int NB = KB + (ST > 0 ? 1 : 0);
-    const float* xb = g.x + 4 * l8;
-    const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * g.ldy : nullptr;
-    const float* zrow = shmp_zero_row + 4 * l8;
-    float4 lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;           // gathered sums of the current block
-    float4 u00, u01, u10, u11, u20, u21, u30, u31;           // in flight: first source (lo, hi) of row it
-    float4 w00, w01, w10, w11, w20, w21, w30, w31;           // in flight: second source
-    int c0, c1, c2, c3, n0, n1, n2, n3;                      // source cursors [c, n) relative to ebase
+// ---- gather machinery (macros: every temporary is a named register) ----------------
+// They use the enclosing scope's rp, ec, ebase, grow0, nr, xb, yb, zrow, g, S, g8, l8 and the
+// registers lo*/hi* (sums), u*/w* (loads in flight), c*/n* (cursors).
 #define DESCO_CUR(it_, slot_)                              \
   {                                                        \
     const int v_ = ((it_) * 8 + g8) * S + (slot_);         \
@@ -168,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     n##it_ = rp[v_ + 1] - ebase;                           \
   }
 #define DESCO_CURS(slot_) DESCO_CUR(0, slot_) DESCO_CUR(1, slot_) DESCO_CUR(2, slot_) DESCO_CUR(3, slot_)
-  // two sources of row it_ (staged ids only: e < WCAP), unconditional loads
+// two sources of row it_ (staged ids only: e < WCAP), unconditional loads
 #define DESCO_ISSUE2(it_, base_, ld_)                                                 \
   {                                                                                   \
     const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
@@ -198,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 #define DESCO_ANY_STAGED()                                                                    \
   __any((c0 < (n0 < WCAP ? n0 : WCAP)) | (c1 < (n1 < WCAP ? n1 : WCAP)) |                     \
         (c2 < (n2 < WCAP ? n2 : WCAP)) | (c3 < (n3 < WCAP ? n3 : WCAP)))
-  // the row itself: rows beyond nr re-read the wave's last valid row (never stored)
+// the row itself: rows beyond nr re-read the wave's last valid row (never stored)
 #define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
@@ -206,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     u##it_##0 = *reinterpret_cast<const float4*>(p_);                                          \
     u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                                     \
   }
-  // table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
+// table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
 #define DESCO_TAB_CUR(it_)                                                                  \
   const int v_ = ((it_) * 8 + g8) * S + g.sm;                                               \
   const int ca_ = rp[v_] - ebase, na_ = rp[v_ + 1] - ebase;                                 \
@@ -226,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
     }                                                                                       \
   }
-  // consume the step; leave the cursor of table slot 0 in (c, n) and of slot 1 in (d, m)
+// consume the step; leave the cursor of table slot 0 in (c, n) and of slot 1 in (d, m)
 #define DESCO_CONSUME_TAB(it_)                                                              \
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
@@ -241,9 +178,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     d##it_ = na_ + (k1_ ? 1 : 0);                                                           \
     m##it_ = nb_;                                                                           \
   }
-  // heavy rows (hub / canonical rows of dense neighborhoods, or ids beyond the staged WCAP): the
-  // whole wave cooperates on one row at a time -- lane group k takes sources c+k, c+k+8, ... and
-  // the 8 partial sums are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
+// heavy rows (hub / canonical rows of dense neighborhoods, or ids beyond the staged WCAP): the
+// whole wave cooperates on one row at a time -- lane group k takes sources c+k, c+k+8, ... and
+// the 8 partial sums are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
 #define DESCO_COOP(it_, base_, ld_)                                                       \
   {                                                                                       \
     unsigned long long m_ = __ballot(c##it_ < n##it_);                                    \
@@ -278,8 +215,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       m_ &= ~(0xffULL << (og_ * 8));                                                      \
     }                                                                                     \
   }
-  // finish a gathered block whose first step is already in flight: consume it, one more batched
-  // step for rows with 3-4 sources, then the cooperative path for what is left
+// finish a gathered block whose first step is already in flight: consume it, one more batched
+// step for rows with 3-4 sources, then the cooperative path for what is left
 #define DESCO_FINISH(base_, ld_)                                                           \
   {                                                                                        \
     DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)                \
@@ -293,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       DESCO_COOP(3, base_, ld_)                                                            \
     }                                                                                      \
   }
-  // first step of block b_ (cursors + loads); nothing waits on the loads here
+// first step of block b_ (cursors + loads); nothing waits on the loads here
 #define DESCO_ISSUE_BLOCK(b_)                                                              \
   {                                                                                        \
     if ((b_) < KB - 1) {                                                                   \
@@ -306,8 +243,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       DESCO_ISSUE_TAB(0) DESCO_ISSUE_TAB(1) DESCO_ISSUE_TAB(2) DESCO_ISSUE_TAB(3)          \
     }                                                                                      \
   }
-  // write one half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
-#define DESCO_PUT(av_, it_)                             \
+// write one fp32 half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
+#define DESCO_PUT_F32(av_, it_)                         \
   {                                                     \
     float* d_ = Aw + ((it_) * 8 + g8) * AH + 4 * l8;    \
     d_[0] = av_.x;                                      \
@@ -315,8 +252,19 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     d_[2] = av_.z;                                      \
     d_[3] = av_.w;                                      \
   }
-  // 32 MFMAs on the staged half h_ of K block b_: A[i = lane&31][k = lane>>5], B[k][j = lane&31]
-#define DESCO_MFMA_HALF(b_, h_)                                                            \
+// write one half image as three bf16 planes (row = it*8 + g8, 4 bf16 at 4*l8 of every plane)
+#define DESCO_PUT_X6(av_, it_)                                                  \
+  {                                                                             \
+    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                      \
+    shmp_split2(av_.x, av_.y, h0_, m0_, l0_);                                   \
+    shmp_split2(av_.z, av_.w, h1_, m1_, l1_);                                   \
+    short* d_ = Ap + ((it_) * 8 + g8) * APS + 4 * l8;                           \
+    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                       \
+    *reinterpret_cast<uint2*>(d_ + WR * APS) = make_uint2(m0_, m1_);            \
+    *reinterpret_cast<uint2*>(d_ + 2 * WR * APS) = make_uint2(l0_, l1_);        \
+  }
+// 32 f32 MFMAs on the staged half h_ of K block b_: A[i = lane&31][k = lane>>5], B[k][j = lane&31]
+#define DESCO_MFMA_HALF_F32(b_, h_)                                                        \
   {                                                                                        \
     const float* as_ = Aw + (lane & 31) * AH + (lane >> 5);                                \
     const float* bs_ = Bimg + ((b_) * 64 + (h_) * 32 + (lane >> 5)) * 64 + (lane & 31);    \
@@ -326,14 +274,141 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bs_[2 * kk * 64 + 32], acc1, 0, 0, 0); \
     }                                                                                      \
   }
-  // add the staged table half rows in the C/D layout: acc[reg] += stage[row(reg)][lane&31]
+// 24 bf16 MFMAs (6-product split) on the staged half: lane (r = lane&31, q = lane>>5) holds
+// A[row r][k = 16 s + 8 q + 0..7] and B[k = 16 s + 8 q + 0..7][col r] of every plane
+#define DESCO_MFMA_HALF_X6(b_, h_)                                                                \
+  {                                                                                               \
+    const short* ap_ = Ap + (lane & 31) * APS + 8 * (lane >> 5);                                  \
+    const short* bp_ = Wp + (lane & 31) * WST + (b_) * 64 + (h_) * 32 + 8 * (lane >> 5);          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                            \
+      const bf16x8 ah_ = *reinterpret_cast<const bf16x8*>(ap_ + 16 * s_);                         \
+      const bf16x8 am_ = *reinterpret_cast<const bf16x8*>(ap_ + WR * APS + 16 * s_);              \
+      const bf16x8 al_ = *reinterpret_cast<const bf16x8*>(ap_ + 2 * WR * APS + 16 * s_);          \
+      const bf16x8 b0h_ = *reinterpret_cast<const bf16x8*>(bp_ + 16 * s_);                        \
+      const bf16x8 b0m_ = *reinterpret_cast<const bf16x8*>(bp_ + WPL + 16 * s_);                  \
+      const bf16x8 b0l_ = *reinterpret_cast<const bf16x8*>(bp_ + 2 * WPL + 16 * s_);              \
+      const bf16x8 b1h_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST + 16 * s_);             \
+      const bf16x8 b1m_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST + WPL + 16 * s_);       \
+      const bf16x8 b1l_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST + 2 * WPL + 16 * s_);   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, b0h_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, b1h_, acc1, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b0l_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b1l_, acc1, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, b0m_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, b1m_, acc1, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, b0h_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, b1h_, acc1, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b0m_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b1m_, acc1, 0, 0, 0);                   \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b0h_, acc0, 0, 0, 0);                   \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, b1h_, acc1, 0, 0, 0);                   \
+    }                                                                                             \
+  }
+// add the staged (fp32) table half rows in the C/D layout: acc[reg] += stage[row(reg)][lane&31]
 #define DESCO_TAB_HALF(acc_)                                                               \
   {                                                                                        \
     _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)                                   \
         acc_[reg] += Aw[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * AH + cl];         \
   }
 
-    DESCO_ISSUE_BLOCK(0)
+// KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2), X6: bf16 6-product arithmetic
+template <int KB, int ST, bool X6>
+__global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WST = KB * 64 + 8;                         // weight plane row stride (shorts)
+  constexpr int WPL = 64 * WST;                            // shorts per weight plane
+  constexpr int W_FLOATS = X6 ? 3 * WPL / 2 : KB * 64 * 64;
+  float* Bimg = lds;                                       // f32: [KB*64][64]
+  short* Wp = reinterpret_cast<short*>(lds);               // x6:  [3][64 n][WST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Aw = lds + W_FLOATS + wave * WAVE_LDS;            // fp32 half image [32][33] (f32 mode, table block)
+  short* Ap = reinterpret_cast<short*>(Aw);                // x6: bf16 planes [3][32][40] of a half image
+  int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [32*S+1] row pointers (absolute)
+  int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids
+  (void)Bimg; (void)Wp; (void)Ap;
+
+  // ---- resident weights -------------------------------------------------------------------
+  if (X6) {
+    // global planes [3][64][KB*64] -> LDS [3][64][WST], 16 bytes at a time
+    constexpr int CH = KB * 8;                             // uint4 chunks per row
+    for (int i = tid; i < 3 * 64 * CH; i += NW * 64) {
+      const int row = i / CH, ch = i - row * CH;           // row = plane*64 + n
+      *reinterpret_cast<uint4*>(Wp + row * WST + 8 * ch) =
+          *reinterpret_cast<const uint4*>(g.wplanes + (int64_t)row * (KB * 64) + 8 * ch);
+    }
+  } else {
+    for (int i = tid; i < KB * 1024; i += NW * 64)
+      *reinterpret_cast<float4*>(Bimg + 4 * i) = *reinterpret_cast<const float4*>(g.wt + 4 * i);
+  }
+  __syncthreads();
+
+  const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
+  const int cl = lane & 31;
+  const int S = g.S;
+  const int nslot = WR * S + 1;                            // <= 129: at most 3 per lane
+  const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
+  constexpr int NB = KB + (ST > 0 ? 1 : 0);                // K blocks incl. the table pseudo block
+  const float* xb = g.x + 4 * l8;
+  const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * g.ldy : nullptr;
+  const float* zrow = shmp_zero_row + 4 * l8;
+  (void)yb;
+
+  // ---- this wave's first tile ---------------------------------------------------------------
+  int64_t tile = blockIdx.x;
+  int64_t w0 = tile * (NW * WR) + wave * WR;               // first row of this wave (relative)
+  if (tile >= ntiles || w0 >= g.num_rows) return;          // no barrier below: idle waves may leave
+  int nr = (int)((g.num_rows - w0) < WR ? (g.num_rows - w0) : WR);
+  int64_t grow0 = g.row0 + w0;
+  int cur = 0;
+  int* rp = rpb;
+  int* ec = ecb;
+  {
+    const int nptr = nr * S + 1;
+    for (int i = lane; i < nslot; i += 64)
+      rp[i] = g.vrowptr[grow0 * S + (i < nptr ? i : nptr - 1)];
+    const int eb = rp[0], ecnt = rp[WR * S] - eb;
+    for (int i = lane; i < ecnt && i < WCAP; i += 64) ec[i] = g.vcol[eb + i];
+  }
+  int ebase = rp[0];
+
+  float4 lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;           // gathered sums of the current block
+  float4 u00, u01, u10, u11, u20, u21, u30, u31;           // in flight: first source (lo, hi) of row it
+  float4 w00, w01, w10, w11, w20, w21, w30, w31;           // in flight: second source
+  w00 = w01 = w10 = w11 = w20 = w21 = w30 = w31 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;   // cursors [c, n) rel. to ebase
+  DESCO_ISSUE_BLOCK(0)
+
+  for (;;) {
+    int* rpn = rpb + (cur ^ 1) * RPN;
+    int* ecn = ecb + (cur ^ 1) * WCAP;
+    // ---- prefetch the row pointers of the next tile (registers now, LDS later) --------------
+    const int64_t tn = tile + gridDim.x;
+    const int64_t w0n = tn * (NW * WR) + wave * WR;
+    const bool has_next = tn < ntiles && w0n < g.num_rows;
+    const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
+    int p0 = 0, p1 = 0, p2 = 0;
+    if (has_next) {
+      const int nptr = nrn * S + 1;
+      const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
+      p0 = src[lane < nptr ? lane : nptr - 1];
+      if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
+      if (lane + 128 < nslot) p2 = src[lane + 128 < nptr ? lane + 128 : nptr - 1];
+    }
+    int qn0 = 0, qn1 = 0;      // source ids of the next tile (registers until the tile ends)
+    int ebn = 0, ecntn = 0;
+
+    // ---- accumulator init: bias ----------------------------------------------------------------
+    f32x16 acc0, acc1;
+    {
+      const float bv0 = g.bias ? g.bias[cl] : 0.f, bv1 = g.bias ? g.bias[32 + cl] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc0[i] = bv0;
+        acc1[i] = bv1;
+      }
+    }
+    // K blocks: b < KB-1 = relation slot b (gathered x rows), b == KB-1 = the row itself,
+    // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       // ---- complete the gather of block b ------------------------------------------------------
@@ -371,12 +446,65 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
-      DESCO_PUT(lo0, 0) DESCO_PUT(lo1, 1) DESCO_PUT(lo2, 2) DESCO_PUT(lo3, 3)
+      if (X6 && b < KB) {
+        DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1) DESCO_PUT_X6(lo2, 2) DESCO_PUT_X6(lo3, 3)
+      } else {
+        DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1) DESCO_PUT_F32(lo2, 2) DESCO_PUT_F32(lo3, 3)
+      }
       if (b + 1 < NB) DESCO_ISSUE_BLOCK(b + 1)
-      if (b < KB) DESCO_MFMA_HALF(b, 0) else DESCO_TAB_HALF(acc0)
-      DESCO_PUT(hi0, 0) DESCO_PUT(hi1, 1) DESCO_PUT(hi2, 2) DESCO_PUT(hi3, 3)
-      if (b < KB) DESCO_MFMA_HALF(b, 1) else DESCO_TAB_HALF(acc1)
+      if (b >= KB) {
+        DESCO_TAB_HALF(acc0)
+      } else if (X6) {
+        DESCO_MFMA_HALF_X6(b, 0)
+      } else {
+        DESCO_MFMA_HALF_F32(b, 0)
+      }
+      if (X6 && b < KB) {
+        DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1) DESCO_PUT_X6(hi2, 2) DESCO_PUT_X6(hi3, 3)
+      } else {
+        DESCO_PUT_F32(hi0, 0) DESCO_PUT_F32(hi1, 1) DESCO_PUT_F32(hi2, 2) DESCO_PUT_F32(hi3, 3)
+      }
+      if (b >= KB) {
+        DESCO_TAB_HALF(acc1)
+      } else if (X6) {
+        DESCO_MFMA_HALF_X6(b, 1)
+      } else {
+        DESCO_MFMA_HALF_F32(b, 1)
+      }
     }
+
+    // ---- switch to the next tile: publish its source ids and launch its first gather step ------
+    const int64_t grow_out = grow0;
+    const int nr_out = nr;
+    if (has_next) {
+      if (lane < ecntn) ecn[lane] = qn0;
+      if (lane + 64 < ecntn && lane + 64 < WCAP) ecn[lane + 64] = qn1;
+      cur ^= 1;
+      rp = rpn;
+      ec = ecn;
+      ebase = ebn;
+      tile = tn;
+      w0 = w0n;
+      nr = nrn;
+      grow0 = g.row0 + w0n;
+      DESCO_ISSUE_BLOCK(0)
+    }
+
+    // ---- epilogue: relu + store; C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5) ----
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (r < nr_out) {
+        const float v0 = acc0[reg], v1 = acc1[reg];
+        float* o = g.out + (grow_out + r) * g.ldo + cl;
+        o[0] = v0 > 0.f ? v0 : 0.f;
+        o[32] = v1 > 0.f ? v1 : 0.f;
+      }
+    }
+    if (!has_next) break;
+  }
+}
+
 #undef DESCO_CUR
 #undef DESCO_CURS
 #undef DESCO_ISSUE2
@@ -390,27 +518,93 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 #undef DESCO_COOP
 #undef DESCO_FINISH
 #undef DESCO_ISSUE_BLOCK
-#undef DESCO_PUT
-#undef DESCO_MFMA_HALF
+#undef DESCO_PUT_F32
+#undef DESCO_PUT_X6
+#undef DESCO_MFMA_HALF_F32
+#undef DESCO_MFMA_HALF_X6
 #undef DESCO_TAB_HALF
 
-    if (has_next) {   // publish the next tile's source ids
-      if (lane < ecntn) ecn[lane] = qn0;
-      if (lane + 64 < ecntn && lane + 64 < WCAP) ecn[lane + 64] = qn1;
-    }
+template <int KB, int ST, bool X6>
+static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+  constexpr int WST = KB * 64 + 8;
+  constexpr size_t w_floats = X6 ? (size_t)3 * 64 * WST / 2 : (size_t)KB * 64 * 64;
+  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS);
+  static_assert(shmem <= 160 * 1024, "SHMP layer: LDS budget exceeded");
+  static bool attr_set = false;     // benign race: the attribute is idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6>), dim3(grid), dim3(NW * 64), shmem, st, g);
+}
 
-    // ---- epilogue: relu + store; C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5) ----
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (r < nr) {
-        const float v0 = acc0[reg], v1 = acc1[reg];
-        float* o = g.out + (grow0 + r) * g.ldo + cl;
-        o[0] = v0 > 0.f ? v0 : 0.f;
-        o[32] = v1 > 0.f ? v1 : 0.f;
-      }
+template <int KB, bool X6>
+static void shmp_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+  switch (g.st) {
+    case 0: shmp_launch_one<KB, 0, X6>(g, grid, st); break;
+    case 1: shmp_launch_one<KB, 1, X6>(g, grid, st); break;
+    default: shmp_launch_one<KB, 2, X6>(g, grid, st); break;
+  }
+}
+
+static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, const int32_t* vrowptr,
+                       const int32_t* vcol, int64_t row0, int64_t num_rows, int slots_stored,
+                       int slots_mfma, int slots_table, const void* weights, const float* bias,
+                       const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
+                       desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  const int max_mfma = x6 ? 2 : 3;
+  if (!x || !vrowptr || !weights || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
+      slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
+      slots_stored < 1 || slots_stored > MAXS || slots_table > 2 || (slots_table > 0 && !ytab) ||
+      ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
+      (slots_table > 0 && mis16(ytab)) || x == out)
+    return fail(DESCO_EINVAL,
+                x6 ? "desco_shmp_layer_bf16x6_f32: bad argument (slots_mfma <= 2, slots_table <= 2)"
+                   : "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
+  const int64_t ntiles = (num_rows + NW * WR - 1) / (NW * WR);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  ShmpArgs g{x,
+             ldx,
+             vrowptr,
+             vcol,
+             row0,
+             num_rows,
+             slots_stored,
+             slots_mfma,
+             slots_table,
+             x6 ? nullptr : static_cast<const float*>(weights),
+             x6 ? static_cast<const short*>(weights) : nullptr,
+             bias,
+             ytab,
+             ldy,
+             ytab_row0,
+             out,
+             ldo};
+  hipStream_t st = (hipStream_t)stream;
+  if (x6) {
+    switch (slots_mfma) {
+      case 0: shmp_launch_st<1, true>(g, grid, st); break;
+      case 1: shmp_launch_st<2, true>(g, grid, st); break;
+      default: shmp_launch_st<3, true>(g, grid, st); break;
+    }
+  } else {
+    switch (slots_mfma) {
+      case 0: shmp_launch_st<1, false>(g, grid, st); break;
+      case 1: shmp_launch_st<2, false>(g, grid, st); break;
+      case 2: shmp_launch_st<3, false>(g, grid, st); break;
+      default: shmp_launch_st<4, false>(g, grid, st); break;
     }
   }
+  return launch_status(who);
 }
 
 }  // namespace desco
@@ -421,51 +615,18 @@ extern "C" int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* 
                                     const float* wt, const float* bias, const float* ytab,
                                     int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                                     desco_stream_t stream) {
-  using namespace desco;
-  if (num_rows == 0) return 0;
-  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (!x || !vrowptr || !wt || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
-      slots_mfma > 3 || slots_table < 0 || slots_mfma + slots_table > slots_stored || slots_stored < 1 ||
-      slots_stored > MAXS || slots_table > 2 || (slots_table > 0 && !ytab) || ldx % 4 || mis16(x) || mis16(wt) ||
-      x == out)
-    return fail(DESCO_EINVAL, "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
-  const int64_t ntiles = (num_rows + NW * WR - 1) / (NW * WR);
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      cus = v;
-  }
-  const int kb = slots_mfma + 1;
-  const size_t shmem = sizeof(float) * ((size_t)kb * 64 * 64 + (size_t)NW * WAVE_LDS);
-  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  ShmpArgs g{x,   ldx,  vrowptr, vcol, row0,      num_rows, slots_stored, slots_mfma, slots_table,
-             wt,  bias, ytab,    ldy,  ytab_row0, out,      ldo};
-  hipStream_t st = (hipStream_t)stream;
-#define DESCO_LAUNCH(KB_, ST_)                                                                   \
-  {                                                                                              \
-    static bool attr_set = false;                                                                \
-    if (!attr_set) {                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB_, ST_>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
-      attr_set = true;                                                                           \
-    }                                                                                            \
-    hipLaunchKernelGGL((shmp_layer_f32_kernel<KB_, ST_>), dim3(grid), dim3(NW * 64), shmem, st,  \
-                       g);                                                                       \
-  }
-#define DESCO_LAUNCH_ST(KB_)                    \
-  switch (slots_table) {                        \
-    case 0: DESCO_LAUNCH(KB_, 0) break;         \
-    case 1: DESCO_LAUNCH(KB_, 1) break;         \
-    default: DESCO_LAUNCH(KB_, 2) break;        \
-  }
-  switch (kb) {
-    case 1: DESCO_LAUNCH_ST(1) break;
-    case 2: DESCO_LAUNCH_ST(2) break;
-    case 3: DESCO_LAUNCH_ST(3) break;
-    default: DESCO_LAUNCH_ST(4) break;
-  }
-#undef DESCO_LAUNCH_ST
-#undef DESCO_LAUNCH
-  return launch_status("desco_shmp_layer_f32");
+  return desco::shmp_launch("desco_shmp_layer_f32", false, x, ldx, vrowptr, vcol, row0, num_rows,
+                            slots_stored, slots_mfma, slots_table, wt, bias, ytab, ldy, ytab_row0, out,
+                            ldo, stream);
+}
+
+extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                           const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                           int slots_stored, int slots_mfma, int slots_table,
+                                           const int16_t* wt_planes, const float* bias,
+                                           const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                           float* out, int64_t ldo, desco_stream_t stream) {
+  return desco::shmp_launch("desco_shmp_layer_bf16x6_f32", true, x, ldx, vrowptr, vcol, row0,
+                            num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
+                            ldy, ytab_row0, out, ldo, stream);
 }

@@ -30,6 +30,8 @@ FUSED_GOSSIP = True
 # inference GEMMs (anchor, post MLP, head, canonical table) on the bf16 matrix pipe with fp32-level
 # accuracy (bf16x6 split, csrc/gemm_split.hip); False: v_mfma_f32_32x32x2_f32 (gemm_f32.hip)
 GEMM_BF16X6 = True
+# True: the fused SHMP layer's MFMA blocks also run as the bf16x6 split (csrc/shmp_layer.hip, K <= 192)
+SHMP_BF16X6 = True
 
 TARGET_NODE_TYPES = ["count", "canonical"]
 # metadata of to_hetero_old(tconv_target=True), lightning_model.py:376-383
@@ -278,6 +280,11 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
                 entry["wt_tab"] = torch.cat([blocks[2], blocks[3]], 1).contiguous()      # [64,128]
                 if bf16_planes and GEMM_BF16X6:
                     entry["wt_tab_nk"] = ops.split_bf16_planes(entry["wt_tab"].t())    # [3,128,64]
+            if bf16_planes and SHMP_BF16X6:
+                # n-major bf16 planes of the MFMA blocks for the x6 form of the fused layer (K <= 192)
+                for name in ("wt_mfma", "wt"):
+                    if name in entry and entry[name].shape[0] <= 192:
+                        entry[name + "_x6"] = ops.split_bf16_planes(entry[name].t())
             per_type[t] = entry
         pk["layers"].append(per_type)
     pk["anchor"] = _lin_t(gnn.anchor_mlp[0])
@@ -357,11 +364,12 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                 if "wt_tab" in e:
                     ytab = (ops.gemm_split(X[-1][Nc:], e["wt_tab_nk"]) if GEMM_BF16X6 else
                             ops.gemm(X[-1][Nc:], e["wt_tab"]))            # canonical rows x [W2|W3]
-                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2, e["wt_mfma"],
+                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2,
+                                   e.get("wt_mfma_x6", e["wt_mfma"]) if SHMP_BF16X6 else e["wt_mfma"],
                                    e["b"], xn, ytab=ytab, ytab_row0=Nc)
                 else:
-                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su, e["wt"],
-                                   e["b"], xn)
+                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
+                                   e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn)
         else:
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
             for t, r0, r1, su in groups:

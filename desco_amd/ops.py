@@ -164,8 +164,14 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                bias: torch.Tensor, out: torch.Tensor, ytab: Optional[torch.Tensor] = None,
                ytab_row0: int = 0) -> torch.Tensor:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
-    ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1."""
-    assert wt.is_contiguous() and wt.shape == ((slots_mfma + 1) * 64, 64)
+    ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1.
+    ``wt``: fp32 [(sm+1)*64, 64] (f32 MFMA) or int16 planes [3, 64, (sm+1)*64] =
+    ``split_bf16_planes(wt.t())`` (fp32-accurate bf16x6 arithmetic, sm <= 2)."""
+    x6 = wt.dtype == torch.int16
+    if x6:
+        assert wt.is_contiguous() and wt.shape == (3, 64, (slots_mfma + 1) * 64)
+    else:
+        assert wt.is_contiguous() and wt.shape == ((slots_mfma + 1) * 64, 64)
     xp, ldx = _rows(x, "x")
     op, ldo = _rows(out, "out")
     st, yp, ldy = 0, None, 0
@@ -173,15 +179,16 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
         st = ytab.shape[1] // 64
         yp, ldy = _rows(ytab, "ytab")
     L = _lib.lib()
+    fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
     # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
     with _Timed("shmp_layer_f32_kernel", fl, nb):
-        _lib.check(L.desco_shmp_layer_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
-                                          _dev(vcol, "vcol", torch.int32), row0, num_rows,
-                                          slots_stored, slots_mfma, st, _dev(wt, "wt"),
-                                          _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
-                                          op, ldo, _stream()), "shmp_layer")
+        _lib.check(fn(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
+                      _dev(vcol, "vcol", torch.int32), row0, num_rows,
+                      slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
+                      _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
+                      op, ldo, _stream()), "shmp_layer")
     return out
 
 

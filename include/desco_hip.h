@@ -144,6 +144,15 @@ int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* vrowptr, co
                          int slots_table, const float* wt, const float* bias, const float* ytab,
                          int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                          desco_stream_t stream);
+/* Same layer with the matrix work on the bf16 pipe at fp32 accuracy (the 6-product split of
+ * desco_gemm_bf16x6_f32): wt_planes[3][64 n][(slots_mfma+1)*64 k] = desco_split_bf16x3_f32 of the
+ * N-MAJOR folded weight (the transpose of desco_shmp_layer_f32's wt).  slots_mfma <= 2. */
+int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                int slots_stored, int slots_mfma, int slots_table,
+                                const int16_t* wt_planes, const float* bias, const float* ytab,
+                                int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
+                                desco_stream_t stream);
 
 /* First SHMP layer (and first pooling block) when every node of a type has the same input row --
  * the default pipeline's all-zero node features (workload.py:431-440, transforms.py:380-384) make

@@ -187,7 +187,10 @@ def test_gossip_layer0_and_gather():
 @pytest.mark.parametrize("S,sm,st", [(4, 3, 0), (4, 2, 0), (2, 2, 0), (4, 2, 2), (1, 1, 0), (4, 0, 1), (4, 3, 1)])
 @pytest.mark.parametrize("num_rows,row0,max_deg", [(1, 0, 3), (63, 5, 4), (256, 0, 2), (1000, 17, 9),
                                                    (333, 0, 70), (70000, 3, 3), (70000, 0, 6)])
-def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg):
+@pytest.mark.parametrize("x6", [False, True])
+def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
+    if x6 and sm > 2:
+        pytest.skip("bf16x6 form holds at most three resident weight blocks")
     g = torch.Generator().manual_seed(S * 1000 + sm * 100 + st * 10 + num_rows)
     n_all = row0 + num_rows + 9
     x = torch.randn(n_all, 64, generator=g)
@@ -208,7 +211,8 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg):
         ytab = ytab_cpu.to(DEV)
     ref = torch.relu(ref)[row0:row0 + num_rows]
     out = torch.full((n_all, 64), -7.0, device=DEV)
-    ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, wt.to(DEV),
+    w_dev = ops.split_bf16_planes(wt.t().contiguous().to(DEV)) if x6 else wt.to(DEV)
+    ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, w_dev,
                    bias.to(DEV), out, ytab=ytab, ytab_row0=0)
     _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
     rest = torch.cat([out[:row0], out[row0 + num_rows:]])
