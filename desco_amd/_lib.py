@@ -45,7 +45,7 @@ SIGNATURES = {
     "desco_gossip_gather_f32": (c_int, [vp, vp, vp, i64, i32, vp, vp, vp]),
     "desco_gossip_scalars_f32": (c_int, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp]),
     "desco_split_bf16x3_f32": (c_int, [vp, i64, vp, vp]),
-    "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 17 + [f32, vp, vp]),
+    "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp]),
     "desco_gemm_tn_workspace": (ctypes.c_size_t, [i64, i32, i32, POINTER(c_int)]),
     "desco_gemm_tn_f32": (c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, vp]),
     "desco_colsum_f32": (c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),

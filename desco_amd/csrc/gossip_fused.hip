@@ -1,4 +1,4 @@
-// Fused gossip stage for gfx950: for a tile of 64 nodes and ONE query the whole per-query network
+// Fused gossip stage for gfx950: for a tile of 128 nodes and ONE query the whole per-query network
 // of the reference (BaseGNN gossip path, gnn_model.py:58-103, 230-260, 303-350; looped over queries
 // in lightning_model.py:613-628) runs on chip:
 //
@@ -11,21 +11,39 @@
 //   out  = x + b7 + sum_c relu(y2 W5 + b5)[c] * w7[c]                (post_mp.5/.7, N=256) MFMA
 //
 // Nothing but the 16-byte scalar records and the [N,Q] result crosses HBM (the unfused path moves
-// ~2.3 KB per (node,query)); the kernel is bound by the f32 MFMA rate (288 MFMAs per wave and tile).
-// Block = 4 waves, output tiles 64x64 as 2x2 wave tiles of 32x32 (v_mfma_f32_32x32x2_f32); three
-// 64x68 activation images + one 64x68 weight image in LDS (71 KB -> 2 blocks per CU); the last GEMM
-// (64 -> 256) runs as a 6-product bf16 split (fp32-accurate) whose planes overlay dead images; weight
-// blocks are prefetched into registers under the previous block's MFMAs.  Blocks are persistent
-// (2 per CU) and walk (tile, query) items; the next item's CSR slice and scalar records are
-// prefetched through registers in three stages under the current item's GEMMs.
-// Algebra: DESIGN.md 4.2.
+// ~2.3 KB per (node,query)).  All four GEMMs run on the bf16 matrix pipe at fp32 accuracy (the
+// 6-product split of gemm_split.hip): activations live in LDS only as three bf16 planes, the
+// weights arrive pre-split from the host.
+//
+// Block = 8 waves = one CU, persistent over (tile, query) items.  LDS (151 KB):
+//   two activation images [3 planes][128 rows][64 k] bf16 (h1/y1 and hh/h2/y2),
+//   two weight-block buffers [3][64 n][64 k] bf16 (nine 64x64 blocks per item, double buffered:
+//   block i+1 is fetched into registers under the MFMAs of block i and stored after them, so a
+//   block costs ONE barrier), the tile's scalar records / row pointers, the bias vectors.
+//   Rows are 128 B without padding; the 16-byte chunk index is XOR-swizzled with (row>>1)&7, which
+//   makes every ds_read_b128 fragment read conflict-free.
+// The GEMMs are computed TRANSPOSED (MFMA A operand = weight rows, B operand = activation rows):
+// in the 32x32 C/D layout a lane then owns one node and 4 consecutive output features per register
+// quad, so an epilogue packs bf16 pairs in registers and writes 8 bytes per plane, reads its
+// per-node scalars once, and the final 256-wide dot product is a per-lane running sum.
+// Wave (wm = wave&3, wn = wave>>2) owns nodes 32wm..+31 x features 32wn..+31 of every 64-wide block.
+// The next item's CSR slice and scalar records are prefetched through registers in three stages
+// under the current item's GEMMs.  Algebra: DESIGN.md 4.2.
 #include "common_device.hpp"
 
 namespace desco {
 
-constexpr int GT = 64;      // rows (nodes) per tile
-constexpr int GAS = 68;     // image row stride (floats): 16-B aligned rows, conflict-free b128 reads
-constexpr int ECAP = 768;   // neighbour records staged per pass (aliases the third image)
+constexpr int GT = 128;            // rows (nodes) per tile
+constexpr int GNT = 512;           // threads per block
+constexpr int PLN = GT * 64;       // shorts per activation plane
+constexpr int WPLN = 64 * 64;      // shorts per weight-block plane
+constexpr int PCAP = 512;          // neighbour records prefetched (one per thread) for the next tile
+constexpr int ECAP = 1024;         // neighbour records staged per pass (aliases weight buffer 1)
+constexpr int CST = 832;           // u, d1, tp, b3 (64 each), b5, w7 (256 each), zp_q (64)
+constexpr size_t GOSSIP_LDS_BYTES = (size_t)2 * 3 * PLN * 2 + (size_t)2 * 3 * WPLN * 2 + GT * 16 +
+                                    132 * 4 + CST * 4 + 2 * GT * 4;
+static_assert(ECAP * 20 <= 3 * WPLN * 2, "neighbour staging must fit in one weight buffer");
+static_assert(GOSSIP_LDS_BYTES <= 160 * 1024, "gossip_fused: LDS budget exceeded");
 
 struct GossipFusedArgs {
   const float4* scal;       // [N*Q] (a0, b0, a1, x)
@@ -42,12 +60,11 @@ struct GossipFusedArgs {
   const float* u;           // [64]  D1a c1
   const float* tp;          // [64]  P0[:,64:128] w_pre
   const float* d1;          // [64]
-  const float* w1;          // [64,128]  (n-major = transposed: row n holds the 128 k)
-  const float* wp;          // [64,128]
-  const float* w3;          // [64,64]
+  const short* w1s;         // [3][64][128]  bf16 planes of the n-major (row n holds the 128 k) W1
+  const short* wps;         // [3][64][128]
+  const short* w3s;         // [3][64][64]
   const float* b3;          // [64]
-  const float* w5;          // [256,64]  (kept for reference / un-split builds)
-  const short* w5s;         // [3][256][64] bf16 planes (hi, mid, lo) of w5, split on the host
+  const short* w5s;         // [3][256][64]
   const float* b5;          // [256]
   const float* w7;          // [256]
   float b7;
@@ -86,77 +103,132 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
                                      b * flo + (1.f - b) * fhi, x[i * ldx + q]);
 }
 
-// weight block staging: 64 output columns n x 64 k, source is n-major (row n, leading dim ld_);
-// thread t moves 4 float4: n = t>>4 (+16,+32,+48), k = 4*(t&15)
-#define DESCO_WLOAD(src_, ld_)                                                          \
-  {                                                                                     \
-    const float* s_ = (src_) + (int64_t)(tid >> 4) * (ld_) + 4 * (tid & 15);            \
-    w0 = *reinterpret_cast<const float4*>(s_);                                          \
-    w1 = *reinterpret_cast<const float4*>(s_ + 16 * (int64_t)(ld_));                    \
-    w2 = *reinterpret_cast<const float4*>(s_ + 32 * (int64_t)(ld_));                    \
-    w3 = *reinterpret_cast<const float4*>(s_ + 48 * (int64_t)(ld_));                    \
-  }
-#define DESCO_WSTORE()                                                                  \
-  {                                                                                     \
-    float* d_ = Bs + (tid >> 4) * GAS + 4 * (tid & 15);                                 \
-    *reinterpret_cast<float4*>(d_) = w0;                                                \
-    *reinterpret_cast<float4*>(d_ + 16 * GAS) = w1;                                     \
-    *reinterpret_cast<float4*>(d_ + 32 * GAS) = w2;                                     \
-    *reinterpret_cast<float4*>(d_ + 48 * GAS) = w3;                                     \
-  }
-// 32 MFMAs of one 64-deep K block.  Lane (r = lane&31, h = lane>>5) owns k = 32h .. 32h+31 of
-// its A row and of its B column (the sum over k is order-free, so the MFMA's k pairing can be
-// chosen per lane half): 8 ds_read_b128 per operand instead of 32 ds_read_b32.
-#define DESCO_MFMA_BLOCK(Aimg_)                                                                   \
-  {                                                                                               \
-    const float4* ap_ = reinterpret_cast<const float4*>((Aimg_) + (wr * 32 + (lane & 31)) * GAS + \
-                                                        32 * (lane >> 5));                        \
-    const float4* bp_ = reinterpret_cast<const float4*>(Bs + (wc * 32 + (lane & 31)) * GAS +      \
-                                                        32 * (lane >> 5));                        \
-    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                            \
-      const float4 a_ = ap_[t_], b_ = bp_[t_];                                                    \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, b_.x, acc, 0, 0, 0);                       \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, b_.y, acc, 0, 0, 0);                       \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, b_.z, acc, 0, 0, 0);                       \
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc, 0, 0, 0);                       \
-    }                                                                                             \
-  }
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
-#define DESCO_ACC_ZERO() \
+
+// element offset of (row, k) inside a [rows][64] bf16 plane with swizzled 16-byte chunks
+__device__ __forceinline__ int gf_pidx(const int row, const int k) {
+  return row * 64 + ((((k >> 3) ^ (row >> 1)) & 7) << 3) + (k & 7);
+}
+
+// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane (truncation split)
+__device__ __forceinline__ void gf_split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
+                                          uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
+  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
+  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
+  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
+  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
+}
+
+// weight block (64 n x 64 k, three planes): thread t moves 8 bf16 of row n = t>>3, chunk t&7, per plane
+#define GF_WLOAD(base_, rows_total_, ldk_, nrow0_, koff_)                                          \
+  {                                                                                                \
+    const short* s_ = (base_) + (int64_t)((nrow0_) + (tid >> 3)) * (ldk_) + (koff_) + 8 * (tid & 7); \
+    q0 = *reinterpret_cast<const uint4*>(s_);                                                      \
+    q1 = *reinterpret_cast<const uint4*>(s_ + (int64_t)(rows_total_) * (ldk_));                    \
+    q2 = *reinterpret_cast<const uint4*>(s_ + (int64_t)2 * (rows_total_) * (ldk_));                \
+  }
+#define GF_WSTORE(wb_)                                                                 \
+  {                                                                                    \
+    short* d_ = (wb_) + (tid >> 3) * 64 + ((((tid & 7) ^ (tid >> 4)) & 7) << 3);       \
+    *reinterpret_cast<uint4*>(d_) = q0;                                                \
+    *reinterpret_cast<uint4*>(d_ + WPLN) = q1;                                         \
+    *reinterpret_cast<uint4*>(d_ + 2 * WPLN) = q2;                                     \
+  }
+// the six products of one 16-deep step (smallest terms first)
+#define GF_MFMA6(wh_, wm_, wl_, xh_, xm_, xl_)                                     \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_, xh_, acc, 0, 0, 0);           \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xl_, acc, 0, 0, 0);           \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm_, xm_, acc, 0, 0, 0);           \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm_, xh_, acc, 0, 0, 0);           \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xm_, acc, 0, 0, 0);           \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xh_, acc, 0, 0, 0);
+// 24 MFMAs of one 64x64 weight block: D^T[n][node] += sum_k W[n][k] X[node][k]; lane (r = lane&31,
+// h = lane>>5) holds W[32wn + r][16 s + 8 h + 0..7] and X[32wm + r][16 s + 8 h + 0..7] of every plane.
+// The six fragments of step s+1 are read while the MFMAs of step s run (two register sets).
+#define GF_FRAGS(wa_, xa_, s_, wh_, wm_, wl_, xh_, xm_, xl_)                                       \
+  {                                                                                                \
+    const int c_ = (((2 * (s_) + (lane >> 5)) ^ swz) & 7) << 3;                                    \
+    wh_ = *reinterpret_cast<const bf16x8*>((wa_) + c_);                                            \
+    wm_ = *reinterpret_cast<const bf16x8*>((wa_) + WPLN + c_);                                     \
+    wl_ = *reinterpret_cast<const bf16x8*>((wa_) + 2 * WPLN + c_);                                 \
+    xh_ = *reinterpret_cast<const bf16x8*>((xa_) + c_);                                            \
+    xm_ = *reinterpret_cast<const bf16x8*>((xa_) + PLN + c_);                                      \
+    xl_ = *reinterpret_cast<const bf16x8*>((xa_) + 2 * PLN + c_);                                  \
+  }
+#define GF_MFMA_BLOCK(wb_, img_)                                                                   \
+  {                                                                                                \
+    const short* wa_ = (wb_) + wrow * 64;                                                          \
+    const short* xa_ = (img_) + xrow * 64;                                                         \
+    bf16x8 awh_, awm_, awl_, axh_, axm_, axl_, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_;                 \
+    GF_FRAGS(wa_, xa_, 0, awh_, awm_, awl_, axh_, axm_, axl_)                                      \
+    GF_FRAGS(wa_, xa_, 1, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                      \
+    GF_MFMA6(awh_, awm_, awl_, axh_, axm_, axl_)                                                   \
+    GF_FRAGS(wa_, xa_, 2, awh_, awm_, awl_, axh_, axm_, axl_)                                      \
+    GF_MFMA6(bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                                   \
+    GF_FRAGS(wa_, xa_, 3, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                      \
+    GF_MFMA6(awh_, awm_, awl_, axh_, axm_, axl_)                                                   \
+    GF_MFMA6(bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                                   \
+  }
+#define GF_ACC_ZERO() \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[i_] = 0.f;
+// write 4 consecutive features (fb_ .. fb_+3) of node xrow as bf16 planes into image img_
+#define GF_PUT4(img_, fb_, v0_, v1_, v2_, v3_)                                           \
+  {                                                                                      \
+    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                               \
+    gf_split2(v0_, v1_, h0_, m0_, l0_);                                                  \
+    gf_split2(v2_, v3_, h1_, m1_, l1_);                                                  \
+    short* d_ = (img_) + gf_pidx(xrow_e, (fb_));                                           \
+    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                \
+    *reinterpret_cast<uint2*>(d_ + PLN) = make_uint2(m0_, m1_);                          \
+    *reinterpret_cast<uint2*>(d_ + 2 * PLN) = make_uint2(l0_, l1_);                      \
+  }
 
-constexpr int PST = 72;     // bf16 plane row stride (144 B): 16-B aligned, conflict-free b128 reads
-constexpr int PCAP = 256;   // neighbour records prefetched (one per thread) for the next tile
-
-__global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[3 * GT * GAS + 64 * GAS + 4 * GT + 68];
-  float* A0 = lds;                      // h1, later y2
-  float* A2 = lds + GT * GAS;           // neighbour staging, later h2, later head partials
-  float* A1 = lds + 2 * GT * GAS;       // hh, later y1
-  // post_mp.5 (64 -> 256, 44 % of the tile's MFMA work) runs fp32-accurately on the bf16 pipe
-  // (bf16x6, see gemm_split.hip): y2 is written as three bf16 planes over A0 + the head of A2, the
-  // pre-split W5 block planes go over the tail of A2 + A1 + the head of Bs (all dead by then).
-  short* Y2P = reinterpret_cast<short*>(lds);            // [3][64][PST]
-  short* W5P = Y2P + 3 * GT * PST;                       // [3][64][PST]
-  float* Bs = lds + 3 * GT * GAS;       // weight block, n-major [64 n][64 k], stride GAS
-  float4* srow = reinterpret_cast<float4*>(Bs + 64 * GAS);   // scalars of the tile rows
-  int* rp = reinterpret_cast<int*>(Bs + 64 * GAS + 4 * GT);  // rowptr[n0 .. n0+64]
-  int* ecol = reinterpret_cast<int*>(A2);                   // [ECAP]
-  float4* escal = reinterpret_cast<float4*>(A2 + ECAP);     // [ECAP]
+__global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
+  short* I0 = reinterpret_cast<short*>(gf_lds);          // h1, later y1
+  short* I1 = I0 + 3 * PLN;                              // hh, later h2, later y2
+  short* WB0 = I1 + 3 * PLN;                             // weight blocks 0, 2, 4, 6, 8
+  short* WB1 = WB0 + 3 * WPLN;                           // weight blocks 1, 3, 5, 7; neighbour staging
+  float4* srow = reinterpret_cast<float4*>(WB1 + 3 * WPLN);   // scalars of the tile rows
+  int* rp = reinterpret_cast<int*>(srow + GT);                // rowptr[n0 .. n0+128]
+  float* cst = reinterpret_cast<float*>(rp + 132);            // bias vectors (see CST)
+  float* red = cst + CST;                                     // [2][128] head partials
+  int* ecol = reinterpret_cast<int*>(WB1);                    // [ECAP]
+  float4* escal = reinterpret_cast<float4*>(ecol + ECAP);     // [ECAP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int xrow = 32 * wm + (lane & 31);   // this lane's node (B operand, epilogues)
+  const int wrow = 32 * wn + (lane & 31);   // this lane's weight row (A operand)
+  const int swz = (lane >> 1) & 7;          // chunk swizzle of both rows: (row >> 1) & 7 with row = 32 j + (lane & 31)
+  const int fq = 32 * wn + 4 * (lane >> 5);      // first output feature of register quad 0 (+8 per quad)
   const int Q = g.Q;
   const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
   int64_t item = blockIdx.x;
   if (item >= nitems) return;
 
+  for (int i = tid; i < 64; i += GNT) {
+    cst[i] = g.u[i];
+    cst[64 + i] = g.d1[i];
+    cst[128 + i] = g.tp[i];
+    cst[192 + i] = g.b3[i];
+  }
+  for (int i = tid; i < 256; i += GNT) {
+    cst[256 + i] = g.b5[i];
+    cst[512 + i] = g.w7[i];
+  }
+
   // The (rowptr -> col -> scalar record) chain of the NEXT item is fetched into these registers
   // in three stages spread over the current item's GEMMs and published to LDS when the current
-  // item is done: a tile no longer starts with three dependent global-memory latencies.
+  // item is done: a tile does not start with three dependent global-memory latencies.
   float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow;
   int n_rp = 0, n_col = 0, n_ebeg = 0, n_cnt = 0;
-#define DESCO_STAGE1(it_)                                                                  \
+#define GF_STAGE1(it_)                                                                     \
   {                                                                                        \
     const int q_ = (int)((it_) % Q);                                                       \
     const int64_t t0_ = ((it_) / Q) * GT;                                                  \
@@ -167,247 +239,237 @@ __global__ __launch_bounds__(256, 2) void gossip_fused_kernel(GossipFusedArgs g,
     n_cnt = g.rowptr[t0_ + nr_] - n_ebeg;                                                  \
     n_cnt = n_cnt < PCAP ? n_cnt : PCAP;                                                   \
   }
-#define DESCO_STAGE2() \
+#define GF_STAGE2() \
   if (tid < n_cnt) n_col = g.col[n_ebeg + tid];
-#define DESCO_STAGE3(it_) \
+#define GF_STAGE3(it_) \
   if (tid < n_cnt) n_scal = g.scal[(int64_t)n_col * Q + (int)((it_) % Q)];
 
-  DESCO_STAGE1(item)
-  DESCO_STAGE2()
-  DESCO_STAGE3(item)
-  const float rc = g.r[lane], tc = g.t[lane];
-  const int col = wc * 32 + (lane & 31);
+  GF_STAGE1(item)
+  GF_STAGE2()
+  GF_STAGE3(item)
+  // phase-1 lane map: two adjacent features (f0, f0+1) of rows wave*16 + 2*i + (lane>>5), i = 0..7
+  const int f0 = 2 * (lane & 31);
+  const float2 rc = *reinterpret_cast<const float2*>(g.r + f0);
+  const float2 tc = *reinterpret_cast<const float2*>(g.t + f0);
+  uint4 q0, q1, q2;                       // weight block in flight (one 16-byte chunk per plane)
+  GF_WLOAD(g.w1s, 64, 128, 0, 0)          // block 0 of the first item
 
   for (;;) {
     // ---- publish the prefetched tile data ------------------------------------------------------
+    const int q = (int)(item % Q);
     if (tid < GT) srow[tid] = n_srow;
     if (tid <= GT) rp[tid] = n_rp;
     if (tid < n_cnt) {
       ecol[tid] = n_col;
       escal[tid] = n_scal;
     }
+    if (tid < 64) cst[768 + tid] = g.zp[q * 64 + tid];
     const int cnt0 = n_cnt;
-    const int q = (int)(item % Q);
     const int64_t n0 = (item / Q) * GT;
     const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
     const int64_t next = item + gridDim.x;
     const bool has_next = next < nitems;
+    GF_WSTORE(WB0)                         // block 0 (W1, k 0..63: multiplies hh)
     __syncthreads();
-    if (has_next) DESCO_STAGE1(next)
-
-    // first weight block (W1 columns for hh) in flight while the tile is being assembled
-    float4 w0, w1, w2, w3;
-    DESCO_WLOAD(g.w1, 128)
-    const float gq = g.g1[q];
-    const float pc = g.p[q * 64 + lane], zc = g.z[q * 64 + lane];
+    if (has_next) GF_STAGE1(next)
+    GF_WLOAD(g.w1s, 64, 128, 0, 64)        // block 1 in flight while the tile is being assembled
 
     // ---- phase 1: h1 of the tile rows, gated neighbour sum hh -----------------------------------
-    float hh[16];
+    {
+      // (the asm keeps the 40-odd row / plane addresses of this phase from being hoisted out of the
+      // item loop, where they would sit in registers through the GEMMs)
+      int lane1 = lane;
+      asm volatile("" : "+v"(lane1));
+      const int half1 = lane1 >> 5, f1 = 2 * (lane1 & 31);
+      const float gq = g.g1[q];
+      const float2 pc = *reinterpret_cast<const float2*>(g.p + q * 64 + f0);
+      const float2 zc = *reinterpret_cast<const float2*>(g.z + q * 64 + f0);
+      float2 hh[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hh[k] = 0.f;
-    const int ebeg = rp[0], eend = rp[GT];
-    // pass 0: the prefetched records [ebeg, ebeg+cnt0); later passes (tiles with more than PCAP
-    // neighbour records) stage ECAP records at a time from global memory
-    int base = ebeg, cnt = cnt0;
-    for (;;) {
+      for (int i = 0; i < 8; ++i) hh[i] = make_float2(0.f, 0.f);
+      const int ebeg = rp[0], eend = rp[GT];
+      // pass 0: the prefetched records [ebeg, ebeg+cnt0); later passes (tiles with more than PCAP
+      // neighbour records) stage ECAP records at a time from global memory
+      int base = ebeg, cnt = cnt0;
+      for (;;) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int row = wave * 16 + k;
-        const int node = (int)n0 + row;
-        int lo = rp[row] - base, hi = rp[row + 1] - base;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > cnt ? cnt : hi;
-        float a = hh[k];
-        for (int e = lo; e < hi; ++e) {
-          const float4 sj = escal[e];
-          float h = sj.x * pc + sj.y * rc + sj.w * tc + zc;
-          h = h > 0.f ? h : 0.f;
-          a += (ecol[e] < node ? gq : 1.f - gq) * h;
+        for (int i = 0; i < 8; ++i) {
+          const int row = wave * 16 + 2 * i + half1;
+          const int node = (int)n0 + row;
+          int lo = rp[row] - base, hi = rp[row + 1] - base;
+          lo = lo < 0 ? 0 : lo;
+          hi = hi > cnt ? cnt : hi;
+          float2 a = hh[i];
+          for (int e = lo; e < hi; ++e) {
+            const float4 sj = escal[e];
+            float hx = sj.x * pc.x + sj.y * rc.x + sj.w * tc.x + zc.x;
+            float hy = sj.x * pc.y + sj.y * rc.y + sj.w * tc.y + zc.y;
+            hx = hx > 0.f ? hx : 0.f;
+            hy = hy > 0.f ? hy : 0.f;
+            const float gt = ecol[e] < node ? gq : 1.f - gq;
+            a.x += gt * hx;
+            a.y += gt * hy;
+          }
+          hh[i] = a;
         }
-        hh[k] = a;
+        base += cnt;
+        if (base >= eend) break;
+        __syncthreads();          // everyone is done with the staged records
+        cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
+        for (int e = tid; e < cnt; e += GNT) {
+          const int j = g.col[base + e];
+          ecol[e] = j;
+          escal[e] = g.scal[(int64_t)j * Q + q];
+        }
+        __syncthreads();
       }
-      base += cnt;
-      if (base >= eend) break;
-      __syncthreads();          // everyone is done with the staged records
-      cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
-      for (int e = tid; e < cnt; e += 256) {
-        const int j = g.col[base + e];
-        ecol[e] = j;
-        escal[e] = g.scal[(int64_t)j * Q + q];
-      }
-      __syncthreads();
-    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int row = wave * 16 + k;
-      const float4 si = srow[row];
-      float h = si.x * pc + si.y * rc + si.w * tc + zc;
-      A0[row * GAS + lane] = h > 0.f ? h : 0.f;
-      A1[row * GAS + lane] = hh[k];
+      for (int i = 0; i < 8; ++i) {
+        const int row = wave * 16 + 2 * i + half1;
+        const float4 si = srow[row];
+        float hx = si.x * pc.x + si.y * rc.x + si.w * tc.x + zc.x;
+        float hy = si.x * pc.y + si.y * rc.y + si.w * tc.y + zc.y;
+        hx = hx > 0.f ? hx : 0.f;
+        hy = hy > 0.f ? hy : 0.f;
+        uint32_t h_, m_, l_;
+        gf_split2(hx, hy, h_, m_, l_);
+        const int o = gf_pidx(row, f1);
+        *reinterpret_cast<uint32_t*>(I0 + o) = h_;
+        *reinterpret_cast<uint32_t*>(I0 + PLN + o) = m_;
+        *reinterpret_cast<uint32_t*>(I0 + 2 * PLN + o) = l_;
+        gf_split2(hh[i].x, hh[i].y, h_, m_, l_);
+        *reinterpret_cast<uint32_t*>(I1 + o) = h_;
+        *reinterpret_cast<uint32_t*>(I1 + PLN + o) = m_;
+        *reinterpret_cast<uint32_t*>(I1 + 2 * PLN + o) = l_;
+      }
     }
+    __syncthreads();
 
     f32x16 acc;
-
-  // ---- G1: h2 = relu([hh|h1] W1 + a1*u + d1) -> A2 -----------------------------------------
-  DESCO_ACC_ZERO()
-  DESCO_WSTORE()
-  __syncthreads();
-  DESCO_WLOAD(g.w1 + 64, 128)
-  DESCO_MFMA_BLOCK(A1)
-  __syncthreads();
-  DESCO_WSTORE()
-  __syncthreads();
-  DESCO_WLOAD(g.wp, 128)
-  DESCO_MFMA_BLOCK(A0)
-  {
-    const float uc = g.u[col], dc = g.d1[col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const float v = acc[reg] + srow[row].z * uc + dc;
-      A2[row * GAS + col] = v > 0.f ? v : 0.f;
-    }
-  }
-  __syncthreads();
-  if (has_next) DESCO_STAGE2()
-  // ---- G2: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> A1 ----------------------------------
-  DESCO_ACC_ZERO()
-  DESCO_WSTORE()
-  __syncthreads();
-  DESCO_WLOAD(g.wp + 64, 128)
-  DESCO_MFMA_BLOCK(A0)
-  __syncthreads();
-  DESCO_WSTORE()
-  __syncthreads();
-  DESCO_WLOAD(g.w3, 64)
-  DESCO_MFMA_BLOCK(A2)
-  {
-    const float tpc = g.tp[col], zpc = g.zp[q * 64 + col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      const float v = acc[reg] + srow[row].w * tpc + zpc;
-      A1[row * GAS + col] = v > 0.f ? v : 0.1f * v;
-    }
-  }
-  __syncthreads();
-  if (has_next) DESCO_STAGE3(next)
-  // ---- G3: y2 = relu(y1 W3 + b3) -> three bf16 planes (hi, mid, lo) -------------------------
-  DESCO_ACC_ZERO()
-  DESCO_WSTORE()
-  __syncthreads();
-  // first W5 column group (64 n x 64 k, three planes): thread t moves 16 shorts of row n = t>>2
-  uint4 q0, q1, q2, q3, q4, q5;
-#define DESCO_W5LOAD(cg_)                                                                     \
-  {                                                                                           \
-    const short* s_ = g.w5s + ((int64_t)(64 * (cg_) + (tid >> 2))) * 64 + 16 * (tid & 3);     \
-    q0 = *reinterpret_cast<const uint4*>(s_);                                                 \
-    q1 = *reinterpret_cast<const uint4*>(s_ + 8);                                             \
-    q2 = *reinterpret_cast<const uint4*>(s_ + 256 * 64);                                      \
-    q3 = *reinterpret_cast<const uint4*>(s_ + 256 * 64 + 8);                                  \
-    q4 = *reinterpret_cast<const uint4*>(s_ + 2 * 256 * 64);                                  \
-    q5 = *reinterpret_cast<const uint4*>(s_ + 2 * 256 * 64 + 8);                              \
-  }
-#define DESCO_W5STORE()                                                                       \
-  {                                                                                           \
-    short* d_ = W5P + (tid >> 2) * PST + 16 * (tid & 3);                                      \
-    *reinterpret_cast<uint4*>(d_) = q0;                                                       \
-    *reinterpret_cast<uint4*>(d_ + 8) = q1;                                                   \
-    *reinterpret_cast<uint4*>(d_ + GT * PST) = q2;                                            \
-    *reinterpret_cast<uint4*>(d_ + GT * PST + 8) = q3;                                        \
-    *reinterpret_cast<uint4*>(d_ + 2 * GT * PST) = q4;                                        \
-    *reinterpret_cast<uint4*>(d_ + 2 * GT * PST + 8) = q5;                                    \
-  }
-  DESCO_W5LOAD(0)
-  DESCO_MFMA_BLOCK(A1)
-  {
-    const float bc = g.b3[col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      float v = acc[reg] + bc;
-      v = v > 0.f ? v : 0.f;
-      // truncation split: hi + mid + lo carries all 24 significand bits of v
-      const uint32_t uh = __float_as_uint(v) & 0xffff0000u;
-      const float r1 = v - __uint_as_float(uh);
-      const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
-      const float r2 = r1 - __uint_as_float(um);
-      short* d = Y2P + row * PST + col;
-      d[0] = (short)(uh >> 16);
-      d[GT * PST] = (short)(um >> 16);
-      d[2 * GT * PST] = (short)(__float_as_uint(r2) >> 16);
-    }
-  }
-  __syncthreads();
-  // ---- G4/G5: head partials  sum_c relu(y2 W5 + b5)[c] * w7[c], 4 column groups of 64 --------
-  float part[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) part[k] = 0.f;
-#pragma unroll
-  for (int cg = 0; cg < 4; ++cg) {
-    DESCO_ACC_ZERO()
-    DESCO_W5STORE()
+    const float4 sx = srow[xrow];          // (a0, b0, a1, x) of this lane's node
+    int xrow_e = xrow, fq_e = fq;          // epilogue addressing, not hoisted out of the item loop
+    asm volatile("" : "+v"(xrow_e), "+v"(fq_e));
+    // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) -> I1 -----------------------------------
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB0, I1)
+    GF_WSTORE(WB1)                         // block 1 (staging is dead)
+    GF_WLOAD(g.wps, 64, 128, 0, 0)
     __syncthreads();
-    if (cg < 3) DESCO_W5LOAD(cg + 1)
-    {
-      // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
-      const short* ya = Y2P + (wr * 32 + (lane & 31)) * PST + 8 * (lane >> 5);
-      const short* wb = W5P + (wc * 32 + (lane & 31)) * PST + 8 * (lane >> 5);
+    if (has_next) GF_STAGE2()
+    GF_MFMA_BLOCK(WB1, I0)
+    GF_WSTORE(WB0)                         // block 2
+    GF_WLOAD(g.wps, 64, 128, 0, 64)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ya + 16 * s4);
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ya + GT * PST + 16 * s4);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ya + 2 * GT * PST + 16 * s4);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wb + 16 * s4);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(wb + GT * PST + 16 * s4);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wb + 2 * GT * PST + 16 * s4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-      }
-    }
-    const float bc = g.b5[cg * 64 + col], wv = g.w7[cg * 64 + col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const float v = acc[reg] + bc;
-      part[reg] += (v > 0.f ? v : 0.f) * wv;
+    for (int rg = 0; rg < 4; ++rg) {
+      const int fb = fq_e + 8 * rg;
+      const float4 uc = *reinterpret_cast<const float4*>(cst + fb);
+      const float4 dc = *reinterpret_cast<const float4*>(cst + 64 + fb);
+      float v0 = acc[4 * rg] + sx.z * uc.x + dc.x, v1 = acc[4 * rg + 1] + sx.z * uc.y + dc.y;
+      float v2 = acc[4 * rg + 2] + sx.z * uc.z + dc.z, v3 = acc[4 * rg + 3] + sx.z * uc.w + dc.w;
+      v0 = v0 > 0.f ? v0 : 0.f;
+      v1 = v1 > 0.f ? v1 : 0.f;
+      v2 = v2 > 0.f ? v2 : 0.f;
+      v3 = v3 > 0.f ? v3 : 0.f;
+      GF_PUT4(I1, fb, v0, v1, v2, v3)
     }
     __syncthreads();
-  }
-#undef DESCO_W5LOAD
-#undef DESCO_W5STORE
-  // reduce the 64 column partials of every row through the (now free) A2 image
+    // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> I0 ---------------------------
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB0, I0)
+    GF_WSTORE(WB1)                         // block 3
+    GF_WLOAD(g.w3s, 64, 64, 0, 0)
+    __syncthreads();
+    if (has_next) GF_STAGE3(next)
+    GF_MFMA_BLOCK(WB1, I1)
+    GF_WSTORE(WB0)                         // block 4
+    GF_WLOAD(g.w5s, 256, 64, 0, 0)
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    A2[row * GAS + col] = part[reg];
-  }
-  __syncthreads();
-  {
-    const int row = tid >> 2, qt = tid & 3;
-    float s = 0.f;
+    for (int rg = 0; rg < 4; ++rg) {
+      const int fb = fq_e + 8 * rg;
+      const float4 tc4 = *reinterpret_cast<const float4*>(cst + 128 + fb);
+      const float4 zc4 = *reinterpret_cast<const float4*>(cst + 768 + fb);
+      float v0 = acc[4 * rg] + sx.w * tc4.x + zc4.x, v1 = acc[4 * rg + 1] + sx.w * tc4.y + zc4.y;
+      float v2 = acc[4 * rg + 2] + sx.w * tc4.z + zc4.z, v3 = acc[4 * rg + 3] + sx.w * tc4.w + zc4.w;
+      v0 = v0 > 0.f ? v0 : 0.1f * v0;
+      v1 = v1 > 0.f ? v1 : 0.1f * v1;
+      v2 = v2 > 0.f ? v2 : 0.1f * v2;
+      v3 = v3 > 0.f ? v3 : 0.1f * v3;
+      GF_PUT4(I0, fb, v0, v1, v2, v3)
+    }
+    __syncthreads();
+    // ---- block 4: y2 = relu(y1 W3 + b3) -> I1 ------------------------------------------------------
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB0, I0)
+    GF_WSTORE(WB1)                         // block 5 (W5 column group 0)
+    GF_WLOAD(g.w5s, 256, 64, 64, 0)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) s += A2[row * GAS + qt * 16 + c];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (qt == 0 && row < nrows) g.out[(n0 + row) * Q + q] = s + g.b7 + srow[row].w;
+    for (int rg = 0; rg < 4; ++rg) {
+      const int fb = fq_e + 8 * rg;
+      const float4 bc = *reinterpret_cast<const float4*>(cst + 192 + fb);
+      float v0 = acc[4 * rg] + bc.x, v1 = acc[4 * rg + 1] + bc.y;
+      float v2 = acc[4 * rg + 2] + bc.z, v3 = acc[4 * rg + 3] + bc.w;
+      v0 = v0 > 0.f ? v0 : 0.f;
+      v1 = v1 > 0.f ? v1 : 0.f;
+      v2 = v2 > 0.f ? v2 : 0.f;
+      v3 = v3 > 0.f ? v3 : 0.f;
+      GF_PUT4(I1, fb, v0, v1, v2, v3)
+    }
+    __syncthreads();
+    // ---- blocks 5..8: head partial  sum_c relu(y2 W5 + b5)[c] * w7[c], 4 column groups of 64 -------
+    float part = 0.f;
+#define GF_HEAD(cg_)                                                                        \
+  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                        \
+    const int fb = 64 * (cg_) + fq_e + 8 * rg;                                                \
+    const float4 bc = *reinterpret_cast<const float4*>(cst + 256 + fb);                     \
+    const float4 wv = *reinterpret_cast<const float4*>(cst + 512 + fb);                     \
+    const float v0 = acc[4 * rg] + bc.x, v1 = acc[4 * rg + 1] + bc.y;                       \
+    const float v2 = acc[4 * rg + 2] + bc.z, v3 = acc[4 * rg + 3] + bc.w;                   \
+    part += (v0 > 0.f ? v0 : 0.f) * wv.x + (v1 > 0.f ? v1 : 0.f) * wv.y +                   \
+            (v2 > 0.f ? v2 : 0.f) * wv.z + (v3 > 0.f ? v3 : 0.f) * wv.w;                    \
   }
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB1, I1)
+    GF_WSTORE(WB0)                         // block 6
+    GF_WLOAD(g.w5s, 256, 64, 128, 0)
+    GF_HEAD(0)
+    __syncthreads();
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB0, I1)
+    GF_WSTORE(WB1)                         // block 7
+    GF_WLOAD(g.w5s, 256, 64, 192, 0)
+    GF_HEAD(1)
+    __syncthreads();
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB1, I1)
+    GF_WSTORE(WB0)                         // block 8
+    GF_WLOAD(g.w1s, 64, 128, 0, 0)         // block 0 of the next item
+    GF_HEAD(2)
+    __syncthreads();
+    GF_ACC_ZERO()
+    GF_MFMA_BLOCK(WB0, I1)
+    GF_HEAD(3)
+#undef GF_HEAD
+    // fold the two lane halves (features 4h..4h+3 of every quad), then the two feature groups wn
+    part += __shfl_xor(part, 32, 64);
+    if (lane < 32) red[wn * GT + xrow] = part;
+    __syncthreads();
+    if (tid < nrows) g.out[(n0 + tid) * Q + q] = red[tid] + red[GT + tid] + g.b7 + srow[tid].w;
     if (!has_next) break;
     item = next;
-    __syncthreads();            // A2 / srow / rp are free again
+    __syncthreads();            // srow / rp / red / weight buffers are free again
   }
-#undef DESCO_STAGE1
-#undef DESCO_STAGE2
-#undef DESCO_STAGE3
+#undef GF_STAGE1
+#undef GF_STAGE2
+#undef GF_STAGE3
 }
 
-#undef DESCO_WLOAD
-#undef DESCO_WSTORE
-#undef DESCO_MFMA_BLOCK
-#undef DESCO_ACC_ZERO
+#undef GF_WLOAD
+#undef GF_WSTORE
+#undef GF_MFMA6
+#undef GF_MFMA_BLOCK
+#undef GF_FRAGS
+#undef GF_ACC_ZERO
+#undef GF_PUT4
 
 }  // namespace desco
 
@@ -433,20 +495,33 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                                       int64_t num_nodes, int num_q, const float* g1, const float* p,
                                       const float* z, const float* zp, const float* r,
                                       const float* t, const float* u, const float* tp,
-                                      const float* d1, const float* w1, const float* wp,
-                                      const float* w3, const float* b3, const float* w5,
-                                      const int16_t* w5_planes, const float* b5, const float* w7,
-                                      float b7, float* out, desco_stream_t stream) {
+                                      const float* d1, const int16_t* w1_planes,
+                                      const int16_t* wp_planes, const int16_t* w3_planes,
+                                      const float* b3, const int16_t* w5_planes, const float* b5,
+                                      const float* w7, float b7, float* out, desco_stream_t stream) {
   if (num_nodes == 0) return 0;
   auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
-  if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !w1 || !wp ||
-      !w3 || !b3 || !w5 || !w5_planes || !b5 || !w7 || !out || num_nodes < 0 || num_q < 1 || num_q > 65535 ||
-      mis16(scal4) || mis16(w1) || mis16(wp) || mis16(w3) || mis16(w5) || mis16(w5_planes))
+  auto mis8 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 7) != 0; };
+  if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !w1_planes ||
+      !wp_planes || !w3_planes || !b3 || !w5_planes || !b5 || !w7 || !out || num_nodes < 0 ||
+      num_q < 1 || num_q > 65535 || mis16(scal4) || mis16(w1_planes) || mis16(wp_planes) ||
+      mis16(w3_planes) || mis16(w5_planes) || mis8(p) || mis8(z) || mis8(r) || mis8(t))
     return fail(DESCO_EINVAL, "desco_gossip_fused_f32: bad argument");
   const int64_t bx = (num_nodes + GT - 1) / GT;
   if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f32: too many nodes");
   GossipFusedArgs a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z,
-                    zp, r, t, u, tp, d1, w1, wp, w3, b3, w5, reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out};
+                    zp, r, t, u, tp, d1,
+                    reinterpret_cast<const short*>(w1_planes), reinterpret_cast<const short*>(wp_planes),
+                    reinterpret_cast<const short*>(w3_planes), b3,
+                    reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out};
+  static bool attr_set = false;     // benign race: the attribute is idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)GOSSIP_LDS_BYTES);
+    if (e != hipSuccess) return fail((int)e, "desco_gossip_fused_f32: cannot size LDS");
+    attr_set = true;
+  }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -454,7 +529,8 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
       cus = v;
   }
   const int64_t nitems = bx * num_q;
-  const unsigned grid = (unsigned)(nitems < 2 * (int64_t)cus ? nitems : 2 * (int64_t)cus);
-  hipLaunchKernelGGL(gossip_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, bx);
+  const unsigned grid = (unsigned)(nitems < (int64_t)cus ? nitems : (int64_t)cus);
+  hipLaunchKernelGGL(gossip_fused_kernel, dim3(grid), dim3(GNT), GOSSIP_LDS_BYTES, (hipStream_t)stream,
+                     a, bx);
   return launch_status("desco_gossip_fused_f32");
 }

@@ -482,8 +482,9 @@ def pack_gossip(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     pk["fused_wp"] = pk["wtp"].t().contiguous()                 # [64,128]
     pk["fused_w3"] = gnn.post_mp[3].weight.contiguous()         # [64,64]  (already [out, in])
     pk["fused_w5"] = gnn.post_mp[5].weight.contiguous()         # [256,64]
-    if bf16_planes:
-        pk["fused_w5s"] = ops.split_bf16_planes(pk["fused_w5"])  # [3,256,64] bf16 planes (bf16x6)
+    if bf16_planes:     # bf16 planes (hi, mid, lo) of the n-major matrices: the fused kernel's operands
+        for k in ("fused_w1", "fused_wp", "fused_w3", "fused_w5"):
+            pk[k + "s"] = ops.split_bf16_planes(pk[k])
     pk["qcache"] = None
     return pk
 
@@ -530,8 +531,8 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
         v = {"g1": q["g1"], "p": q["p"], "z": q["z"], "zp": q["zp"], "r": q["r"], "t": q["t"],
              "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"],
              # the fused kernel takes n-major ([out, in]) weight blocks
-             "w1": pk["fused_w1"], "wp": pk["fused_wp"], "w3": pk["fused_w3"], "b3": b3,
-             "w5": pk["fused_w5"], "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
+             "w1s": pk["fused_w1s"], "wps": pk["fused_wps"], "w3s": pk["fused_w3s"], "b3": b3,
+             "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
         return ops.gossip_fused(scal4, batch.rowptr, batch.col, N, Q, v)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0

@@ -351,15 +351,15 @@ GOSSIP_FUSED_FLOPS_PER_ROW = 2.0 * 64 * (128 + 128 + 64) + 2.0 * 64 * 256
 
 def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
                  num_q: int, v: dict) -> torch.Tensor:
-    """One on-chip pass per (64-node tile, query): returns pred [N, Q] (see desco_hip.h)."""
+    """One on-chip pass per (128-node tile, query): returns pred [N, Q] (see desco_hip.h)."""
     out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
     L = _lib.lib()
-    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1", "wp", "w3", "b3", "w5", "w5s", "b5", "w7")
+    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1s", "wps", "w3s", "b3", "w5s", "b5", "w7")
     ptrs = []
     for n in names:
         if not v[n].is_contiguous():
             raise ValueError(f"gossip_fused: operand {n} must be contiguous")
-        ptrs.append(_dev(v[n], n, torch.int16 if n == "w5s" else torch.float32))
+        ptrs.append(_dev(v[n], n, torch.int16 if n in ("w1s", "wps", "w3s", "w5s") else torch.float32))
     rows = float(num_nodes) * num_q
     with _Timed("gossip_fused_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
                 rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):

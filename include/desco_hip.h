@@ -206,14 +206,14 @@ int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t
 /* Fused gossip stage (csrc/gossip_fused.hip), two launches for all queries:
  *  (1) desco_gossip_scalars_f32: scal4[i*Q+q] = (a0, b0, a1, x[i,q]) with
  *      a_l = g_l[q]*deg_lo(i) + (1-g_l[q])*deg_hi(i),  b0 = g0[q]*sum_{j<i} x[j,q] + (1-g0[q])*sum_{j>i} x[j,q]
- *  (2) desco_gossip_fused_f32: per tile of 64 nodes and one query, entirely on chip,
+ *  (2) desco_gossip_fused_f32: per tile of 128 nodes and one query, entirely on chip,
  *      h1 = relu(a0*p_q + b0*r + x*t + z_q);  hh = sum_j (j<i ? g1 : 1-g1)*h1_j;
  *      h2 = relu([hh|h1] w1 + a1*u + d1);  y1 = leaky_0.1([h1|h2] wp + x*tp + zp_q);
  *      y2 = relu(y1 w3 + b3);  out[i,q] = x + b7 + sum_c relu(y2 w5 + b5)[c]*w7[c]
- *      Weights are passed n-major (= torch's [out, in] layout of the folded matrices):
- *      w1, wp: [64,128]; w3: [64,64]; w5: [256,64]; w5_planes: [3][256][64] bf16 bit patterns =
- *      the truncation split w5 = hi + mid + lo (post_mp.5 runs as the fp32-accurate 6-product
- *      bf16 split of desco_gemm_bf16x6_f32).
+ *      The four weight matrices are passed N-MAJOR (torch's [out, in] layout of the folded
+ *      matrices: w1, wp [64,128]; w3 [64,64]; w5 [256,64]) and pre-split into bf16 planes by
+ *      desco_split_bf16x3_f32: w*_planes[3][out][in].  All GEMMs run as the fp32-accurate
+ *      6-product bf16 split of desco_gemm_bf16x6_f32.  p, z, r, t must be 8-byte aligned.
  * Replaces BaseGNN.forward (gossip) for every query: gnn_model.py:58-103, 230-260, 303-350 and the
  * loop of lightning_model.py:613-628; equals layer0 + gather + 4 GEMMs + rowdot of the unfused path. */
 int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
@@ -222,10 +222,11 @@ int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr,
 int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
                            int64_t num_nodes, int num_q, const float* g1, const float* p,
                            const float* z, const float* zp, const float* r, const float* t,
-                           const float* u, const float* tp, const float* d1, const float* w1,
-                           const float* wp, const float* w3, const float* b3, const float* w5,
-                           const int16_t* w5_planes, const float* b5, const float* w7, float b7,
-                           float* out, desco_stream_t stream);
+                           const float* u, const float* tp, const float* d1,
+                           const int16_t* w1_planes, const int16_t* wp_planes,
+                           const int16_t* w3_planes, const float* b3, const int16_t* w5_planes,
+                           const float* b5, const float* w7, float b7, float* out,
+                           desco_stream_t stream);
 
 /* K21 tail: out[r] = add[r] + sum_c y[r,c]*w[c] + b   (post_mp.7 with output_dim 1, then
  * pred = neigh_pred + gossip_pred, lightning_model.py:622-625) */
