@@ -70,6 +70,8 @@ struct ShmpArgs {
   int64_t ldy, ytab_row0;
   float* out;
   int64_t ldo;
+  int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
+  float slope;
 };
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -362,12 +364,15 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   int cur = 0;
   int* rp = rpb;
   int* ec = ecb;
-  {
+  if (S > 0) {                                             // S == 0: no CSR at all (plain row-wise Linear)
     const int nptr = nr * S + 1;
     for (int i = lane; i < nslot; i += 64)
       rp[i] = g.vrowptr[grow0 * S + (i < nptr ? i : nptr - 1)];
     const int eb = rp[0], ecnt = rp[WR * S] - eb;
     for (int i = lane; i < ecnt && i < WCAP; i += 64) ec[i] = g.vcol[eb + i];
+  } else if (lane == 0) {
+    rp[0] = 0;
+    rpb[RPN] = 0;
   }
   int ebase = rp[0];
 
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     const bool has_next = tn < ntiles && w0n < g.num_rows;
     const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
     int p0 = 0, p1 = 0, p2 = 0;
-    if (has_next) {
+    if (has_next && S > 0) {
       const int nptr = nrn * S + 1;
       const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
       p0 = src[lane < nptr ? lane : nptr - 1];
@@ -497,8 +502,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       if (r < nr_out) {
         const float v0 = acc0[reg], v1 = acc1[reg];
         float* o = g.out + (grow_out + r) * g.ldo + cl;
-        o[0] = v0 > 0.f ? v0 : 0.f;
-        o[32] = v1 > 0.f ? v1 : 0.f;
+        o[0] = apply_act(v0, g.act, g.slope);
+        o[32] = apply_act(v1, g.act, g.slope);
       }
     }
     if (!has_next) break;
@@ -552,13 +557,13 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const int32_t* vcol, int64_t row0, int64_t num_rows, int slots_stored,
                        int slots_mfma, int slots_table, const void* weights, const float* bias,
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                       desco_stream_t stream) {
+                       int act, float slope, desco_stream_t stream) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
-  if (!x || !vrowptr || !weights || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
+  if (!x || (!vrowptr && slots_stored > 0) || !weights || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
-      slots_stored < 1 || slots_stored > MAXS || slots_table > 2 || (slots_table > 0 && !ytab) ||
+      slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
       ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
       (slots_table > 0 && mis16(ytab)) || x == out)
     return fail(DESCO_EINVAL,
@@ -588,7 +593,9 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              ldy,
              ytab_row0,
              out,
-             ldo};
+             ldo,
+             act,
+             slope};
   hipStream_t st = (hipStream_t)stream;
   if (x6) {
     switch (slots_mfma) {
@@ -617,7 +624,7 @@ extern "C" int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* 
                                     desco_stream_t stream) {
   return desco::shmp_launch("desco_shmp_layer_f32", false, x, ldx, vrowptr, vcol, row0, num_rows,
                             slots_stored, slots_mfma, slots_table, wt, bias, ytab, ldy, ytab_row0, out,
-                            ldo, stream);
+                            ldo, DESCO_ACT_RELU, 0.f, stream);
 }
 
 extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
@@ -628,5 +635,16 @@ extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const in
                                            float* out, int64_t ldo, desco_stream_t stream) {
   return desco::shmp_launch("desco_shmp_layer_bf16x6_f32", true, x, ldx, vrowptr, vcol, row0,
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
-                            ldy, ytab_row0, out, ldo, stream);
+                            ldy, ytab_row0, out, ldo, DESCO_ACT_RELU, 0.f, stream);
+}
+
+// Row-wise Linear with K = 64 inputs on the same streaming machinery (no CSR, one resident weight
+// block, cross-tile prefetch): out[i, 0:64] = act(x[i, 0:64] * W^T + bias).  Wider outputs are
+// 64-column blocks (one launch each, out + 64 j with ldo = N): memory-shaped projections such as
+// the canonical table and post_mp.0 run at the HBM stream rate instead of a tiled GEMM's.
+extern "C" int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int16_t* w_planes,
+                                         const float* bias, int act, float slope, float* out,
+                                         int64_t ldo, int64_t num_rows, desco_stream_t stream) {
+  return desco::shmp_launch("desco_linear64_bf16x6_f32", true, x, ldx, nullptr, nullptr, 0, num_rows,
+                            0, 0, 0, w_planes, bias, nullptr, 0, 0, out, ldo, act, slope, stream);
 }

@@ -279,7 +279,7 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
                 entry["wt_mfma"] = torch.cat([blocks[0], blocks[1], blocks[4]], 0).contiguous()
                 entry["wt_tab"] = torch.cat([blocks[2], blocks[3]], 1).contiguous()      # [64,128]
                 if bf16_planes and GEMM_BF16X6:
-                    entry["wt_tab_nk"] = ops.split_bf16_planes(entry["wt_tab"].t())    # [3,128,64]
+                    entry["wt_tab_l64"] = ops.linear64_planes(entry["wt_tab"].t())     # [2,3,64,64]
             if bf16_planes and SHMP_BF16X6:
                 # n-major bf16 planes of the MFMA blocks for the x6 form of the fused layer (K <= 192)
                 for name in ("wt_mfma", "wt"):
@@ -293,18 +293,23 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
         return pk
     # n-major ([out, in]) pre-split operands of the bf16x6 GEMM
     pk["anchor_nk"] = (ops.split_bf16_planes(gnn.anchor_mlp[0].weight), gnn.anchor_mlp[0].bias.contiguous())
-    pk["post_nk"] = [(ops.split_bf16_planes(gnn.post_mp[i].weight), gnn.post_mp[i].bias.contiguous())
-                     for i in (0, 3, 5, 7)]
+    # (64-input layers run on the streaming row-wise kernel: planes per 64-column output block)
+    pk["post_nk"] = [((ops.linear64_planes(gnn.post_mp[i].weight) if gnn.post_mp[i].in_features == 64
+                       else ops.split_bf16_planes(gnn.post_mp[i].weight)),
+                      gnn.post_mp[i].bias.contiguous()) for i in (0, 3, 5, 7)]
     return pk
 
 
 def _post_mp(pk, pooled):
     if GEMM_BF16X6 and "post_nk" in pk:
+        def lin(a, w, b, act=ops.ACT_NONE, slope=0.0):
+            f = ops.linear64 if w.dim() == 4 else ops.gemm_split
+            return f(a, w, b, act=act, slope=slope)
         (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post_nk"]
-        h = ops.gemm_split(pooled, w0, b0, act=ops.ACT_LEAKY, slope=0.1)
-        h = ops.gemm_split(h, w3, b3, act=ops.ACT_RELU)
-        h = ops.gemm_split(h, w5, b5, act=ops.ACT_RELU)
-        return ops.gemm_split(h, w7, b7)
+        h = lin(pooled, w0, b0, ops.ACT_LEAKY, 0.1)
+        h = lin(h, w3, b3, ops.ACT_RELU)
+        h = lin(h, w5, b5, ops.ACT_RELU)
+        return lin(h, w7, b7)
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
     h = ops.gemm(pooled, w0, b0, act=ops.ACT_LEAKY, slope=0.1)
     h = ops.gemm(h, w3, b3, act=ops.ACT_RELU)
@@ -362,7 +367,7 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                     continue
                 e = pk["layers"][l][t]
                 if "wt_tab" in e:
-                    ytab = (ops.gemm_split(X[-1][Nc:], e["wt_tab_nk"]) if GEMM_BF16X6 else
+                    ytab = (ops.linear64(X[-1][Nc:], e["wt_tab_l64"]) if GEMM_BF16X6 else
                             ops.gemm(X[-1][Nc:], e["wt_tab"]))            # canonical rows x [W2|W3]
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2,
                                    e.get("wt_mfma_x6", e["wt_mfma"]) if SHMP_BF16X6 else e["wt_mfma"],

@@ -165,7 +165,7 @@ class NeighborhoodCountingModel(_LightningLike):
                 W1, b1 = self.count_model[0].weight, self.count_model[0].bias       # [256,128]
                 self._head_cache = (ver, {
                     "wt_t": W1[:, :H].t().contiguous(), "wt_q": W1[:, H:].t().contiguous(),
-                    "w_t_nk": ops.split_bf16_planes(W1[:, :H]), "w_q_nk": ops.split_bf16_planes(W1[:, H:]),
+                    "w_t_l64": ops.linear64_planes(W1[:, :H]), "w_q_nk": ops.split_bf16_planes(W1[:, H:]),
                     "b1": b1.contiguous(), "w2": self.count_model[2].weight[0].contiguous(),
                     "b2": float(self.count_model[2].bias[0])})
         return self._head_cache[1]
@@ -176,7 +176,7 @@ class NeighborhoodCountingModel(_LightningLike):
         hp = self._head_pack()
         from . import gnn_model as GM
         if GM.GEMM_BF16X6:
-            T = ops.gemm_split(emb_t, hp["w_t_nk"])                         # target half
+            T = ops.linear64(emb_t, hp["w_t_l64"])                         # target half
             Qh = ops.gemm_split(emb_q, hp["w_q_nk"], hp["b1"])              # query half + bias
         else:
             T = ops.gemm(emb_t, hp["wt_t"])

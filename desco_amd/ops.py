@@ -192,6 +192,36 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     return out
 
 
+def linear64_planes(w: torch.Tensor) -> torch.Tensor:
+    """[N/64, 3, 64, 64] int16: per 64-row block of a [N, 64] weight its bf16 planes (operand of
+    ``linear64``)."""
+    n, k = w.shape
+    assert k == 64 and n % 64 == 0
+    return torch.stack([split_bf16_planes(w[j:j + 64]) for j in range(0, n, 64)]).contiguous()
+
+
+def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             act: int = ACT_NONE, slope: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(x @ W.T + bias) for a [N, 64] weight given as ``linear64_planes(W)``: one streaming
+    launch per 64-column block of the output (memory-shaped projections, see desco_hip.h)."""
+    m = x.shape[0]
+    nb = planes.shape[0]
+    assert x.shape[1] == 64 and planes.shape[1:] == (3, 64, 64) and planes.dtype == torch.int16
+    if out is None:
+        out = torch.empty((m, 64 * nb), device=x.device, dtype=torch.float32)
+    xp, ldx = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    if bias is not None:
+        bias = bias.contiguous()
+    L = _lib.lib()
+    for j in range(nb):
+        with _Timed("shmp_layer_f32_kernel", 2.0 * m * 64 * 64, 512.0 * m, ("linear64", m)):
+            _lib.check(L.desco_linear64_bf16x6_f32(
+                xp, ldx, planes[j].data_ptr(), None if bias is None else bias.data_ptr() + 256 * j,
+                act, slope, op + 256 * j, ldo, m, _stream()), "linear64")
+    return out
+
+
 def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, coef: torch.Tensor,
                   act: int, slope: float, out: torch.Tensor,
                   extra: Optional[torch.Tensor] = None) -> torch.Tensor:

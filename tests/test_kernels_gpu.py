@@ -219,6 +219,21 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
 
+@pytest.mark.parametrize("m,n,act", [(1, 64, 0), (257, 128, 1), (5000, 256, 2), (70001, 128, 0)])
+def test_linear64_streaming(m, n, act):
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, 80, generator=g)[:, 8:72] * 3          # strided input view (ldx = 80)
+    w = torch.randn(n, 64, generator=g) / 8
+    bias = torch.randn(n, generator=g)
+    ref = x.double() @ w.double().T + bias.double()
+    ref = [ref, torch.relu(ref), torch.nn.functional.leaky_relu(ref, 0.1)][act]
+    xd = x.to(DEV)
+    got = ops.linear64(xd, ops.linear64_planes(w.to(DEV)), bias.to(DEV), act=act, slope=0.1)
+    _close(got, ref, rtol=1e-5, atol=1e-5)
+    nob = ops.linear64(xd, ops.linear64_planes(w.to(DEV)))
+    _close(nob, x.double() @ w.double().T, rtol=1e-5, atol=1e-5)
+
+
 def test_degree_affine():
     g = torch.Generator().manual_seed(11)
     n, S, row0 = 500, 4, 37

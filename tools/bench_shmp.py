@@ -28,9 +28,14 @@ def case(n, deg01, tab, sm=2, S=4, local=True):
     out = torch.empty(n, 64, device=DEV)
     ytab = torch.randn(nb, 128, device=DEV) if tab else None
     ptr, col = ptr.to(DEV), col.to(torch.int32).to(DEV)
-    ms = timeit(lambda: ops.shmp_layer(x, ptr, col, 0, n, S, sm, wt, bias, out, ytab=ytab, ytab_row0=0))
     fl = 2.0 * n * (sm + 1) * 4096
-    print(f"shmp n={n} sm={sm} deg/slot={deg01} table={tab} local={local}: {ms:.3f} ms {fl/ms/1e9:.1f} TF/s  {512.0*n/ms/1e6:.0f} GB/s(x+out)", flush=True)
+    for x6 in (False, True):
+        if x6 and sm > 2:
+            continue
+        w = ops.split_bf16_planes(wt.t().contiguous()) if x6 else wt
+        ms = timeit(lambda: ops.shmp_layer(x, ptr, col, 0, n, S, sm, w, bias, out, ytab=ytab, ytab_row0=0))
+        print(f"shmp{'-x6' if x6 else '   '} n={n} sm={sm} deg/slot={deg01} table={tab} local={local}: {ms:.3f} ms "
+              f"{fl/ms/1e9:.1f} TF/s  {512.0*n/ms/1e6:.0f} GB/s(x+out)", flush=True)
 
 if __name__ == "__main__":
     n = 4_000_000
