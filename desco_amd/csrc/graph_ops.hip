@@ -99,6 +99,48 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   out[b * ldo + c] = acc0;
 }
 
+// 64-column form (every pooling block of the SHMP path): a 16-lane group (float4 per lane) owns
+// one segment and keeps four row loads in flight; a wave serves four consecutive segments, so it
+// streams one contiguous row range.  Rows past the end of a segment re-read its last row and are
+// discarded (branch-free loads, one wait per four).
+__global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const int32_t* __restrict__ seg_ptr,
+                                                            int64_t num_seg,
+                                                            const float* __restrict__ extra,
+                                                            int64_t ld_extra, float* __restrict__ out,
+                                                            int64_t ldo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * 4 + (lane >> 4);
+  const bool live = b < num_seg;
+  const int r0 = live ? seg_ptr[b] : 0, r1 = live ? seg_ptr[b + 1] : 0;
+  const float* xc = x + 4 * (lane & 15);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  for (int r = r0; r < r1; r += 4) {
+    const int last = r1 - 1;
+    const float4 v0 = *reinterpret_cast<const float4*>(xc + (int64_t)r * ldx);
+    const float4 v1 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 1 < r1 ? r + 1 : last) * ldx);
+    const float4 v2 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 2 < r1 ? r + 2 : last) * ldx);
+    const float4 v3 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 3 < r1 ? r + 3 : last) * ldx);
+    const float m1 = r + 1 < r1 ? 1.f : 0.f, m2 = r + 2 < r1 ? 1.f : 0.f, m3 = r + 3 < r1 ? 1.f : 0.f;
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += r + 1 < r1 ? v1.x : 0.f; a1.y += r + 1 < r1 ? v1.y : 0.f;
+    a1.z += r + 1 < r1 ? v1.z : 0.f; a1.w += r + 1 < r1 ? v1.w : 0.f;
+    a2.x += r + 2 < r1 ? v2.x : 0.f; a2.y += r + 2 < r1 ? v2.y : 0.f;
+    a2.z += r + 2 < r1 ? v2.z : 0.f; a2.w += r + 2 < r1 ? v2.w : 0.f;
+    a3.x += r + 3 < r1 ? v3.x : 0.f; a3.y += r + 3 < r1 ? v3.y : 0.f;
+    a3.z += r + 3 < r1 ? v3.z : 0.f; a3.w += r + 3 < r1 ? v3.w : 0.f;
+    (void)m1; (void)m2; (void)m3;
+  }
+  if (!live) return;
+  float4 o = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                         (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  if (extra) {
+    const float4 e = *reinterpret_cast<const float4*>(extra + b * ld_extra + 4 * (lane & 15));
+    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+  }
+  *reinterpret_cast<float4*>(out + b * ldo + 4 * (lane & 15)) = o;
+}
+
 // count head, separable form of lightning_model.py:176-193, 210-221.
 // One thread per (b, q), 256-long dot product.  The Qh table is staged TRANSPOSED in LDS
 // ([c][32], consecutive q on consecutive banks: conflict-free), w2 is wave-uniform, the T row is a
@@ -186,6 +228,9 @@ __global__ __launch_bounds__(256) void rowdot_add_kernel(const float* __restrict
 // First SHMP layer when every node of a type carries the same input row (all-zero node features:
 // pre_mp output = its bias, workload.py:431-440): the aggregate of slot s is deg_s(i) * x0_src(s),
 // so the layer is  out[i] = act( coef[S] + sum_s deg_s(i) * coef[s] ) (+ extra[i]) -- no gather, no GEMM.
+// 16 lanes x float4 per row, four rows per wave and step, persistent grid-stride over row groups:
+// the coefficient rows stay in registers and every store is a full 256-B row.
+constexpr int DA_MAXS = 4;
 __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __restrict__ vrowptr,
                                                             int64_t row0, int64_t num_rows, int S,
                                                             const float* __restrict__ coef, int act,
@@ -193,20 +238,43 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
                                                             const float* __restrict__ extra,
                                                             int64_t ld_extra,
                                                             float* __restrict__ out, int64_t ldo) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-  if (i >= num_rows) return;
-  const int64_t v = (row0 + i) * S;
-  float acc = coef[S * 64 + lane];
-  int prev = vrowptr[v];
-  for (int s = 0; s < S; ++s) {
-    const int nxt = vrowptr[v + s + 1];
-    acc += (float)(nxt - prev) * coef[s * 64 + lane];
-    prev = nxt;
+  const int c4 = 4 * (threadIdx.x & 15);
+  float4 cf[DA_MAXS];
+#pragma unroll
+  for (int s = 0; s < DA_MAXS; ++s)
+    cf[s] = s < S ? *reinterpret_cast<const float4*>(coef + s * 64 + c4)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 c0 = *reinterpret_cast<const float4*>(coef + S * 64 + c4);
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < num_rows; i += stride) {
+    const int32_t* vp = vrowptr + (row0 + i) * S;
+    float4 acc = c0;
+    int prev = vp[0];
+#pragma unroll
+    for (int s = 0; s < DA_MAXS; ++s) {
+      if (s < S) {
+        const int nxt = vp[s + 1];
+        const float d = (float)(nxt - prev);
+        acc.x += d * cf[s].x;
+        acc.y += d * cf[s].y;
+        acc.z += d * cf[s].z;
+        acc.w += d * cf[s].w;
+        prev = nxt;
+      }
+    }
+    acc.x = apply_act(acc.x, act, slope);
+    acc.y = apply_act(acc.y, act, slope);
+    acc.z = apply_act(acc.z, act, slope);
+    acc.w = apply_act(acc.w, act, slope);
+    if (extra) {
+      const float4 e = *reinterpret_cast<const float4*>(extra + i * ld_extra + c4);
+      acc.x += e.x;
+      acc.y += e.y;
+      acc.z += e.z;
+      acc.w += e.w;
+    }
+    *reinterpret_cast<float4*>(out + (row0 + i) * ldo + c4) = acc;
   }
-  acc = apply_act(acc, act, slope);
-  if (extra) acc += extra[i * ld_extra + lane];
-  out[(row0 + i) * ldo + lane] = acc;
 }
 
 inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= INT32_MAX; }
@@ -244,6 +312,15 @@ extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,
   if (num_seg == 0) return 0;
   if (!seg_ptr || !out || num_seg < 0 || ncols <= 0)
     return fail(DESCO_EINVAL, "desco_segment_sum_f32: bad argument");
+  auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (ncols == 64 && ldx % 4 == 0 && ldo % 4 == 0 && al16(x) && al16(out) &&
+      (!extra || (ld_extra % 4 == 0 && al16(extra)))) {
+    const int64_t blocks64 = (num_seg + 15) / 16;
+    if (!grid_ok(blocks64)) return fail(DESCO_EINVAL, "desco_segment_sum_f32: too many segments");
+    hipLaunchKernelGGL(segment_sum64_kernel, dim3((unsigned)blocks64), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, seg_ptr, num_seg, extra, ld_extra, out, ldo);
+    return launch_status("desco_segment_sum_f32");
+  }
   const int nch = (ncols + 63) / 64;
   const int64_t blocks = (num_seg * nch + 3) / 4;
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_segment_sum_f32: too many segments");
@@ -312,10 +389,12 @@ extern "C" int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int
                                        const float* extra, int64_t ld_extra, float* out,
                                        int64_t ldo, desco_stream_t stream) {
   if (num_rows == 0) return 0;
-  if (!vrowptr || !coef || !out || row0 < 0 || num_rows < 0 || slots < 1 || slots > 8)
-    return fail(DESCO_EINVAL, "desco_degree_affine_f32: bad argument");
-  const int64_t blocks = (num_rows + 3) / 4;
-  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_degree_affine_f32: too many rows");
+  auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
+  if (!vrowptr || !coef || !out || row0 < 0 || num_rows < 0 || slots < 1 || slots > DA_MAXS ||
+      ldo % 4 || mis16(out) || mis16(coef) || (extra && (ld_extra % 4 || mis16(extra))))
+    return fail(DESCO_EINVAL, "desco_degree_affine_f32: bad argument (slots <= 4, 16-byte rows)");
+  int64_t blocks = (num_rows + 15) / 16;
+  if (blocks > 8 * 256) blocks = 8 * 256;
   hipLaunchKernelGGL(degree_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      vrowptr, row0, num_rows, slots, coef, act, slope, extra, ld_extra, out, ldo);
   return launch_status("desco_degree_affine_f32");
