@@ -29,6 +29,25 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   return v;
 }
 
+// Truncation split of two floats into their three bf16 terms (hi + mid + lo carries all 24
+// significand bits), packed per plane as (f0 | f1 << 16): the operand format of the bf16x6 kernels.
+// Written on 2-vectors so the two exact residual subtractions are one v_pk_add_f32 each.
+typedef float desco_f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t desco_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16x3(const float f0, const float f1, uint32_t& hi,
+                                              uint32_t& mid, uint32_t& lo) {
+  const desco_f2 f = {f0, f1};
+  const desco_u2 u = __builtin_bit_cast(desco_u2, f);
+  const desco_f2 a = f - __builtin_bit_cast(desco_f2, u & 0xffff0000u);
+  const desco_u2 v = __builtin_bit_cast(desco_u2, a);
+  const desco_f2 c = a - __builtin_bit_cast(desco_f2, v & 0xffff0000u);
+  const desco_u2 w = __builtin_bit_cast(desco_u2, c);
+  // v_perm_b32: bytes {2,3} of the first float, bytes {2,3} of the second
+  hi = __builtin_amdgcn_perm(u.y, u.x, 0x07060302u);
+  mid = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+  lo = __builtin_amdgcn_perm(w.y, w.x, 0x07060302u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -45,21 +45,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 constexpr int SBM = 128, SBK = 32, SST = 40;   // SST: plane row stride in bf16 (80 B)
 constexpr int APLANE = SBM * SST;              // elements per A plane
 
-// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane
-__device__ __forceinline__ void split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
-                                       uint32_t& lo) {
-  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
-  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
-  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
-  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
-  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
-  // v_perm_b32: bytes {2,3} of the first float, bytes {2,3} of the second
-  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
-}
-
 template <int WN>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
   constexpr int BN = 64 * WN, BPLANE = BN * SST;
@@ -130,8 +115,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
 #define DESCO_PUT(row_, v_)                                                                   \
   {                                                                                           \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                    \
-    split2(v_.x, v_.y, h0_, m0_, l0_);                                                        \
-    split2(v_.z, v_.w, h1_, m1_, l1_);                                                        \
+    split2_bf16x3(v_.x, v_.y, h0_, m0_, l0_);                                                        \
+    split2_bf16x3(v_.z, v_.w, h1_, m1_, l1_);                                                        \
     short* d_ = Ap + (row_)*SST + 4 * ac4;                                                    \
     *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                     \
     *reinterpret_cast<uint2*>(d_ + APLANE) = make_uint2(m0_, m1_);                            \

@@ -110,20 +110,6 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
   return row * 64 + ((((k >> 3) ^ (row >> 1)) & 7) << 3) + (k & 7);
 }
 
-// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane (truncation split)
-__device__ __forceinline__ void gf_split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
-                                          uint32_t& lo) {
-  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
-  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
-  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
-  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
-  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
-  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
-}
-
 // weight block (64 n x 64 k, three planes): thread t moves 8 bf16 of row n = t>>3, chunk t&7, per plane
 #define GF_WLOAD(base_, rows_total_, ldk_, nrow0_, koff_)                                          \
   {                                                                                                \
@@ -180,8 +166,8 @@ __device__ __forceinline__ void gf_split2(const float f0, const float f1, uint32
 #define GF_PUT4(img_, fb_, v0_, v1_, v2_, v3_)                                           \
   {                                                                                      \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                               \
-    gf_split2(v0_, v1_, h0_, m0_, l0_);                                                  \
-    gf_split2(v2_, v3_, h1_, m1_, l1_);                                                  \
+    split2_bf16x3(v0_, v1_, h0_, m0_, l0_);                                                  \
+    split2_bf16x3(v2_, v3_, h1_, m1_, l1_);                                                  \
     short* d_ = (img_) + gf_pidx(xrow_e, (fb_));                                           \
     *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                \
     *reinterpret_cast<uint2*>(d_ + PLN) = make_uint2(m0_, m1_);                          \
@@ -332,12 +318,12 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
         hx = hx > 0.f ? hx : 0.f;
         hy = hy > 0.f ? hy : 0.f;
         uint32_t h_, m_, l_;
-        gf_split2(hx, hy, h_, m_, l_);
+        split2_bf16x3(hx, hy, h_, m_, l_);
         const int o = gf_pidx(row, f1);
         *reinterpret_cast<uint32_t*>(I0 + o) = h_;
         *reinterpret_cast<uint32_t*>(I0 + PLN + o) = m_;
         *reinterpret_cast<uint32_t*>(I0 + 2 * PLN + o) = l_;
-        gf_split2(hh[i].x, hh[i].y, h_, m_, l_);
+        split2_bf16x3(hh[i].x, hh[i].y, h_, m_, l_);
         *reinterpret_cast<uint32_t*>(I1 + o) = h_;
         *reinterpret_cast<uint32_t*>(I1 + PLN + o) = m_;
         *reinterpret_cast<uint32_t*>(I1 + 2 * PLN + o) = l_;

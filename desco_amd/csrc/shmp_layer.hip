@@ -83,20 +83,6 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   a.w += b.w;
 }
 
-// two floats -> their (hi, mid, lo) bf16 terms packed as (f0 | f1 << 16) per plane (truncation split)
-__device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint32_t& hi, uint32_t& mid,
-                                            uint32_t& lo) {
-  const uint32_t u0 = __float_as_uint(f0), u1 = __float_as_uint(f1);
-  const float a0 = f0 - __uint_as_float(u0 & 0xffff0000u);
-  const float a1 = f1 - __uint_as_float(u1 & 0xffff0000u);
-  const uint32_t v0 = __float_as_uint(a0), v1 = __float_as_uint(a1);
-  const float c0 = a0 - __uint_as_float(v0 & 0xffff0000u);
-  const float c1 = a1 - __uint_as_float(v1 & 0xffff0000u);
-  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-  mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  lo = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);
-}
-
 // ---- gather machinery (macros: every temporary is a named register) ----------------
 // They use the enclosing scope's rp, ec, ebase, grow0, nr, xb, yb, zrow, g, S, g8, l8 and the
 // registers lo*/hi* (sums), u*/w* (loads in flight), c*/n* (cursors).
@@ -141,7 +127,7 @@ __device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint
 #define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
-    const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * g.ldx;                          \
+    const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDX;                          \
     u##it_##0 = *reinterpret_cast<const float4*>(p_);                                          \
     u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                                     \
   }
@@ -156,11 +142,11 @@ __device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
     const int i0_ = ec[k0_ ? ca_ : 0], i1_ = ec[k1_ ? na_ : 0];                             \
-    const float* p0_ = k0_ ? yb + (int64_t)i0_ * g.ldy : zrow;                              \
+    const float* p0_ = k0_ ? yb + (int64_t)i0_ * LDY : zrow;                              \
     u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                      \
     u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                                 \
     if (ST > 1) {                                                                           \
-      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * g.ldy : zrow;                       \
+      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * LDY : zrow;                       \
       w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                    \
       w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
     }                                                                                       \
@@ -237,8 +223,8 @@ __device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint
   {                                                                                        \
     if ((b_) < KB - 1) {                                                                   \
       DESCO_CURS(b_)                                                                       \
-      DESCO_ISSUE2(0, xb, g.ldx) DESCO_ISSUE2(1, xb, g.ldx)                                \
-      DESCO_ISSUE2(2, xb, g.ldx) DESCO_ISSUE2(3, xb, g.ldx)                                \
+      DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                \
+      DESCO_ISSUE2(2, xb, LDX) DESCO_ISSUE2(3, xb, LDX)                                \
     } else if ((b_) == KB - 1) {                                                           \
       DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1) DESCO_ISSUE_SELF(2) DESCO_ISSUE_SELF(3)      \
     } else {                                                                               \
@@ -258,8 +244,8 @@ __device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint
 #define DESCO_PUT_X6(av_, it_)                                                  \
   {                                                                             \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                      \
-    shmp_split2(av_.x, av_.y, h0_, m0_, l0_);                                   \
-    shmp_split2(av_.z, av_.w, h1_, m1_, l1_);                                   \
+    split2_bf16x3(av_.x, av_.y, h0_, m0_, l0_);                                   \
+    split2_bf16x3(av_.z, av_.w, h1_, m1_, l1_);                                   \
     short* d_ = Ap + ((it_) * 8 + g8) * APS + 4 * l8;                           \
     *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                       \
     *reinterpret_cast<uint2*>(d_ + WR * APS) = make_uint2(m0_, m1_);            \
@@ -313,8 +299,10 @@ __device__ __forceinline__ void shmp_split2(const float f0, const float f1, uint
         acc_[reg] += Aw[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * AH + cl];         \
   }
 
-// KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2), X6: bf16 6-product arithmetic
-template <int KB, int ST, bool X6>
+// KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2), X6: bf16 6-product arithmetic,
+// LD64: x rows are 64 floats and ytab rows 64*ST floats apart (the product path's layouts): source-row
+// addresses then need a shift instead of a 64-bit multiply per gathered row
+template <int KB, int ST, bool X6, bool LD64>
 __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WST = KB * 64 + 8;                         // weight plane row stride (shorts)
@@ -350,8 +338,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   const int nslot = WR * S + 1;                            // <= 129: at most 3 per lane
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
   constexpr int NB = KB + (ST > 0 ? 1 : 0);                // K blocks incl. the table pseudo block
+  const int64_t LDX = LD64 ? 64 : g.ldx, LDY = LD64 ? 64 * (ST > 0 ? ST : 1) : g.ldy;
   const float* xb = g.x + 4 * l8;
-  const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * g.ldy : nullptr;
+  const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * LDY : nullptr;
   const float* zrow = shmp_zero_row + 4 * l8;
   (void)yb;
 
@@ -419,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       // ---- complete the gather of block b ------------------------------------------------------
       DESCO_ZERO_SUMS()
       if (b < KB - 1) {
-        DESCO_FINISH(xb, g.ldx)
+        DESCO_FINISH(xb, LDX)
       } else if (b == KB - 1) {
         lo0 = u00; hi0 = u01; lo1 = u10; hi1 = u11;
         lo2 = u20; hi2 = u21; lo3 = u30; hi3 = u31;
@@ -429,14 +418,14 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
         int d0, d1, d2, d3, m0, m1, m2, m3;
         DESCO_CONSUME_TAB(0) DESCO_CONSUME_TAB(1) DESCO_CONSUME_TAB(2) DESCO_CONSUME_TAB(3)
         if (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3))) {
-          DESCO_COOP(0, yb, g.ldy) DESCO_COOP(1, yb, g.ldy) DESCO_COOP(2, yb, g.ldy)
-          DESCO_COOP(3, yb, g.ldy)
+          DESCO_COOP(0, yb, LDY) DESCO_COOP(1, yb, LDY) DESCO_COOP(2, yb, LDY)
+          DESCO_COOP(3, yb, LDY)
         }
         if (ST > 1 && __any((d0 < m0) | (d1 < m1) | (d2 < m2) | (d3 < m3))) {
           c0 = d0; c1 = d1; c2 = d2; c3 = d3;
           n0 = m0; n1 = m1; n2 = m2; n3 = m3;
-          DESCO_COOP(0, yb + 64, g.ldy) DESCO_COOP(1, yb + 64, g.ldy) DESCO_COOP(2, yb + 64, g.ldy)
-          DESCO_COOP(3, yb + 64, g.ldy)
+          DESCO_COOP(0, yb + 64, LDY) DESCO_COOP(1, yb + 64, LDY) DESCO_COOP(2, yb + 64, LDY)
+          DESCO_COOP(3, yb + 64, LDY)
         }
       }
       if (b == 0 && has_next) {
@@ -529,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 #undef DESCO_MFMA_HALF_X6
 #undef DESCO_TAB_HALF
 
-template <int KB, int ST, bool X6>
+template <int KB, int ST, bool X6, bool LD64>
 static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 8;
   constexpr size_t w_floats = X6 ? (size_t)3 * 64 * WST / 2 : (size_t)KB * 64 * 64;
@@ -537,20 +526,27 @@ static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   static_assert(shmem <= 160 * 1024, "SHMP layer: LDS budget exceeded");
   static bool attr_set = false;     // benign race: the attribute is idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6, LD64>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6>), dim3(grid), dim3(NW * 64), shmem, st, g);
+  hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6, LD64>), dim3(grid), dim3(NW * 64), shmem, st, g);
 }
 
 template <int KB, bool X6>
 static void shmp_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st);
+#define DESCO_ONE(ST_)                                         \
+  if (ld64)                                                    \
+    shmp_launch_one<KB, ST_, X6, true>(g, grid, st);           \
+  else                                                         \
+    shmp_launch_one<KB, ST_, X6, false>(g, grid, st);
   switch (g.st) {
-    case 0: shmp_launch_one<KB, 0, X6>(g, grid, st); break;
-    case 1: shmp_launch_one<KB, 1, X6>(g, grid, st); break;
-    default: shmp_launch_one<KB, 2, X6>(g, grid, st); break;
+    case 0: DESCO_ONE(0) break;
+    case 1: DESCO_ONE(1) break;
+    default: DESCO_ONE(2) break;
   }
+#undef DESCO_ONE
 }
 
 static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, const int32_t* vrowptr,

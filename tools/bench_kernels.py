@@ -54,8 +54,12 @@ def gemm_case(m, k1, k2, n, lda1=None, check=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only-anchor", action="store_true", help="just the 576x576 case (for counter passes)")
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.only_anchor:
+        gemm_case(750_000, 576, 0, 576)
+        return
     gemm_case(5_240_000, 256, 64, 64, check=args.check)          # SHMP count rows
     gemm_case(750_000, 128, 64, 64, lda1=256, check=args.check)  # SHMP canonical rows
     gemm_case(750_000, 576, 0, 576, check=args.check)            # anchor

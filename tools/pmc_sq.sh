@@ -1,8 +1,9 @@
 #!/bin/bash
 # Diagnostic SQ counter passes over one bench step (run on the GPU box via gpurun).
-# usage: tools/pmc_sq.sh <out-subdir under gpurun_out>
+# usage: tools/pmc_sq.sh <out-subdir under gpurun_out> ["script.py args" relative to the repo root]
 set -u
 OUT=${1:-sq}
+CMD=${2:-"bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES"
@@ -11,7 +12,7 @@ P3="SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COE
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $ROOT/gpurun_out/$OUT/p$i -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $ROOT/gpurun_out/$OUT/p$i.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d $ROOT/gpurun_out/$OUT/p$i -- python3 $ROOT/$CMD > $ROOT/gpurun_out/$OUT/p$i.log 2>&1
 done
 cd $ROOT
 python3 - "$OUT" <<'PY'
