@@ -70,6 +70,8 @@ struct ShmpArgs {
   int64_t ldy, ytab_row0;
   float* out;
   int64_t ldo;
+  float* out2;              // optional second copy of the output rows (row i - row0 of a [num_rows, *] view)
+  int64_t ldo2;
   int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
   float slope;
 };
@@ -490,9 +492,15 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
       if (r < nr_out) {
         const float v0 = acc0[reg], v1 = acc1[reg];
+        const float r0v = apply_act(v0, g.act, g.slope), r1v = apply_act(v1, g.act, g.slope);
         float* o = g.out + (grow_out + r) * g.ldo + cl;
-        o[0] = apply_act(v0, g.act, g.slope);
-        o[32] = apply_act(v1, g.act, g.slope);
+        o[0] = r0v;
+        o[32] = r1v;
+        if (g.out2) {        // e.g. the canonical rows' column block of the anchor-MLP operand
+          float* o2 = g.out2 + (grow_out - g.row0 + r) * g.ldo2 + cl;
+          o2[0] = r0v;
+          o2[32] = r1v;
+        }
       }
     }
     if (!has_next) break;
@@ -553,7 +561,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const int32_t* vcol, int64_t row0, int64_t num_rows, int slots_stored,
                        int slots_mfma, int slots_table, const void* weights, const float* bias,
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                       int act, float slope, desco_stream_t stream) {
+                       float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
@@ -561,7 +569,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
       slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
       ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
-      (slots_table > 0 && mis16(ytab)) || x == out)
+      (slots_table > 0 && mis16(ytab)) || x == out || x == out2)
     return fail(DESCO_EINVAL,
                 x6 ? "desco_shmp_layer_bf16x6_f32: bad argument (slots_mfma <= 2, slots_table <= 2)"
                    : "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
@@ -590,6 +598,8 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              ytab_row0,
              out,
              ldo,
+             out2,
+             ldo2,
              act,
              slope};
   hipStream_t st = (hipStream_t)stream;
@@ -617,10 +627,10 @@ extern "C" int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* 
                                     int slots_stored, int slots_mfma, int slots_table,
                                     const float* wt, const float* bias, const float* ytab,
                                     int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                                    desco_stream_t stream) {
+                                    float* out2, int64_t ldo2, desco_stream_t stream) {
   return desco::shmp_launch("desco_shmp_layer_f32", false, x, ldx, vrowptr, vcol, row0, num_rows,
                             slots_stored, slots_mfma, slots_table, wt, bias, ytab, ldy, ytab_row0, out,
-                            ldo, DESCO_ACT_RELU, 0.f, stream);
+                            ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream);
 }
 
 extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
@@ -628,10 +638,11 @@ extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const in
                                            int slots_stored, int slots_mfma, int slots_table,
                                            const int16_t* wt_planes, const float* bias,
                                            const float* ytab, int64_t ldy, int64_t ytab_row0,
-                                           float* out, int64_t ldo, desco_stream_t stream) {
+                                           float* out, int64_t ldo, float* out2, int64_t ldo2,
+                                           desco_stream_t stream) {
   return desco::shmp_launch("desco_shmp_layer_bf16x6_f32", true, x, ldx, vrowptr, vcol, row0,
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
-                            ldy, ytab_row0, out, ldo, DESCO_ACT_RELU, 0.f, stream);
+                            ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream);
 }
 
 // Row-wise Linear with K = 64 inputs on the same streaming machinery (no CSR, one resident weight
@@ -642,5 +653,5 @@ extern "C" int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int1
                                          const float* bias, int act, float slope, float* out,
                                          int64_t ldo, int64_t num_rows, desco_stream_t stream) {
   return desco::shmp_launch("desco_linear64_bf16x6_f32", true, x, ldx, nullptr, nullptr, 0, num_rows,
-                            0, 0, 0, w_planes, bias, nullptr, 0, 0, out, ldo, act, slope, stream);
+                            0, 0, 0, w_planes, bias, nullptr, 0, 0, out, ldo, nullptr, 0, act, slope, stream);
 }

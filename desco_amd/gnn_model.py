@@ -341,12 +341,15 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         for t, r0, r1, su in groups:
             if r1 <= r0:
                 continue
-            e = pk["layers"][0][t]
-            wt = e["wt"]                                        # [(su+1)*64, 64]
-            rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
-            rows += [torch.zeros(H, device=dev)] * (S - su)     # unused slots of this type
-            rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
-            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, torch.stack(rows).contiguous(),
+            ck = ("layer0_coef", t, S)
+            if ck not in pk:                                    # folded once per weight version
+                e = pk["layers"][0][t]
+                wt = e["wt"]                                    # [(su+1)*64, 64]
+                rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
+                rows += [torch.zeros(H, device=dev)] * (S - su)  # unused slots of this type
+                rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
+                pk[ck] = torch.stack(rows).contiguous()
+            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, pk[ck],
                               ops.ACT_RELU, 0.0, xn)
         X = [None, xn]
         first = 1
@@ -359,6 +362,12 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
             ops.linear_smallk(feat[r0:r1], wt, b, out=x[r0:r1])               # :231
         X = [x]
         first = 0
+    B = batch.num_graphs
+    P = H * (core.layer_num + 1)
+    # emb["canonical"] [B, P] (operand of the anchor MLP): the fused canonical launches write their
+    # column block directly (out2), so no concatenation pass is needed
+    direct_canon = FUSED_SHMP_LAYER and isinstance(batch, NeighborhoodBatch)
+    canon = torch.empty((B, P), device=dev) if direct_canon else None
     for l in range(first, core.layer_num):
         xn = torch.empty((N, H), device=dev)
         if FUSED_SHMP_LAYER:
@@ -374,7 +383,9 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                                    e["b"], xn, ytab=ytab, ytab_row0=Nc)
                 else:
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
-                                   e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn)
+                                   e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn,
+                                   out2=(canon[:, (l + 1) * H:(l + 2) * H]
+                                         if direct_canon and t == "canonical" else None))
         else:
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
             for t, r0, r1, su in groups:
@@ -383,12 +394,15 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                     ops.gemm(agg[r0:r1, :su * H], e["wt"], e["b"], a2=X[-1][r0:r1],
                              act=ops.ACT_RELU, out=xn[r0:r1])
         X.append(xn)
-    B = batch.num_graphs
-    P = H * (core.layer_num + 1)
     pooled = torch.empty((B, P), device=dev)
     if isinstance(batch, NeighborhoodBatch):
         c0 = x0["canonical"].expand(B, H) if const_input else X[0][Nc:]
-        canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)            # emb["canonical"] [B,P]
+        if direct_canon:
+            canon[:, :H] = c0
+            for l in range(1, first + 1):        # layers produced outside the fused launches
+                canon[:, l * H:(l + 1) * H] = X[l][Nc:]
+        else:
+            canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)        # emb["canonical"] [B,P]
         aw, ab = pk["anchor"]
         if GEMM_BF16X6:
             anch = ops.gemm_split(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
@@ -403,8 +417,10 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         out_l = pooled[:, l * H:(l + 1) * H]
         if xl is None:       # constant X_0: the segment sum is (rows in segment) * x0
             t0 = groups[0][0]
-            coef = torch.stack([x0[t0], torch.zeros(H, device=dev)]).contiguous()
-            ops.degree_affine(seg_ptr, 0, B, 1, coef, ops.ACT_NONE, 0.0, out_l, extra=extra)
+            ck = ("pool0_coef", t0)
+            if ck not in pk:
+                pk[ck] = torch.stack([x0[t0], torch.zeros(H, device=dev)]).contiguous()
+            ops.degree_affine(seg_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, out_l, extra=extra)
         else:
             ops.segment_sum(xl[:Nc], seg_ptr, B, extra=extra, out=out_l)
     return _post_mp(pk, pooled)                                            # :108

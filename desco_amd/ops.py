@@ -162,9 +162,10 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
 def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0: int,
                num_rows: int, slots_stored: int, slots_mfma: int, wt: torch.Tensor,
                bias: torch.Tensor, out: torch.Tensor, ytab: Optional[torch.Tensor] = None,
-               ytab_row0: int = 0) -> torch.Tensor:
+               ytab_row0: int = 0, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
     ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1.
+    ``out2`` [num_rows, >=64] (optional): second copy of the produced rows (see desco_hip.h).
     ``wt``: fp32 [(sm+1)*64, 64] (f32 MFMA) or int16 planes [3, 64, (sm+1)*64] =
     ``split_bf16_planes(wt.t())`` (fp32-accurate bf16x6 arithmetic, sm <= 2)."""
     x6 = wt.dtype == torch.int16
@@ -178,6 +179,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     if ytab is not None:
         st = ytab.shape[1] // 64
         yp, ldy = _rows(ytab, "ytab")
+    o2p, ldo2 = (None, 0) if out2 is None else _rows(out2, "out2")
     L = _lib.lib()
     fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
     # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
@@ -188,7 +190,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                       _dev(vcol, "vcol", torch.int32), row0, num_rows,
                       slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
                       _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
-                      op, ldo, _stream()), "shmp_layer")
+                      op, ldo, o2p, ldo2, _stream()), "shmp_layer")
     return out
 
 

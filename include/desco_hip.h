@@ -137,13 +137,16 @@ int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco
  * Wt: [(sm+1)*64, 64] row major.  "Table slots" are relations whose sources were already multiplied
  * by their weight block (ytab = x_src * [Wt_sm' | ...], ld ldy): (sum_j x_j) W = sum_j (x_j W).
  * x / out are indexed by the same global row ids as vrowptr; out must not alias x.
+ * out2 (optional, may be NULL): a second copy of the produced rows, row i stored at
+ * out2[(i - row0)*ldo2 ...] -- the canonical launches fill their column block of the anchor-MLP
+ * operand [B, 64*(layers+1)] this way instead of a separate concatenation pass.
  * Replaces SAGEConv.propagate + lin + to_hetero sum + updates + relu
  * (gnn_model.py:262-264, 273, 392-395) without materialising the aggregates. */
 int desco_shmp_layer_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
                          int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
                          int slots_table, const float* wt, const float* bias, const float* ytab,
-                         int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                         desco_stream_t stream);
+                         int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo, float* out2,
+                         int64_t ldo2, desco_stream_t stream);
 /* Same layer with the matrix work on the bf16 pipe at fp32 accuracy (the 6-product split of
  * desco_gemm_bf16x6_f32): wt_planes[3][64 n][(slots_mfma+1)*64 k] = desco_split_bf16x3_f32 of the
  * N-MAJOR folded weight (the transpose of desco_shmp_layer_f32's wt).  slots_mfma <= 2. */
@@ -151,8 +154,8 @@ int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrow
                                 const int32_t* vcol, int64_t row0, int64_t num_rows,
                                 int slots_stored, int slots_mfma, int slots_table,
                                 const int16_t* wt_planes, const float* bias, const float* ytab,
-                                int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                                desco_stream_t stream);
+                                int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo, float* out2,
+                                int64_t ldo2, desco_stream_t stream);
 
 /* Row-wise Linear with 64 inputs and 64 outputs on the fused layer's streaming machinery (bf16x6
  * arithmetic, fp32-accurate): out[i, 0:64] = act(x[i, 0:64] * W^T + bias), w_planes[3][64 n][64 k] =
