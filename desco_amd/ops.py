@@ -185,7 +185,8 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
-    with _Timed("shmp_layer_f32_kernel", fl, nb):
+    # profiler key = the device kernel's template instance (KB = sm + 1 weight blocks, ST table slots)
+    with _Timed(f"shmp_layer_f32_kernel<{slots_mfma + 1},{st},{'x6' if x6 else 'f32'}>", fl, nb):
         _lib.check(fn(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
                       _dev(vcol, "vcol", torch.int32), row0, num_rows,
                       slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
@@ -217,7 +218,7 @@ def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor]
         bias = bias.contiguous()
     L = _lib.lib()
     for j in range(nb):
-        with _Timed("shmp_layer_f32_kernel", 2.0 * m * 64 * 64, 512.0 * m, ("linear64", m)):
+        with _Timed("shmp_layer_f32_kernel<1,0,x6>", 2.0 * m * 64 * 64, 512.0 * m, ("linear64", m)):
             _lib.check(L.desco_linear64_bf16x6_f32(
                 xp, ldx, planes[j].data_ptr(), None if bias is None else bias.data_ptr() + 256 * j,
                 act, slope, op + 256 * j, ldo, m, _stream()), "linear64")

@@ -18,7 +18,12 @@ def load(path, cname):
         if r["Counter_Name"] != cname:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
-        k = k.split("<")[0]
+        if k.startswith("shmp_layer_f32_kernel<"):
+            # template <KB, ST, X6, LD64> -> the profiler key of desco_amd/ops.py
+            a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            k = f"shmp_layer_f32_kernel<{a[0]},{a[1]},{'x6' if a[2] == 'true' else 'f32'}>"
+        else:
+            k = k.split("<")[0]
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return agg
@@ -30,7 +35,7 @@ def main():
            "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction for 16 B/lane reads)",
            "kernels": {}}
     for k in sorted(f, key=lambda k: -f[k][1]):
-        if not k.endswith("_kernel"):
+        if "_kernel" not in k:
             continue
         fk = f[k][1] / f[k][0]
         wk = w[k][1] / w[k][0] if k in w and w[k][0] else 0.0
