@@ -72,6 +72,11 @@ def lib():
             raise DescoLibraryError(
                 f"{LIB_PATH} not found: the HIP extension is not built. desco_amd has no CPU or "
                 "PyTorch fallback; run `make -C desco_amd/csrc` (or __graft_entry__.build()).")
+        # PyTorch's wheel bundles its own HIP / HSA runtime.  It must be in the process BEFORE this
+        # library is opened, so that the library's libamdhip64 dependency resolves (by SONAME) to the
+        # runtime torch's tensors live in; opened first, it would pull in /opt/rocm's copy and the
+        # process would hold two runtimes ("no ROCm-capable device" from the second one).
+        import torch  # noqa: F401
         try:
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
