@@ -39,6 +39,9 @@ SIGNATURES = {
     "desco_degree_affine_f32": (c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i64, vp, i64, vp]),
     "desco_gemm_bf16x6_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
                                       vp, i64, i64, vp]),
+    "desco_gemm_bf16_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
+                                      vp, i64, i64, vp]),
+    "desco_round_bf16_f32": (c_int, [vp, i64, vp, vp]),
     "desco_segment_sum_f32": (c_int, [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
     "desco_count_head_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, f32, i32, vp, i64, i64, i32, vp]),
     "desco_scatter_rows_f32": (c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),

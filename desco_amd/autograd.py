@@ -13,6 +13,21 @@ import torch
 
 from . import ops
 
+# Matrix-product precision of the training path: "fp32" (v_mfma_f32_32x32x2_f32, the default) or
+# "bf16" (BASELINE config 3: operands rounded to nearest-even bf16, one v_mfma_f32_32x32x16_bf16
+# product per multiply-add, fp32 accumulation; activations, gathers, pooling, the loss, the weight
+# gradients' accumulation and the master weights stay fp32).
+PRECISION = "fp32"
+
+
+def set_precision(p: str) -> None:
+    global PRECISION
+    p = {"32": "fp32", "32-true": "fp32", "bf16-mixed": "bf16"}.get(str(p), str(p))
+    if p not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
+    PRECISION = p
+
+
 
 class GatherSum(torch.autograd.Function):
     """agg = csr_gather_sum(x); backward = gather over the transposed index (csr_t)."""
@@ -37,7 +52,11 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a1, a2, wt, bias, act, slope):
         wt = wt.contiguous()
-        c = ops.gemm(a1, wt, bias, a2=a2, act=act, slope=slope)
+        ctx.bf16 = PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0
+        if ctx.bf16:
+            c = ops.gemm_bf16(a1, ops.round_bf16(wt.t()), bias, a2=a2, act=act, slope=slope)
+        else:
+            c = ops.gemm(a1, wt, bias, a2=a2, act=act, slope=slope)
         ctx.save_for_backward(a1, a2 if a2 is not None else a1.new_empty(0), wt, c)
         ctx.has_a2, ctx.act, ctx.slope, ctx.has_bias = a2 is not None, act, slope, bias is not None
         return c
@@ -50,7 +69,10 @@ class Linear(torch.autograd.Function):
         da1 = da2 = dwt = dbias = None
         need_a1, need_a2 = ctx.needs_input_grad[0], ctx.has_a2 and ctx.needs_input_grad[1]
         if need_a1 or need_a2:
-            da = ops.gemm(dz, wt.t().contiguous())             # dA = dZ @ Wt^T  (k % 64 == 0)
+            if ctx.bf16:     # dA[m,k] = sum_n dZ[m,n] wt[k,n]: wt is already the n-major operand
+                da = ops.gemm_bf16(dz, ops.round_bf16(wt))
+            else:
+                da = ops.gemm(dz, wt.t().contiguous())         # dA = dZ @ Wt^T  (k % 64 == 0)
             if need_a1:
                 da1 = da[:, :k1]
             if need_a2:

@@ -48,6 +48,13 @@ __device__ __forceinline__ void split2_bf16x3(const float f0, const float f1, ui
   lo = __builtin_amdgcn_perm(w.y, w.x, 0x07060302u);
 }
 
+// two floats -> (bf16(f0) | bf16(f1) << 16), round to nearest even (v_cvt_pk_bf16_f32; NaN stays NaN)
+typedef __bf16 desco_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16_rne(const float f0, const float f1) {
+  const desco_f2 f = {f0, f1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, desco_bf2));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -45,12 +45,14 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 constexpr int SBM = 128, SBK = 32, SST = 40;   // SST: plane row stride in bf16 (80 B)
 constexpr int APLANE = SBM * SST;              // elements per A plane
 
-template <int WN>
+// NP = 3: hi/mid/lo planes and six products (fp32-accurate); NP = 1: one round-to-nearest bf16 plane
+// and one product (plain bf16 MFMA with fp32 accumulation, the bf16 training mode)
+template <int WN, int NP>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
   constexpr int BN = 64 * WN, BPLANE = BN * SST;
   extern __shared__ __attribute__((aligned(16))) short lds[];
   short* Ap = lds;                  // planes hi, mid, lo of the A chunk [128][40]
-  short* Bp = lds + 3 * APLANE;     // planes hi, mid, lo of the W chunk [BN][40]
+  short* Bp = lds + NP * APLANE;    // planes hi, mid, lo of the W chunk [BN][40]
 
   // block id -> (m tile, n tile): ids id, id+8, id+16, ... share an XCD (round-robin dispatch);
   // within an XCD the n tile runs fastest so an A row panel is fetched from HBM once per XCD.
@@ -99,28 +101,39 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
     ra3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);                           \
     const short* w_ = pw + k_;                                                                \
     rb00 = *reinterpret_cast<const uint4*>(w_);                                               \
-    rb01 = *reinterpret_cast<const uint4*>(w_ + wplane);                                      \
-    rb02 = *reinterpret_cast<const uint4*>(w_ + 2 * wplane);                                  \
+    if constexpr (NP == 3) {                                                                  \
+      rb01 = *reinterpret_cast<const uint4*>(w_ + wplane);                                    \
+      rb02 = *reinterpret_cast<const uint4*>(w_ + 2 * wplane);                                \
+    }                                                                                         \
     if constexpr (WN > 1) {                                                                   \
       rb10 = *reinterpret_cast<const uint4*>(w_ + wj);                                        \
-      rb11 = *reinterpret_cast<const uint4*>(w_ + wj + wplane);                               \
-      rb12 = *reinterpret_cast<const uint4*>(w_ + wj + 2 * wplane);                           \
+      if constexpr (NP == 3) {                                                                \
+        rb11 = *reinterpret_cast<const uint4*>(w_ + wj + wplane);                             \
+        rb12 = *reinterpret_cast<const uint4*>(w_ + wj + 2 * wplane);                         \
+      }                                                                                       \
     }                                                                                         \
     if constexpr (WN > 2) {                                                                   \
       rb20 = *reinterpret_cast<const uint4*>(w_ + 2 * wj);                                    \
-      rb21 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + wplane);                           \
-      rb22 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + 2 * wplane);                       \
+      if constexpr (NP == 3) {                                                                \
+        rb21 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + wplane);                         \
+        rb22 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + 2 * wplane);                     \
+      }                                                                                       \
     }                                                                                         \
   }
 #define DESCO_PUT(row_, v_)                                                                   \
   {                                                                                           \
-    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                    \
-    split2_bf16x3(v_.x, v_.y, h0_, m0_, l0_);                                                        \
-    split2_bf16x3(v_.z, v_.w, h1_, m1_, l1_);                                                        \
     short* d_ = Ap + (row_)*SST + 4 * ac4;                                                    \
-    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                     \
-    *reinterpret_cast<uint2*>(d_ + APLANE) = make_uint2(m0_, m1_);                            \
-    *reinterpret_cast<uint2*>(d_ + 2 * APLANE) = make_uint2(l0_, l1_);                        \
+    if constexpr (NP == 3) {                                                                  \
+      uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                  \
+      split2_bf16x3(v_.x, v_.y, h0_, m0_, l0_);                                               \
+      split2_bf16x3(v_.z, v_.w, h1_, m1_, l1_);                                               \
+      *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                   \
+      *reinterpret_cast<uint2*>(d_ + APLANE) = make_uint2(m0_, m1_);                          \
+      *reinterpret_cast<uint2*>(d_ + 2 * APLANE) = make_uint2(l0_, l1_);                      \
+    } else {                                                                                  \
+      *reinterpret_cast<uint2*>(d_) = make_uint2(pack2_bf16_rne(v_.x, v_.y),                  \
+                                                 pack2_bf16_rne(v_.z, v_.w));                 \
+    }                                                                                         \
   }
 #define DESCO_STORE_CHUNK()                                                                   \
   {                                                                                           \
@@ -130,17 +143,23 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
     DESCO_PUT(arow + 96, ra3)                                                                 \
     short* b_ = Bp + brow * SST + 8 * bpart;                                                  \
     *reinterpret_cast<uint4*>(b_) = rb00;                                                     \
-    *reinterpret_cast<uint4*>(b_ + BPLANE) = rb01;                                            \
-    *reinterpret_cast<uint4*>(b_ + 2 * BPLANE) = rb02;                                        \
+    if constexpr (NP == 3) {                                                                  \
+      *reinterpret_cast<uint4*>(b_ + BPLANE) = rb01;                                          \
+      *reinterpret_cast<uint4*>(b_ + 2 * BPLANE) = rb02;                                      \
+    }                                                                                         \
     if constexpr (WN > 1) {                                                                   \
       *reinterpret_cast<uint4*>(b_ + 64 * SST) = rb10;                                        \
-      *reinterpret_cast<uint4*>(b_ + 64 * SST + BPLANE) = rb11;                               \
-      *reinterpret_cast<uint4*>(b_ + 64 * SST + 2 * BPLANE) = rb12;                           \
+      if constexpr (NP == 3) {                                                                \
+        *reinterpret_cast<uint4*>(b_ + 64 * SST + BPLANE) = rb11;                             \
+        *reinterpret_cast<uint4*>(b_ + 64 * SST + 2 * BPLANE) = rb12;                         \
+      }                                                                                       \
     }                                                                                         \
     if constexpr (WN > 2) {                                                                   \
       *reinterpret_cast<uint4*>(b_ + 128 * SST) = rb20;                                       \
-      *reinterpret_cast<uint4*>(b_ + 128 * SST + BPLANE) = rb21;                              \
-      *reinterpret_cast<uint4*>(b_ + 128 * SST + 2 * BPLANE) = rb22;                          \
+      if constexpr (NP == 3) {                                                                \
+        *reinterpret_cast<uint4*>(b_ + 128 * SST + BPLANE) = rb21;                            \
+        *reinterpret_cast<uint4*>(b_ + 128 * SST + 2 * BPLANE) = rb22;                        \
+      }                                                                                       \
     }                                                                                         \
   }
 
@@ -168,26 +187,30 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 16 * s);
-        am[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + APLANE + 16 * s);
-        al[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 2 * APLANE + 16 * s);
+        if constexpr (NP == 3) {
+          am[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + APLANE + 16 * s);
+          al[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 2 * APLANE + 16 * s);
+        }
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const short* bt = bp + j * 32 * SST + 16 * s;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bt);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bt + BPLANE);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bt + 2 * BPLANE);
-        // smallest terms first; the two row tiles alternate so dependent MFMAs are never adjacent
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bm, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bm, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bh, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bh, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bm, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bm, acc[1][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bt + BPLANE);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bt + 2 * BPLANE);
+          // smallest terms first; the two row tiles alternate so dependent MFMAs are never adjacent
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bm, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bm, acc[1][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bh, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bh, acc[1][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bm, acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bm, acc[1][j], 0, 0, 0);
+        }
         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh, acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1][j], 0, 0, 0);
       }
@@ -227,6 +250,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
   }
 }
 
+// w[count] -> round-to-nearest-even bf16 bit patterns
+__global__ __launch_bounds__(256) void round_bf16_kernel(const float* __restrict__ w, int64_t count,
+                                                         short* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  out[i] = (short)(pack2_bf16_rne(w[i], 0.f) & 0xffffu);
+}
+
 // w[count] -> planes[3][count] (hi, mid, lo bf16 bit patterns of the truncation split)
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ w, int64_t count,
                                                             short* __restrict__ planes) {
@@ -242,13 +273,13 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   planes[2 * count + i] = (short)(__float_as_uint(r2) >> 16);
 }
 
-template <int WN>
+template <int WN, int NP>
 static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
   constexpr int BN = 64 * WN;
-  constexpr size_t lds_bytes = (size_t)(3 * APLANE + 3 * BN * SST) * sizeof(short);
+  constexpr size_t lds_bytes = (size_t)(NP * APLANE + NP * BN * SST) * sizeof(short);
   static bool configured = false;     // benign race: the attribute is idempotent
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_f32: cannot size LDS");
     configured = true;
@@ -257,31 +288,70 @@ static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
   const int ny = g.n / BN;
   const int64_t blocks = ((gm + 7) / 8) * 8 * ny;
   if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: m too large");
-  hipLaunchKernelGGL(gemm_split_kernel<WN>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, g,
+  hipLaunchKernelGGL((gemm_split_kernel<WN, NP>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, g,
                      gm, ny);
   return launch_status("desco_gemm_bf16x6_f32");
 }
 
 }  // namespace desco
 
+static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, int k1, const float* a2,
+                       int64_t lda2, int k2, const int16_t* w, int n, const float* bias,
+                       int bias_rows, const float* s, int ns, const float* ws, int act, float slope,
+                       float* c, int64_t ldc, int64_t m, desco_stream_t stream) {
+  using namespace desco;
+  if (m == 0) return 0;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (m < 0 || !a1 || !w || !c || k1 <= 0 || k1 % SBK || k2 < 0 || k2 % SBK || n <= 0 ||
+      n % 64 || (k2 > 0 && !a2) || ns < 0 || ns > 4 || (ns > 0 && (!s || !ws)) ||
+      (bias && bias_rows < 1) || lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) ||
+      (k2 > 0 && mis16(a2)) || mis16(w))
+    return fail(DESCO_EINVAL, who);
+  GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w), n, bias,
+                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m};
+  hipStream_t st = (hipStream_t)stream;
+  if (np == 3) {
+    if (n % 192 == 0) return launch_gemm_split<3, 3>(g, st);
+    if (n % 128 == 0) return launch_gemm_split<2, 3>(g, st);
+    return launch_gemm_split<1, 3>(g, st);
+  }
+  if (n % 192 == 0) return launch_gemm_split<3, 1>(g, st);
+  if (n % 128 == 0) return launch_gemm_split<2, 1>(g, st);
+  return launch_gemm_split<1, 1>(g, st);
+}
+
 extern "C" int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2,
                                      int64_t lda2, int k2, const int16_t* w_planes, int n,
                                      const float* bias, int bias_rows, const float* s, int ns,
                                      const float* ws, int act, float slope, float* c, int64_t ldc,
                                      int64_t m, desco_stream_t stream) {
+  return gemm_planes("desco_gemm_bf16x6_f32: bad argument (k%32, n%64, 16-byte alignment)", 3, a1, lda1,
+                     k1, a2, lda2, k2, w_planes, n, bias, bias_rows, s, ns, ws, act, slope, c, ldc, m,
+                     stream);
+}
+
+// Plain bf16 MFMA GEMM with fp32 accumulation and fp32 output (bf16 training mode): A is rounded
+// to nearest-even bf16 in the kernel, the weight arrives rounded (desco_round_bf16_f32), n-major.
+extern "C" int desco_gemm_bf16_f32(const float* a1, int64_t lda1, int k1, const float* a2,
+                                   int64_t lda2, int k2, const int16_t* w_bf16, int n,
+                                   const float* bias, int bias_rows, const float* s, int ns,
+                                   const float* ws, int act, float slope, float* c, int64_t ldc,
+                                   int64_t m, desco_stream_t stream) {
+  return gemm_planes("desco_gemm_bf16_f32: bad argument (k%32, n%64, 16-byte alignment)", 1, a1, lda1,
+                     k1, a2, lda2, k2, w_bf16, n, bias, bias_rows, s, ns, ws, act, slope, c, ldc, m,
+                     stream);
+}
+
+extern "C" int desco_round_bf16_f32(const float* w, int64_t count, int16_t* out,
+                                    desco_stream_t stream) {
   using namespace desco;
-  if (m == 0) return 0;
-  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (m < 0 || !a1 || !w_planes || !c || k1 <= 0 || k1 % SBK || k2 < 0 || k2 % SBK || n <= 0 ||
-      n % 64 || (k2 > 0 && !a2) || ns < 0 || ns > 4 || (ns > 0 && (!s || !ws)) ||
-      (bias && bias_rows < 1) || lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) ||
-      (k2 > 0 && mis16(a2)) || mis16(w_planes))
-    return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: bad argument (k%32, n%64, 16-byte alignment)");
-  GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w_planes), n, bias,
-                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m};
-  if (n % 192 == 0) return launch_gemm_split<3>(g, (hipStream_t)stream);
-  if (n % 128 == 0) return launch_gemm_split<2>(g, (hipStream_t)stream);
-  return launch_gemm_split<1>(g, (hipStream_t)stream);
+  if (count == 0) return 0;
+  if (count < 0 || !w || !out) return fail(DESCO_EINVAL, "desco_round_bf16_f32: bad argument");
+  const int64_t blocks = (count + 255) / 256;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_round_bf16_f32: count too large");
+  hipLaunchKernelGGL(round_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     count, reinterpret_cast<short*>(out));
+  return launch_status("desco_round_bf16_f32");
 }
 
 extern "C" int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes,

@@ -271,6 +271,47 @@ def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def round_bf16(w: torch.Tensor) -> torch.Tensor:
+    """int16 tensor of w's shape: round-to-nearest-even bf16 bit patterns (weight operand of
+    ``gemm_bf16``)."""
+    w = w.contiguous()
+    out = torch.empty(w.shape, device=w.device, dtype=torch.int16)
+    L = _lib.lib()
+    _lib.check(L.desco_round_bf16_f32(_dev(w, "w"), w.numel(), _dev(out, "out", torch.int16),
+                                      _stream()), "round_bf16")
+    return out
+
+
+def gemm_bf16(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act([a1 | a2] @ w.T + bias) with bf16 operands (A rounded in the kernel, ``w`` =
+    ``round_bf16(weight)`` of torch's [n, k1+k2], or a float weight rounded on the fly), fp32
+    accumulation and output: the matrix product of the bf16 training mode."""
+    if w.dtype != torch.int16:
+        w = round_bf16(w)
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == k1 + k2 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((m, n), device=a1.device, dtype=torch.float32)
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    op, ldo = _rows(out, "out")
+    bias_rows = 1
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_rows = 1 if bias.dim() == 1 else bias.shape[0]
+    L = _lib.lib()
+    kk = k1 + k2
+    with _Timed("gemm_bf16_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + m * n) + 2.0 * kk * n, (m, kk, n)):
+        _lib.check(L.desco_gemm_bf16_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(w, "w", torch.int16), n,
+                                         _opt(bias, "bias"), bias_rows, None, 0, None, act, slope,
+                                         op, ldo, m, _stream()), "gemm_bf16")
+    return out
+
+
 def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
                 extra: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

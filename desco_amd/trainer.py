@@ -25,7 +25,10 @@ class ModelCheckpoint:
 class Trainer:
     def __init__(self, max_epochs: int = 1, accelerator: str = "gpu", devices=None,
                  default_root_dir: str = ".", callbacks=None, strategy: Optional[str] = None,
-                 grad_reduce: str = "mean", **unused):
+                 grad_reduce: str = "mean", precision: str = "fp32", **unused):
+        # precision: "fp32" | "bf16" (Lightning's "32" / "bf16-mixed" spellings accepted): matrix
+        # products of the training step in fp32 or bf16 MFMA (desco_amd.autograd.set_precision)
+        self.precision = precision
         self.max_epochs = max_epochs
         self.root = default_root_dir
         self.callbacks = callbacks or []
@@ -64,6 +67,8 @@ class Trainer:
 
     # ---- API ----------------------------------------------------------------------------------
     def fit(self, model, datamodule):
+        from . import autograd as AG
+        AG.set_precision(self.precision)
         model.to(self.device)
         cfg = model.configure_optimizers()
         opt, sched = cfg["optimizer"], cfg["lr_scheduler"]

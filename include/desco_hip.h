@@ -130,6 +130,15 @@ int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2
                           int64_t ldc, int64_t m, desco_stream_t stream);
 int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco_stream_t stream);
 
+/* bf16 training mode (BASELINE config 3): the same GEMM contract with ONE bf16 product per
+ * multiply-add -- A is rounded to nearest-even bf16 inside the kernel, the N-MAJOR weight arrives
+ * rounded by desco_round_bf16_f32 (out[count] bf16 bit patterns); fp32 accumulation and output. */
+int desco_gemm_bf16_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+                        const int16_t* w_bf16, int n, const float* bias, int bias_rows,
+                        const float* s, int ns, const float* ws, int act, float slope, float* c,
+                        int64_t ldc, int64_t m, desco_stream_t stream);
+int desco_round_bf16_f32(const float* w, int64_t count, int16_t* out, desco_stream_t stream);
+
 /* Fused SHMP layer (K2-K7 in one launch; csrc/shmp_layer.hip).  For destination rows i in
  * [row0, row0+num_rows), with sm = slots_mfma <= 3, st = slots_table <= 2, S = slots_stored (sm+st <= S <= 4):
  *   out[i] = relu( sum_{s<sm} (sum_{e in vrow(i*S+s)} x[vcol[e]]) * Wt_s + x[i] * Wt_sm + bias

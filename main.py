@@ -69,7 +69,8 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
                                  save_last=True)
     neigh_trainer = Trainer(max_epochs=args_neighborhood.epoch_num, accelerator="gpu", devices=devices,
                             default_root_dir=args_neighborhood.model_path, callbacks=[neigh_ckpt],
-                            strategy="ddp" if len(devices) > 1 else None, grad_reduce="mean")
+                            strategy="ddp" if len(devices) > 1 else None, grad_reduce="mean",
+                            precision=getattr(args_opt, "precision", "fp32"))
     if train_neighborhood and neighborhood_checkpoint is None:
         neigh_model = NeighborhoodCountingModel(input_dim=args_neighborhood.input_dim,
                                                 hidden_dim=args_neighborhood.hidden_dim,
@@ -119,7 +120,7 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
                                       save_last=True)
         gossip_trainer = Trainer(max_epochs=args_gossip.epoch_num, accelerator="gpu", devices=devices[:1],
                                  default_root_dir=args_gossip.model_path, callbacks=[gossip_ckpt],
-                                 grad_reduce="sum")
+                                 grad_reduce="sum", precision=getattr(args_opt, "precision", "fp32"))
         gossip_model.to(gossip_trainer.device)
         gossip_model.set_query_emb(neigh_model.get_query_emb())
         if train_gossip:
@@ -184,9 +185,12 @@ if __name__ == "__main__":
     parse_neighborhood(parser)
     parse_gossip(parser)
     parser.add_argument("--data_root", type=str, default="data")
+    parser.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
+                        help="matrix-product precision of the training steps (bf16: BASELINE config 3)")
     args = parser.parse_args()
     print(args)
     args_neighborhood, args_gossip, args_opt = split_namespaces(args)
+    args_opt.precision = args.precision          # this build's flag (not in the reference's groups)
     assert args_neighborhood.use_hetero
     query_ids = gen_query_ids(query_size=[3, 4, 5])
     output_dir = args_opt.output_dir or os.path.join(

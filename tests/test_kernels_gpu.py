@@ -219,6 +219,24 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
 
+@pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (300, 128, 64, 128), (1000, 576, 0, 576), (4097, 64, 0, 192)])
+def test_gemm_bf16_rounds_operands_to_nearest_even(m, k1, k2, n):
+    """bf16 training GEMM == exact product of the RNE-bf16-rounded operands (fp32 accumulation)."""
+    g = torch.Generator().manual_seed(m + n + 1)
+    a1 = torch.randn(m, k1, generator=g) * 5
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    bias = torch.randn(n, generator=g)
+    A = a1 if a2 is None else torch.cat([a1, a2], 1)
+    Ar, wr = A.bfloat16().double(), w.bfloat16().double()
+    ref = torch.relu(Ar @ wr.T + bias.double())
+    got = ops.gemm_bf16(a1.to(DEV), w.to(DEV), bias.to(DEV), a2=None if a2 is None else a2.to(DEV),
+                        act=ops.ACT_RELU)
+    _close(got, ref, rtol=2e-5, atol=2e-4)
+    planes = ops.round_bf16(w.to(DEV))
+    assert torch.equal(planes.cpu(), w.bfloat16().view(torch.int16))
+
+
 @pytest.mark.parametrize("m,n,act", [(1, 64, 0), (257, 128, 1), (5000, 256, 2), (70001, 128, 0)])
 def test_linear64_streaming(m, n, act):
     g = torch.Generator().manual_seed(m + n)

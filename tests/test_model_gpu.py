@@ -213,6 +213,54 @@ def test_neighborhood_adam_steps_reduce_loss(setup):
     assert abs(float(val) - float(nm.train_forward(batch, 0))) < 1e-3
 
 
+def test_bf16_training_mode_tracks_fp32(setup):
+    """BASELINE config 3 (bf16 neighborhood training): matrix products with bf16-rounded operands.
+    Tolerance (stated): loss within 2 % of the fp32 step, every sizeable gradient tensor within
+    cosine 0.99 of its fp32 counterpart; Adam steps in bf16 mode reduce the loss."""
+    from desco_amd import autograd as AG
+    nm0, gm, qids, queries = setup
+    nm, _ = make_models(seed=0)
+    nm = nm.to(DEV)
+    nm.set_queries(qids)
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=41)[:14]), 4)
+    g = torch.Generator().manual_seed(4)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) ** 3 * 40)
+    batch = NeighborhoodBatch(part, DEV, y=y)
+    grads = {}
+    losses = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            AG.set_precision(prec)
+            nm.zero_grad()
+            loss = nm.train_forward(batch, 0)
+            loss.backward()
+            losses[prec] = float(loss)
+            grads[prec] = {n: p.grad.detach().clone() for n, p in nm.named_parameters() if p.grad is not None}
+        assert abs(losses["bf16"] - losses["fp32"]) <= 2e-2 * abs(losses["fp32"]), losses
+        worst = 1.0
+        for n, gref in grads["fp32"].items():
+            if float(gref.abs().max()) < 1e-6:
+                continue
+            cos = float(torch.nn.functional.cosine_similarity(gref.flatten(), grads["bf16"][n].flatten(), dim=0))
+            worst = min(worst, cos)
+            assert cos > 0.99, (n, cos)
+        print(f"[parity] bf16 training: loss {losses['bf16']:.5f} vs fp32 {losses['fp32']:.5f}; "
+              f"worst gradient cosine {worst:.5f}")
+        opt = nm.configure_optimizers()["optimizer"]
+        for pg in opt.param_groups:
+            pg["lr"] = 1e-3
+        hist = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = nm.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            hist.append(float(loss))
+        assert hist[-1] < hist[0], hist
+    finally:
+        AG.set_precision("fp32")
+
+
 def test_gossip_training_loss_and_gradients(setup):
     """GossipCountingModel.train_forward + backward vs torch autograd through the CPU oracle
     (lightning_model.py:585-608, 630-635)."""

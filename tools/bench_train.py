@@ -23,7 +23,11 @@ def main():
     ap.add_argument("--workload", default="syn_1827")
     ap.add_argument("--graphs", type=int, default=200)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--batch", type=int, default=512, help="neighborhoods per training step")
     args = ap.parse_args()
+    from desco_amd import autograd as AG
+    AG.set_precision(args.precision)
     dev = torch.device("cuda", 0)
     nm, gm = bench.build_models(dev)
     nm.set_queries(STANDARD_QUERY_IDS)
@@ -33,8 +37,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     Q = len(STANDARD_QUERY_IDS)
     batches = []
-    for b0 in range(0, part.num_neigh, 512):
-        p = part.slice(b0, b0 + 512)
+    for b0 in range(0, part.num_neigh, args.batch):
+        p = part.slice(b0, b0 + args.batch)
         y = torch.floor(torch.rand(p.num_neigh, Q, generator=g) ** 3 * 50)     # surrogate labels
         batches.append(NeighborhoodBatch(p, dev, y=y))
     batches = batches[:args.steps + 2]
@@ -56,7 +60,7 @@ def main():
         rows += b.num_rows
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"neighborhood training ({args.workload}-shaped, batch 512, fp32): {len(batches) - 2} steps, "
+    print(f"neighborhood training ({args.workload}-shaped, batch {args.batch}, {args.precision}): {len(batches) - 2} steps, "
           f"{n / dt:.0f} neighborhoods/s, {rows / dt / 1e6:.2f} M rows/s, {1e3 * dt / (len(batches) - 2):.1f} ms/step")
     # gossip
     x = torch.rand(gs.num_nodes, Q, generator=g) * 20
