@@ -204,7 +204,7 @@ def main():
             "neighborhoods_per_gpu": part.num_neigh, "neighborhood_rows_per_gpu": part.num_rows,
             "neighborhood_directed_edges_per_gpu": part.num_edges,
             "parallelism": f"dp{world} (graph sharding, no data-path collective)",
-            "host_partition_build_s": round(t_build, 3),
+            "partition_build_s": round(t_build, 3), "partition_backend": pipe.partition_backend,
             "launch_mode": "hipGraph replay" if args.graph else "eager launches",
         },
     }

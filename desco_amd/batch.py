@@ -69,9 +69,13 @@ class NeighborhoodBatch(_TrainIndexMixin):
         self.num_graphs = part.num_neigh
         self.num_count = part.num_count
         self.num_rows = part.num_rows
-        self.count_ptr = _i32(part.count_ptr, device)
-        self.vrowptr = _i32(part.vrowptr, device)
-        self.vcol = _i32(part.vcol, device)
+        da = getattr(part, "device_arrays", None)
+        if da is not None and _norm_device(da["device"]) == device:    # built on this device already
+            self.count_ptr, self.vrowptr, self.vcol = da["count_ptr"], da["vrowptr"], da["vcol"]
+        else:
+            self.count_ptr = _i32(part.count_ptr, device)
+            self.vrowptr = _i32(part.vrowptr, device)
+            self.vcol = _i32(part.vcol, device)
         self.input_dim = input_dim if node_feature is None else node_feature.shape[1]
         # None == all-zero features (ZeroNodeFeat, workload.py:431-440): pre_mp output is its bias
         self.node_feature = None if node_feature is None else node_feature.to(device).float()

@@ -124,3 +124,63 @@ def build_partition(graphs: GraphSet, depth: int = 4, quirk_batch: int = 0,
         L.desco_partition_free(handle)
     return NeighborhoodPartition(neigh_index, indicator.astype(bool), count_ptr, count_orig,
                                  vrowptr, vcol, depth, quirk_batch)
+
+
+def build_partition_device(graphs: GraphSet, depth: int = 4, device="cuda",
+                           num_waves: int = 0) -> NeighborhoodPartition:
+    """Same result as ``build_partition`` (quirk_batch = 0), computed on the GPU by
+    desco_partition_dev_* (csrc/partition_dev.hip).  The flat CSR is produced in
+    device memory; the returned object also carries host copies (the host-side API of
+    NeighborhoodPartition) and keeps the device tensors in ``device_arrays`` so that
+    ``NeighborhoodBatch`` does not upload them again.  Graphs too large for the per-wave LDS
+    workspace raise ``ValueError`` (use ``build_partition``)."""
+    import torch
+    L = _lib.lib()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("build_partition_device needs the MI355X (cuda) device; there is no CPU fallback")
+    V = graphs.num_nodes
+    sizes = np.diff(graphs.graph_ptr)
+    n_max = int(sizes.max()) if len(sizes) else 1
+    if graphs.rowptr[-1] > np.iinfo(np.int32).max:
+        raise ValueError("build_partition_device: more than 2^31 directed edges")
+    gp = torch.from_numpy(graphs.graph_ptr).to(dev)
+    node_graph = torch.from_numpy(graphs.node_graph_ids().astype(np.int32)).to(dev)
+    rowptr = torch.from_numpy(graphs.rowptr.astype(np.int32)).to(dev)
+    col = torch.from_numpy(graphs.col).to(dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if num_waves <= 0:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        num_waves = int(min(max(4, ((V + 3) // 4) * 4), cus * 16))
+    i32 = dict(device=dev, dtype=torch.int32)
+    i64 = dict(device=dev, dtype=torch.int64)
+    nsize, ecc, eck = (torch.empty(V, **i32) for _ in range(3))
+    _lib.check(L.desco_partition_dev_count(gp.data_ptr(), node_graph.data_ptr(), rowptr.data_ptr(),
+                                           col.data_ptr(), V, depth, n_max, num_waves,
+                                           nsize.data_ptr(), ecc.data_ptr(), eck.data_ptr(), st),
+               "desco_partition_dev_count")
+    b_index, row_off, eoc, eok = (torch.empty(V, **i64) for _ in range(4))
+    totals = torch.zeros(4, **i64)
+    _lib.check(L.desco_partition_dev_scan(nsize.data_ptr(), ecc.data_ptr(), eck.data_ptr(), V,
+                                          b_index.data_ptr(), row_off.data_ptr(), eoc.data_ptr(),
+                                          eok.data_ptr(), totals.data_ptr(), st),
+               "desco_partition_dev_scan")
+    B, Nc, Ec, Ek = (int(t) for t in totals.cpu())          # the one host sync: output sizes
+    neigh_index = torch.empty((B, 2), **i64)
+    indicator = torch.empty(V, device=dev, dtype=torch.uint8)
+    count_ptr = torch.empty(B + 1, **i32)
+    count_orig = torch.empty(Nc, **i32)
+    vrowptr = torch.empty(4 * (Nc + B) + 1, **i32)
+    vcol = torch.empty(Ec + Ek, **i32)
+    _lib.check(L.desco_partition_dev_fill(gp.data_ptr(), node_graph.data_ptr(), rowptr.data_ptr(),
+                                          col.data_ptr(), V, depth, n_max, num_waves,
+                                          b_index.data_ptr(), row_off.data_ptr(), eoc.data_ptr(),
+                                          eok.data_ptr(), B, Nc, Ec, Ek, neigh_index.data_ptr(),
+                                          indicator.data_ptr(), count_ptr.data_ptr(),
+                                          count_orig.data_ptr(), vrowptr.data_ptr(), vcol.data_ptr(), st),
+               "desco_partition_dev_fill")
+    part = NeighborhoodPartition(neigh_index.cpu().numpy(), indicator.cpu().numpy().astype(bool),
+                                 count_ptr.cpu().numpy(), count_orig.cpu().numpy(),
+                                 vrowptr.cpu().numpy(), vcol.cpu().numpy(), depth, 0)
+    part.device_arrays = {"device": dev, "count_ptr": count_ptr, "vrowptr": vrowptr, "vcol": vcol}
+    return part

@@ -15,7 +15,7 @@ import torch
 from . import ops
 from .batch import GossipBatch, NeighborhoodBatch
 from .graphs import GraphSet
-from .partition import NeighborhoodPartition, build_partition
+from .partition import NeighborhoodPartition, build_partition, build_partition_device
 
 
 def _split_by_budget(weights: np.ndarray, budget: int) -> List[int]:
@@ -36,13 +36,30 @@ class InferencePipeline:
     def __init__(self, neigh_model, gossip_model, graphs: GraphSet, depth: int = 4,
                  device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 6_000_000,
                  max_gossip_rows: int = 4_000_000, num_threads: int = 0,
-                 partition: Optional[NeighborhoodPartition] = None):
+                 partition: Optional[NeighborhoodPartition] = None,
+                 partition_backend: str = "device"):
         self.nm, self.gm = neigh_model, gossip_model
         self.graphs = graphs
         from .batch import _norm_device
         self.device = _norm_device(device)
         device = self.device
-        self.partition = partition or build_partition(graphs, depth, quirk_batch, num_threads)
+        # canonical partition: built on the GPU (csrc/partition_dev.hip) unless the PyG quirk
+        # emulation is requested or a graph exceeds the device builder's per-wave LDS workspace
+        # (then the host C++ builder, same output)
+        self.partition_backend = "given"
+        if partition is None:
+            partition = None
+            if partition_backend == "device" and quirk_batch == 0:
+                try:
+                    partition = build_partition_device(graphs, depth, device)
+                    self.partition_backend = "device"
+                except RuntimeError as e:
+                    if "does not fit the LDS workspace" not in str(e):
+                        raise
+            if partition is None:
+                partition = build_partition(graphs, depth, quirk_batch, num_threads)
+                self.partition_backend = "host"
+        self.partition = partition
         part = self.partition
         self.num_queries = None
         # neighborhood blocks by row budget

@@ -79,6 +79,36 @@ int desco_partition_export(const desco_partition* p, int64_t* neigh_index, uint8
                            int32_t* vcol);
 void desco_partition_free(desco_partition* p);
 
+/* ------------------------------------------------------------------------------------------
+ * DEVICE: the same canonical-partition builder on the GPU (csrc/partition_dev.hip), one wavefront
+ * per target node, output streamed into the flat 4-slot CSR in device memory.
+ * Inputs (device): graph_ptr[G+1] int64, node_graph[V] (graph id of every node), the CSR
+ * rowptr[V+1] / col over global node ids (int32; symmetric, loop-free, rows sorted ascending);
+ * n_max = nodes of the largest graph (sizes the per-wave LDS workspace: graphs above ~4400 nodes
+ * return DESCO_EINVAL -> use the host builder); num_waves (multiple of 4) = wavefronts to launch.
+ *   1. desco_partition_dev_count -> nsize[V] (0 = node skipped), ecnt_count[V], ecnt_canon[V]
+ *   2. desco_partition_dev_scan  -> exclusive scans b_index / row_off / eoff_count / eoff_canon [V]
+ *      and totals4 = (B, N_c, E_count, E_canon); the caller reads totals4 and allocates the outputs
+ *   3. desco_partition_dev_fill  -> neigh_index[B,2], indicator[V], count_ptr[B+1], count_orig[N_c],
+ *      vrowptr[4(N_c+B)+1], vcol[E]  -- bit-identical to desco_partition_export (quirk_batch = 0).
+ * ------------------------------------------------------------------------------------------ */
+int desco_partition_dev_count(const int64_t* graph_ptr, const int32_t* node_graph,
+                              const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int depth,
+                              int n_max, int num_waves, int32_t* nsize, int32_t* ecnt_count,
+                              int32_t* ecnt_canon, desco_stream_t stream);
+int desco_partition_dev_scan(const int32_t* nsize, const int32_t* ecnt_count,
+                             const int32_t* ecnt_canon, int64_t num_nodes, int64_t* b_index,
+                             int64_t* row_off, int64_t* eoff_count, int64_t* eoff_canon,
+                             int64_t* totals4, desco_stream_t stream);
+int desco_partition_dev_fill(const int64_t* graph_ptr, const int32_t* node_graph,
+                             const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int depth,
+                             int n_max, int num_waves, const int64_t* b_index, const int64_t* row_off,
+                             const int64_t* eoff_count, const int64_t* eoff_canon, int64_t num_neigh,
+                             int64_t num_count, int64_t edges_count, int64_t edges_canon,
+                             int64_t* neigh_index, uint8_t* indicator, int32_t* count_ptr,
+                             int32_t* count_orig, int32_t* vrowptr, int32_t* vcol,
+                             desco_stream_t stream);
+
 /* HOST: exact canonical (induced, symmetry-normalised) counts of connected query graphs with
  * 2..6 nodes for every node of every graph: out[v][q] = #{S : max(S) = v, G[S] isomorphic to q}.
  * Replaces the VF2 ground truth (workload.py:327-348 MatchSubgraphWorker divided by
