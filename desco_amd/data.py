@@ -118,6 +118,49 @@ def relabel(graphs: GraphSet, mode: str) -> GraphSet:
     return GraphSet.from_edge_lists(out)
 
 
+def read_syn_edgelist(edgelist_path: str, indicator_path: str) -> GraphSet:
+    """The reference's synthetic-dataset text format (``DeSCoSyntheticDataset``, data.py:644-750):
+    ``<name>_edgelist.txt`` = ``# nodes edges`` + one ``u v`` line per undirected edge with global
+    node ids, graph after graph; ``<name>_graph_indicator.txt`` = ``# graphs`` + the number of
+    edges of every graph.  As in ``process()`` (``from_networkx`` of ``add_edges_from``), a graph's
+    local node ids are the order of FIRST APPEARANCE of its nodes in its edge lines."""
+    edge_counts = [int(l) for l in open(indicator_path, "rt") if l.strip() and not l.startswith("#")]
+    graphs, g, local, edges = [], 0, {}, []
+    with open(edgelist_path, "rt") as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            while g < len(edge_counts) and edge_counts[g] == 0:      # (the generator never emits these)
+                graphs.append((0, []))
+                g += 1
+            a, b = line.split()[:2]
+            u = local.setdefault(int(a), len(local))
+            v = local.setdefault(int(b), len(local))
+            edges.append((u, v))
+            if len(edges) == edge_counts[g]:
+                graphs.append((len(local), edges))
+                g, local, edges = g + 1, {}, []
+    if edges or g != len(edge_counts):
+        raise ValueError(f"{edgelist_path}: edge lines do not add up to the graph indicator")
+    return GraphSet.from_edge_lists(graphs)
+
+
+def write_syn_edgelist(graphs: GraphSet, edgelist_path: str, indicator_path: str) -> None:
+    """Writer of the same format (``download()``, data.py:666-704): global ids, ``u < v`` per line."""
+    lists = graphs.edge_lists()
+    with open(edgelist_path, "w") as f:
+        f.write("# {:d} {:d}\n".format(graphs.num_nodes, sum(len(e) for _, e in lists)))
+        base = 0
+        for n, edges in lists:
+            for u, v in edges:
+                f.write("{} {}\n".format(base + u, base + v))
+            base += n
+    with open(indicator_path, "w") as f:
+        f.write("# {:d}\n".format(len(lists)))
+        for _, edges in lists:
+            f.write("{:d}\n".format(len(edges)))
+
+
 def load_data(dataset_name: str, root_folder="data", n_neighborhoods=-1, transform=None,
               train_split=0.25, val_split=0.25, test_split=0.5) -> GraphSet:
     """Target graphs by name, with the reference's name mini-DSL (data.py:104-137, 206-227):
@@ -142,8 +185,15 @@ def load_data(dataset_name: str, root_folder="data", n_neighborhoods=-1, transfo
             mode = m
             dataset_name = dataset_name.replace(suffix, "")
     raw = os.path.join(root_folder, dataset_name, "raw")
+    syn_name = None
+    if dataset_name.split("_")[0] == "Syn" and dataset_name.split("_")[1:2]:
+        # "Syn_<graph_num>" -> the reference's raw file names (data.py:188-197, 636-638)
+        syn_name = "Synthetic_size_min_10_max_500_graph_num_{:d}".format(int(dataset_name.split("_")[1]))
     if os.path.exists(os.path.join(raw, dataset_name + "_A.txt")):
         graphs = _read_tu_raw(raw, dataset_name)
+    elif syn_name and os.path.exists(os.path.join(raw, syn_name + "_edgelist.txt")):
+        graphs = read_syn_edgelist(os.path.join(raw, syn_name + "_edgelist.txt"),
+                                   os.path.join(raw, syn_name + "_graph_indicator.txt"))
     elif dataset_name in _SYNTHETIC_BY_NAME:
         from . import synthetic
         warnings.warn(f"{dataset_name}: no raw files under {raw}; using the seeded shape-matched "

@@ -131,3 +131,45 @@ def test_workload_bookkeeping(tmp_path):
     truth = torch.arange(11 * 2, dtype=torch.double).reshape(11, 2)
     nd.apply_truth_from_dataset(truth)
     assert torch.equal(nd.y, truth[torch.from_numpy(nd.nx_neighs_indicator)])
+
+
+def test_syn_edgelist_text_format_round_trip(tmp_path):
+    """The reference's synthetic-dataset text files (data.py:644-750): global ids, per-graph edge
+    counts; local ids = order of first appearance (from_networkx of add_edges_from)."""
+    import os
+    from desco_amd.data import load_data, read_syn_edgelist, write_syn_edgelist
+    from desco_amd.graphs import GraphSet
+    graphs = [(5, [(3, 4), (0, 3), (1, 0), (2, 1)]), (3, [(0, 2), (1, 2)]), (4, [(0, 1), (1, 2), (2, 3), (0, 3)])]
+    raw = tmp_path / "Syn_3" / "raw"
+    os.makedirs(raw)
+    name = "Synthetic_size_min_10_max_500_graph_num_3"
+    # hand-written file in the reference's layout (arbitrary line order inside a graph)
+    with open(raw / f"{name}_edgelist.txt", "w") as f:
+        f.write("# 12 10\n")
+        base = 0
+        for n, edges in graphs:
+            for u, v in edges:
+                f.write(f"{base + u} {base + v}\n")
+            base += n
+    with open(raw / f"{name}_graph_indicator.txt", "w") as f:
+        f.write("# 3\n" + "".join(f"{len(e)}\n" for _, e in graphs))
+    got = read_syn_edgelist(raw / f"{name}_edgelist.txt", raw / f"{name}_graph_indicator.txt")
+    # expected: relabel every graph by first appearance in its edge lines
+    exp = []
+    for n, edges in graphs:
+        order = {}
+        for u, v in edges:
+            order.setdefault(u, len(order))
+            order.setdefault(v, len(order))
+        exp.append((n, [(order[u], order[v]) for u, v in edges]))
+    ref = GraphSet.from_edge_lists(exp)
+    assert np.array_equal(got.graph_ptr, ref.graph_ptr)
+    assert np.array_equal(got.rowptr, ref.rowptr) and np.array_equal(got.col, ref.col)
+    # load_data finds the files under <root>/Syn_3/raw like the reference's DeSCoSyntheticDataset
+    via = load_data("Syn_3", root_folder=str(tmp_path))
+    assert np.array_equal(via.col, ref.col)
+    # writer -> reader is the identity up to the first-appearance relabelling of sorted edge lines
+    write_syn_edgelist(ref, raw / "w_edgelist.txt", raw / "w_graph_indicator.txt")
+    again = read_syn_edgelist(raw / "w_edgelist.txt", raw / "w_graph_indicator.txt")
+    assert again.num_graphs == 3 and again.num_nodes == 12
+    assert sorted(np.diff(again.rowptr).tolist()) == sorted(np.diff(ref.rowptr).tolist())
