@@ -43,15 +43,19 @@ class _TrainIndexMixin:
 
     def train_index(self):
         if getattr(self, "_train_index", None) is None:
-            vr = self.vrowptr.cpu().numpy()
-            vc = self.vcol.cpu().numpy()
-            t_rowptr, t_col = _transpose_index(vr, vc, self.num_rows)
-            seg_ptr = self._seg_ptr_host()
-            seg_id = np.repeat(np.arange(len(seg_ptr) - 1), np.diff(seg_ptr))
+            from . import ops
+            # both built on the device (desco_vcsr_transpose_sym / desco_segment_ids): the blocks
+            # are symmetric, so the transposed index is row-local (include/desco_hip.h)
+            num_count = getattr(self, "num_count", self.num_rows)
+            t_rowptr, t_col = ops.vcsr_transpose_sym(self.vrowptr, self.vcol, self.num_rows,
+                                                     self.slots, num_count)
+            seg_ptr = self._seg_ptr_device()
+            n_seg_rows = num_count if self.slots == 4 else self.num_rows
+            seg_id = ops.segment_ids(seg_ptr, n_seg_rows)
             dev = self.vrowptr.device
             self._train_index = {
-                "t_rowptr": _i32(t_rowptr, dev), "t_col": _i32(t_col, dev),
-                "seg_id": _i32(seg_id, dev), "ident_ptr": _i32(np.arange(len(seg_id) + 1), dev),
+                "t_rowptr": t_rowptr, "t_col": t_col, "seg_id": seg_id,
+                "ident_ptr": torch.arange(n_seg_rows + 1, device=dev, dtype=torch.int32),
             }
         return self._train_index
 
@@ -88,6 +92,9 @@ class NeighborhoodBatch(_TrainIndexMixin):
 
     def _seg_ptr_host(self):
         return self.part.count_ptr.astype(np.int64)
+
+    def _seg_ptr_device(self):
+        return self.count_ptr
 
     # PyG-style views -----------------------------------------------------------------------
     @property
@@ -155,6 +162,9 @@ class QueryBatch(_TrainIndexMixin):
 
     def _seg_ptr_host(self):
         return self.graph_ptr_host
+
+    def _seg_ptr_device(self):
+        return self.graph_ptr
 
 
 class GossipBatch:

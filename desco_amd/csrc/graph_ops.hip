@@ -277,6 +277,58 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
   }
 }
 
+// Transposed index of a SYMMETRIC S-slot virtual-row CSR (the backward gather's index), computed
+// row-locally: edge (dst j <- src k, slot s) has the mirror edge (dst k <- src j) in slot
+// 2*(j is canonical) + (s & 1) (the tride bit belongs to the undirected edge), so the virtual rows
+// that READ row j are { k*S + mirror_slot } over j's own sources k -- the same count, hence
+// t_rowptr[j] = vrowptr[S*j].  Ascending virtual-row order = ascending k: an S-way merge of the
+// row's S sorted slot lists (every neighbour sits in exactly one slot).  One thread per row.
+__global__ __launch_bounds__(256) void vcsr_transpose_sym_kernel(const int32_t* __restrict__ vrowptr,
+                                                                 const int32_t* __restrict__ vcol,
+                                                                 int64_t num_rows, int S,
+                                                                 int64_t num_count,
+                                                                 int32_t* __restrict__ t_rowptr,
+                                                                 int32_t* __restrict__ t_col) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > num_rows) return;
+  if (j == num_rows) {
+    t_rowptr[j] = vrowptr[S * num_rows];
+    return;
+  }
+  int c[4], n[4];
+  for (int s = 0; s < 4; ++s) {
+    c[s] = s < S ? vrowptr[S * j + s] : 0;
+    n[s] = s < S ? vrowptr[S * j + s + 1] : 0;
+  }
+  int out = c[0];
+  t_rowptr[j] = out;
+  const int jbit = (S == 4 && j >= num_count) ? 2 : 0;
+  for (;;) {
+    int best = -1, bk = 0x7fffffff;
+    for (int s = 0; s < S; ++s) {
+      if (c[s] < n[s]) {
+        const int k = vcol[c[s]];
+        if (k < bk) {
+          bk = k;
+          best = s;
+        }
+      }
+    }
+    if (best < 0) break;
+    const int ms = S == 4 ? jbit + (best & 1) : best;
+    t_col[out++] = bk * S + ms;
+    ++c[best];
+  }
+}
+
+// seg_id[r] = b for rows seg_ptr[b] <= r < seg_ptr[b+1] (one thread per segment)
+__global__ __launch_bounds__(256) void segment_ids_kernel(const int32_t* __restrict__ seg_ptr,
+                                                          int64_t num_seg, int32_t* __restrict__ seg_id) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= num_seg) return;
+  for (int r = seg_ptr[b]; r < seg_ptr[b + 1]; ++r) seg_id[r] = (int32_t)b;
+}
+
 inline bool grid_ok(int64_t blocks) { return blocks > 0 && blocks <= INT32_MAX; }
 
 }  // namespace desco
@@ -398,4 +450,28 @@ extern "C" int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int
   hipLaunchKernelGGL(degree_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      vrowptr, row0, num_rows, slots, coef, act, slope, extra, ld_extra, out, ldo);
   return launch_status("desco_degree_affine_f32");
+}
+
+extern "C" int desco_vcsr_transpose_sym(const int32_t* vrowptr, const int32_t* vcol, int64_t num_rows,
+                                        int slots, int64_t num_count, int32_t* t_rowptr,
+                                        int32_t* t_col, desco_stream_t stream) {
+  if (!vrowptr || !t_rowptr || num_rows < 0 || !(slots == 1 || slots == 2 || slots == 4) ||
+      num_count < 0 || num_count > num_rows)
+    return fail(DESCO_EINVAL, "desco_vcsr_transpose_sym: bad argument (slots in {1,2,4})");
+  const int64_t blocks = (num_rows + 1 + 255) / 256;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_vcsr_transpose_sym: too many rows");
+  hipLaunchKernelGGL(vcsr_transpose_sym_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, vrowptr, vcol, num_rows, slots, num_count, t_rowptr, t_col);
+  return launch_status("desco_vcsr_transpose_sym");
+}
+
+extern "C" int desco_segment_ids(const int32_t* seg_ptr, int64_t num_seg, int32_t* seg_id,
+                                 desco_stream_t stream) {
+  if (num_seg == 0) return 0;
+  if (!seg_ptr || !seg_id || num_seg < 0) return fail(DESCO_EINVAL, "desco_segment_ids: bad argument");
+  const int64_t blocks = (num_seg + 255) / 256;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_segment_ids: too many segments");
+  hipLaunchKernelGGL(segment_ids_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     seg_ptr, num_seg, seg_id);
+  return launch_status("desco_segment_ids");
 }

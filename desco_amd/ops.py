@@ -271,6 +271,32 @@ def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def vcsr_transpose_sym(vrowptr: torch.Tensor, vcol: torch.Tensor, num_rows: int, slots: int,
+                       num_count: Optional[int] = None):
+    """(t_rowptr [num_rows+1], t_col [E]): the backward gather's index of a symmetric virtual-row
+    CSR, built on the device (see desco_hip.h)."""
+    t_rowptr = torch.empty(num_rows + 1, device=vrowptr.device, dtype=torch.int32)
+    t_col = torch.empty(vcol.numel(), device=vrowptr.device, dtype=torch.int32)
+    L = _lib.lib()
+    _lib.check(L.desco_vcsr_transpose_sym(_dev(vrowptr, "vrowptr", torch.int32),
+                                          _dev(vcol, "vcol", torch.int32) if vcol.numel() else None,
+                                          num_rows, slots, num_rows if num_count is None else num_count,
+                                          _dev(t_rowptr, "t_rowptr", torch.int32),
+                                          _dev(t_col, "t_col", torch.int32) if vcol.numel() else None,
+                                          _stream()), "vcsr_transpose_sym")
+    return t_rowptr, t_col
+
+
+def segment_ids(seg_ptr: torch.Tensor, num_rows: int) -> torch.Tensor:
+    """seg_id [num_rows] int32 of contiguous segments (device)."""
+    out = torch.empty(num_rows, device=seg_ptr.device, dtype=torch.int32)
+    L = _lib.lib()
+    _lib.check(L.desco_segment_ids(_dev(seg_ptr, "seg_ptr", torch.int32), seg_ptr.numel() - 1,
+                                   _dev(out, "seg_id", torch.int32) if num_rows else None, _stream()),
+               "segment_ids")
+    return out
+
+
 def round_bf16(w: torch.Tensor) -> torch.Tensor:
     """int16 tensor of w's shape: round-to-nearest-even bf16 bit patterns (weight operand of
     ``gemm_bf16``)."""

@@ -215,6 +215,18 @@ int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_ro
                             const float* coef, int act, float slope, const float* extra,
                             int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream);
 
+/* Indices of the backward pass, built on the device (replaces the per-batch host transposes):
+ *  desco_vcsr_transpose_sym: the transposed index of a SYMMETRIC virtual-row CSR (every edge
+ *    dst<-src has its mirror src<-dst; true for canonical-partition blocks, query graphs and the
+ *    gossip CSR): t_rowptr[num_rows+1] (= vrowptr[slots*j]) and t_col[E] = the virtual rows
+ *    (k*slots + mirror slot) that read row j, ascending.  num_count: rows >= num_count are
+ *    canonical rows (only used for slots == 4; pass num_rows otherwise).
+ *  desco_segment_ids: seg_id[r] = b for seg_ptr[b] <= r < seg_ptr[b+1]. */
+int desco_vcsr_transpose_sym(const int32_t* vrowptr, const int32_t* vcol, int64_t num_rows, int slots,
+                             int64_t num_count, int32_t* t_rowptr, int32_t* t_col,
+                             desco_stream_t stream);
+int desco_segment_ids(const int32_t* seg_ptr, int64_t num_seg, int32_t* seg_id, desco_stream_t stream);
+
 /* K9  global_add_pool (gnn_model.py:107) over contiguous row segments, plus one optional extra row
  * per segment (the anchored canonical embedding, gnn_model.py:69-73, 88-89):
  * out[b, 0:ncols] = sum_{r in [seg_ptr[b], seg_ptr[b+1])} x[r, 0:ncols] + extra[b, 0:ncols]

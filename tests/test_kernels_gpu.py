@@ -252,6 +252,27 @@ def test_linear64_streaming(m, n, act):
     _close(nob, x.double() @ w.double().T, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("quirk", [0, 7])
+def test_device_transposed_index_matches_stable_sort(quirk):
+    """desco_vcsr_transpose_sym == stable argsort by source (batch._transpose_index) on canonical
+    partitions (4 slots, with and without the PyG-quirk edge drops) and on query blocks (2 slots)."""
+    from helpers import golden_graphs, standard_queries
+    from desco_amd.batch import NeighborhoodBatch, QueryBatch, _transpose_index
+    from desco_amd.graphs import GraphSet
+    from desco_amd.partition import build_partition
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=60)), 4, quirk_batch=quirk)
+    nb = NeighborhoodBatch(part, DEV)
+    qb = QueryBatch(standard_queries()[1], DEV)
+    for b in (nb, qb):
+        ti = b.train_index()
+        rp, tc = _transpose_index(b.vrowptr.cpu().numpy(), b.vcol.cpu().numpy(), b.num_rows)
+        assert np.array_equal(ti["t_rowptr"].cpu().numpy(), rp)
+        assert np.array_equal(ti["t_col"].cpu().numpy(), tc)
+        seg_ptr = b._seg_ptr_host()
+        seg_id = np.repeat(np.arange(len(seg_ptr) - 1), np.diff(seg_ptr))
+        assert np.array_equal(ti["seg_id"].cpu().numpy(), seg_id)
+
+
 def test_degree_affine():
     g = torch.Generator().manual_seed(11)
     n, S, row0 = 500, 4, 37

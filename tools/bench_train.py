@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=512, help="neighborhoods per training step")
+    ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event breakdown of the timed steps")
     args = ap.parse_args()
     from desco_amd import autograd as AG
     AG.set_precision(args.precision)
@@ -52,6 +53,9 @@ def main():
     for b in batches[:2]:
         step(b)
     torch.cuda.synchronize()
+    from desco_amd import ops
+    ops.PROFILER.enabled = args.profile
+    ops.PROFILER.reset()
     t0 = time.perf_counter()
     n = rows = 0
     for b in batches[2:]:
@@ -60,6 +64,13 @@ def main():
         rows += b.num_rows
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ops.PROFILER.enabled = False
+    if args.profile:
+        summ = ops.PROFILER.summary()
+        tot = sum(v["ms"] for v in summ.values())
+        print(f"profiled kernel time {tot / (len(batches) - 2):.1f} ms/step:")
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]:
+            print(f"   {k:32s} {v['calls'] // (len(batches) - 2):4d} launches/step {v['ms'] / (len(batches) - 2):7.2f} ms/step")
     print(f"neighborhood training ({args.workload}-shaped, batch {args.batch}, {args.precision}): {len(batches) - 2} steps, "
           f"{n / dt:.0f} neighborhoods/s, {rows / dt / 1e6:.2f} M rows/s, {1e3 * dt / (len(batches) - 2):.1f} ms/step")
     # gossip
