@@ -48,6 +48,7 @@ constexpr int AH = 33;        // half-K fp32 A image row stride (floats): confli
 constexpr int APS = 40;       // half-K bf16 plane row stride (shorts, 80 B): conflict-free ds_read_b128
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
+constexpr int EXTRA_STEPS = 5; // batched 2-source steps after the prefetched one (<= 12 sources per row)
 constexpr int WCAP = 128;     // source ids staged per wave (longer slices fall back to global)
 constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(32*33, 3*32*40/2) floats
 constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
@@ -205,12 +206,13 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
       m_ &= ~(0xffULL << (og_ * 8));                                                      \
     }                                                                                     \
   }
-// finish a gathered block whose first step is already in flight: consume it, one more batched
-// step for rows with 3-4 sources, then the cooperative path for what is left
+// finish a gathered block whose first step is already in flight: consume it, up to EXTRA_STEPS more
+// batched steps (two sources per row each: all four rows of a lane group advance together), then
+// the cooperative path for rows that are heavier still (one row at a time, the whole wave on it)
 #define DESCO_FINISH(base_, ld_)                                                           \
   {                                                                                        \
     DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)                \
-    if (DESCO_ANY_STAGED()) {                                                              \
+    for (int st_ = 0; st_ < EXTRA_STEPS && DESCO_ANY_STAGED(); ++st_) {                    \
       DESCO_ISSUE2(0, base_, ld_) DESCO_ISSUE2(1, base_, ld_)                              \
       DESCO_ISSUE2(2, base_, ld_) DESCO_ISSUE2(3, base_, ld_)                              \
       DESCO_CONSUME2(0) DESCO_CONSUME2(1) DESCO_CONSUME2(2) DESCO_CONSUME2(3)              \
@@ -552,7 +554,11 @@ static void shmp_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   switch (g.st) {
     case 0: DESCO_ONE(0) break;
     case 1: DESCO_ONE(1) break;
-    default: DESCO_ONE(2) break;
+    default:
+      if constexpr (KB <= 3) {           // sm + st <= 4 slots: four weight blocks leave room for one table slot
+        DESCO_ONE(2)
+      }
+      break;
   }
 #undef DESCO_ONE
 }
