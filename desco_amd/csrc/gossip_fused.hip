@@ -160,8 +160,15 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
     GF_MFMA6(awh_, awm_, awl_, axh_, axm_, axl_)                                                   \
     GF_MFMA6(bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                                   \
   }
-#define GF_ACC_ZERO() \
-  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[i_] = 0.f;
+// accumulators seeded with post_mp.5's bias of column group cg_
+#define GF_ACC_B5(cg_)                                                                      \
+  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                        \
+    const float4 bc = *reinterpret_cast<const float4*>(cst + 256 + 64 * (cg_) + fq_e + 8 * rg); \
+    acc[4 * rg] = bc.x;                                                                     \
+    acc[4 * rg + 1] = bc.y;                                                                 \
+    acc[4 * rg + 2] = bc.z;                                                                 \
+    acc[4 * rg + 3] = bc.w;                                                                 \
+  }
 // write 4 consecutive features (fb_ .. fb_+3) of node xrow as bf16 planes into image img_
 #define GF_PUT4(img_, fb_, v0_, v1_, v2_, v3_)                                           \
   {                                                                                      \
@@ -336,7 +343,16 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     int xrow_e = xrow, fq_e = fq;          // epilogue addressing, not hoisted out of the item loop
     asm volatile("" : "+v"(xrow_e), "+v"(fq_e));
     // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) -> I1 -----------------------------------
-    GF_ACC_ZERO()
+    // (the affine terms seed the accumulators, so an epilogue is activation + split only)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 uc = *reinterpret_cast<const float4*>(cst + fq_e + 8 * rg);
+      const float4 dc = *reinterpret_cast<const float4*>(cst + 64 + fq_e + 8 * rg);
+      acc[4 * rg] = sx.z * uc.x + dc.x;
+      acc[4 * rg + 1] = sx.z * uc.y + dc.y;
+      acc[4 * rg + 2] = sx.z * uc.z + dc.z;
+      acc[4 * rg + 3] = sx.z * uc.w + dc.w;
+    }
     GF_MFMA_BLOCK(WB0, I1)
     GF_WSTORE(WB1)                         // block 1 (staging is dead)
     GF_WLOAD(g.wps, 64, 128, 0, 0)
@@ -348,10 +364,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int fb = fq_e + 8 * rg;
-      const float4 uc = *reinterpret_cast<const float4*>(cst + fb);
-      const float4 dc = *reinterpret_cast<const float4*>(cst + 64 + fb);
-      float v0 = acc[4 * rg] + sx.z * uc.x + dc.x, v1 = acc[4 * rg + 1] + sx.z * uc.y + dc.y;
-      float v2 = acc[4 * rg + 2] + sx.z * uc.z + dc.z, v3 = acc[4 * rg + 3] + sx.z * uc.w + dc.w;
+      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
       v0 = v0 > 0.f ? v0 : 0.f;
       v1 = v1 > 0.f ? v1 : 0.f;
       v2 = v2 > 0.f ? v2 : 0.f;
@@ -360,7 +373,15 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     }
     __syncthreads();
     // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> I0 ---------------------------
-    GF_ACC_ZERO()
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 tc4 = *reinterpret_cast<const float4*>(cst + 128 + fq_e + 8 * rg);
+      const float4 zc4 = *reinterpret_cast<const float4*>(cst + 768 + fq_e + 8 * rg);
+      acc[4 * rg] = sx.w * tc4.x + zc4.x;
+      acc[4 * rg + 1] = sx.w * tc4.y + zc4.y;
+      acc[4 * rg + 2] = sx.w * tc4.z + zc4.z;
+      acc[4 * rg + 3] = sx.w * tc4.w + zc4.w;
+    }
     GF_MFMA_BLOCK(WB0, I0)
     GF_WSTORE(WB1)                         // block 3
     GF_WLOAD(g.w3s, 64, 64, 0, 0)
@@ -372,10 +393,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int fb = fq_e + 8 * rg;
-      const float4 tc4 = *reinterpret_cast<const float4*>(cst + 128 + fb);
-      const float4 zc4 = *reinterpret_cast<const float4*>(cst + 768 + fb);
-      float v0 = acc[4 * rg] + sx.w * tc4.x + zc4.x, v1 = acc[4 * rg + 1] + sx.w * tc4.y + zc4.y;
-      float v2 = acc[4 * rg + 2] + sx.w * tc4.z + zc4.z, v3 = acc[4 * rg + 3] + sx.w * tc4.w + zc4.w;
+      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
       v0 = v0 > 0.f ? v0 : 0.1f * v0;
       v1 = v1 > 0.f ? v1 : 0.1f * v1;
       v2 = v2 > 0.f ? v2 : 0.1f * v2;
@@ -384,16 +402,21 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     }
     __syncthreads();
     // ---- block 4: y2 = relu(y1 W3 + b3) -> I1 ------------------------------------------------------
-    GF_ACC_ZERO()
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 bc = *reinterpret_cast<const float4*>(cst + 192 + fq_e + 8 * rg);
+      acc[4 * rg] = bc.x;
+      acc[4 * rg + 1] = bc.y;
+      acc[4 * rg + 2] = bc.z;
+      acc[4 * rg + 3] = bc.w;
+    }
     GF_MFMA_BLOCK(WB0, I0)
     GF_WSTORE(WB1)                         // block 5 (W5 column group 0)
     GF_WLOAD(g.w5s, 256, 64, 64, 0)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int fb = fq_e + 8 * rg;
-      const float4 bc = *reinterpret_cast<const float4*>(cst + 192 + fb);
-      float v0 = acc[4 * rg] + bc.x, v1 = acc[4 * rg + 1] + bc.y;
-      float v2 = acc[4 * rg + 2] + bc.z, v3 = acc[4 * rg + 3] + bc.w;
+      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
       v0 = v0 > 0.f ? v0 : 0.f;
       v1 = v1 > 0.f ? v1 : 0.f;
       v2 = v2 > 0.f ? v2 : 0.f;
@@ -406,32 +429,31 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 #define GF_HEAD(cg_)                                                                        \
   _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                        \
     const int fb = 64 * (cg_) + fq_e + 8 * rg;                                                \
-    const float4 bc = *reinterpret_cast<const float4*>(cst + 256 + fb);                     \
     const float4 wv = *reinterpret_cast<const float4*>(cst + 512 + fb);                     \
-    const float v0 = acc[4 * rg] + bc.x, v1 = acc[4 * rg + 1] + bc.y;                       \
-    const float v2 = acc[4 * rg + 2] + bc.z, v3 = acc[4 * rg + 3] + bc.w;                   \
+    const float v0 = acc[4 * rg], v1 = acc[4 * rg + 1];                                     \
+    const float v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];                                 \
     part += (v0 > 0.f ? v0 : 0.f) * wv.x + (v1 > 0.f ? v1 : 0.f) * wv.y +                   \
             (v2 > 0.f ? v2 : 0.f) * wv.z + (v3 > 0.f ? v3 : 0.f) * wv.w;                    \
   }
-    GF_ACC_ZERO()
+    GF_ACC_B5(0)
     GF_MFMA_BLOCK(WB1, I1)
     GF_WSTORE(WB0)                         // block 6
     GF_WLOAD(g.w5s, 256, 64, 128, 0)
     GF_HEAD(0)
     __syncthreads();
-    GF_ACC_ZERO()
+    GF_ACC_B5(1)
     GF_MFMA_BLOCK(WB0, I1)
     GF_WSTORE(WB1)                         // block 7
     GF_WLOAD(g.w5s, 256, 64, 192, 0)
     GF_HEAD(1)
     __syncthreads();
-    GF_ACC_ZERO()
+    GF_ACC_B5(2)
     GF_MFMA_BLOCK(WB1, I1)
     GF_WSTORE(WB0)                         // block 8
     GF_WLOAD(g.w1s, 64, 128, 0, 0)         // block 0 of the next item
     GF_HEAD(2)
     __syncthreads();
-    GF_ACC_ZERO()
+    GF_ACC_B5(3)
     GF_MFMA_BLOCK(WB0, I1)
     GF_HEAD(3)
 #undef GF_HEAD
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 #undef GF_MFMA6
 #undef GF_MFMA_BLOCK
 #undef GF_FRAGS
-#undef GF_ACC_ZERO
+#undef GF_ACC_B5
 #undef GF_PUT4
 
 }  // namespace desco
