@@ -109,6 +109,31 @@ def test_end_to_end_pipeline_vs_oracle(setup):
         torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
 
 
+def test_full_size_run_is_replica_invariant(setup):
+    """BASELINE config 2 at the benchmarked size (COX2-shaped x64 = 29 888 graphs, 1.2 M
+    neighborhoods, 9.5 M rows): size-independent properties -- every replica of a graph gets the
+    same counts wherever it sits in the launch (tiles, batches and blocks differ between replicas),
+    everything is finite, and replica 0 equals a stand-alone run of the 467-graph set."""
+    from desco_amd import synthetic
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    base = synthetic.WORKLOADS["cox2"]()
+    R = 64
+    big = InferencePipeline(nm, gm, base.replicate(R), depth=4, device=DEV).run()
+    small = InferencePipeline(nm, gm, base, depth=4, device=DEV).run()
+    G, Q = base.num_graphs, len(qids)
+    for key, per in (("graph_gossip_count", G), ("graph_neigh_count", G), ("node_count", base.num_nodes)):
+        x = big[key].reshape(R, per, Q)
+        assert torch.isfinite(x).all(), key
+        ref = small[key].reshape(1, per, Q)
+        assert float(ref.abs().max()) > 1.0 and float(ref.std()) > 0.0, key     # not a trivial output
+        scale = ref.abs().clamp_min(1.0)
+        worst = float(((x - ref).abs() / scale).max())
+        print(f"[property] {key}: worst replica deviation {worst:.2e} (relative to max(1, |count|)); "
+              f"max |count| {float(ref.abs().max()):.3e}")
+        assert worst < 1e-4, (key, worst)
+
+
 def test_fused_gossip_equals_unfused_incl_hubs(setup):
     """The on-chip gossip kernel vs the 7-launch path on a graph set with hub nodes whose tile
     holds more neighbour records than one staging pass (ECAP = 768)."""
