@@ -195,6 +195,8 @@ def main():
         "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "arithmetic": "fp32 in/out; matrix products as 6 bf16 MFMA products per multiply-add (3-way "
+                      "truncation split, fp32 accumulation): fp32-accurate, see DESIGN.md section 4",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}-shaped synthetic ({base.num_graphs} graphs) x{args.replicas} "
