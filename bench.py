@@ -43,8 +43,6 @@ def mfma_peak(kernel: str):
     if kernel == "gemm_f32_kernel" or kernel.endswith(",f32>"):
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
     if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>"):
-        if kernel == "shmp_layer_f32_kernel<1,0,x6>":
-            return None                  # the streaming row-wise Linear is HBM-shaped
         return PEAK_X6_TFLOPS, "v_mfma_f32_32x32x16_bf16 x 6 products (bf16x6, fp32-accurate)"
     return None
 

@@ -509,6 +509,95 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   }
 }
 
+// ---- streaming row-wise Linear, K = 64 (desco_linear64_bf16x6_f32) ---------------------------------
+// The layer kernel's self block on its own: no CSR, NJ resident 64x64 weight blocks (NJ output
+// column blocks per pass over x, so x is read once per NJ*64 outputs), rows of the next tile in
+// flight under the current tile's MFMAs and stores.
+struct Lin64Args {
+  const float* x;
+  int64_t ldx;
+  const short* wplanes;     // [NJ][3][64 n][64 k]
+  const float* bias;        // [NJ*64] or null
+  float* out;               // first of the NJ column blocks
+  int64_t ldo;
+  int64_t num_rows;
+  int act;
+  float slope;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WST = 72, WPL = 64 * WST;                  // one weight block: [3][64][72] shorts
+  constexpr int W_FLOATS = NJ * 3 * WPL / 2;
+  short* wbase = reinterpret_cast<short*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Aw = lds + W_FLOATS + wave * A_FLOATS;
+  short* Ap = reinterpret_cast<short*>(Aw);
+  for (int i = tid; i < NJ * 3 * 64 * 8; i += NW * 64) {   // [NJ*3*64 rows][8 chunks of 8 shorts]
+    const int row = i >> 3, ch = i & 7;
+    *reinterpret_cast<uint4*>(wbase + row * WST + 8 * ch) =
+        *reinterpret_cast<const uint4*>(g.wplanes + (int64_t)row * 64 + 8 * ch);
+  }
+  __syncthreads();
+  const int g8 = lane >> 3, l8 = lane & 7, cl = lane & 31;
+  const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
+  int64_t tile = blockIdx.x;
+  int64_t w0 = tile * (NW * WR) + wave * WR;
+  if (tile >= ntiles || w0 >= g.num_rows) return;
+  const float* xb = g.x + 4 * l8;
+  float4 u00, u01, u10, u11, u20, u21, u30, u31;
+#define DESCO_LIN_LOAD(it_)                                                        \
+  {                                                                                \
+    const int64_t r_ = w0 + (it_) * 8 + g8;                                        \
+    const float* p_ = xb + (r_ < g.num_rows ? r_ : g.num_rows - 1) * g.ldx;        \
+    u##it_##0 = *reinterpret_cast<const float4*>(p_);                              \
+    u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                         \
+  }
+  DESCO_LIN_LOAD(0) DESCO_LIN_LOAD(1) DESCO_LIN_LOAD(2) DESCO_LIN_LOAD(3)
+  for (;;) {
+    const float4 lo0 = u00, hi0 = u01, lo1 = u10, hi1 = u11, lo2 = u20, hi2 = u21, lo3 = u30, hi3 = u31;
+    const int64_t row_out = w0;
+    const int nr = (int)((g.num_rows - w0) < WR ? (g.num_rows - w0) : WR);
+    const int64_t tn = tile + gridDim.x;
+    const int64_t w0n = tn * (NW * WR) + wave * WR;
+    const bool has_next = tn < ntiles && w0n < g.num_rows;
+    if (has_next) {
+      tile = tn;
+      w0 = w0n;
+      DESCO_LIN_LOAD(0) DESCO_LIN_LOAD(1) DESCO_LIN_LOAD(2) DESCO_LIN_LOAD(3)
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const short* Wp = wbase + j * 3 * WPL;
+      f32x16 acc0, acc1;
+      {
+        const float bv0 = g.bias ? g.bias[64 * j + cl] : 0.f, bv1 = g.bias ? g.bias[64 * j + 32 + cl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc0[i] = bv0;
+          acc1[i] = bv1;
+        }
+      }
+      DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1) DESCO_PUT_X6(lo2, 2) DESCO_PUT_X6(lo3, 3)
+      DESCO_MFMA_HALF_X6(0, 0)
+      DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1) DESCO_PUT_X6(hi2, 2) DESCO_PUT_X6(hi3, 3)
+      DESCO_MFMA_HALF_X6(0, 1)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (r < nr) {
+          float* o = g.out + (row_out + r) * g.ldo + 64 * j + cl;
+          o[0] = apply_act(acc0[reg], g.act, g.slope);
+          o[32] = apply_act(acc1[reg], g.act, g.slope);
+        }
+      }
+    }
+    if (!has_next) break;
+  }
+#undef DESCO_LIN_LOAD
+}
+
 #undef DESCO_CUR
 #undef DESCO_CURS
 #undef DESCO_ISSUE2
@@ -651,13 +740,45 @@ extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const in
                             ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream);
 }
 
-// Row-wise Linear with K = 64 inputs on the same streaming machinery (no CSR, one resident weight
-// block, cross-tile prefetch): out[i, 0:64] = act(x[i, 0:64] * W^T + bias).  Wider outputs are
-// 64-column blocks (one launch each, out + 64 j with ldo = N): memory-shaped projections such as
-// the canonical table and post_mp.0 run at the HBM stream rate instead of a tiled GEMM's.
+// Row-wise Linear with K = 64 inputs (see linear64_kernel): out[i, 0:64*nb] = act(x[i, 0:64] * W^T + bias),
+// w_planes = nb blocks [3][64 n][64 k].  Two column blocks per pass over x where possible.
 extern "C" int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int16_t* w_planes,
-                                         const float* bias, int act, float slope, float* out,
-                                         int64_t ldo, int64_t num_rows, desco_stream_t stream) {
-  return desco::shmp_launch("desco_linear64_bf16x6_f32", true, x, ldx, nullptr, nullptr, 0, num_rows,
-                            0, 0, 0, w_planes, bias, nullptr, 0, 0, out, ldo, nullptr, 0, act, slope, stream);
+                                         int num_blocks, const float* bias, int act, float slope,
+                                         float* out, int64_t ldo, int64_t num_rows,
+                                         desco_stream_t stream) {
+  using namespace desco;
+  if (num_rows == 0 || num_blocks == 0) return 0;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (!x || !w_planes || !out || num_rows < 0 || num_blocks < 0 || ldx % 4 || mis16(x) ||
+      mis16(w_planes) || x == out)
+    return fail(DESCO_EINVAL, "desco_linear64_bf16x6_f32: bad argument");
+  const int64_t ntiles = (num_rows + NW * WR - 1) / (NW * WR);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  static bool attr_set = false;     // benign race: the attribute is idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear64_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear64_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  constexpr size_t wave_bytes = sizeof(float) * (size_t)NW * A_FLOATS;
+  for (int j = 0; j < num_blocks;) {
+    const int nj = num_blocks - j >= 2 ? 2 : 1;
+    Lin64Args a{x, ldx, reinterpret_cast<const short*>(w_planes) + (int64_t)j * 3 * 64 * 64,
+                bias ? bias + 64 * j : nullptr, out + 64 * j, ldo, num_rows, act, slope};
+    const size_t shmem = (size_t)nj * 3 * 64 * 72 * sizeof(short) + wave_bytes;
+    if (nj == 2)
+      hipLaunchKernelGGL(linear64_kernel<2>, dim3(grid), dim3(NW * 64), shmem, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(linear64_kernel<1>, dim3(grid), dim3(NW * 64), shmem, (hipStream_t)stream, a);
+    j += nj;
+  }
+  return launch_status("desco_linear64_bf16x6_f32");
 }

@@ -205,8 +205,8 @@ def linear64_planes(w: torch.Tensor) -> torch.Tensor:
 
 def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor] = None,
              act: int = ACT_NONE, slope: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act(x @ W.T + bias) for a [N, 64] weight given as ``linear64_planes(W)``: one streaming
-    launch per 64-column block of the output (memory-shaped projections, see desco_hip.h)."""
+    """out = act(x @ W.T + bias) for a [N, 64] weight given as ``linear64_planes(W)``: streaming
+    launches, two 64-column output blocks per pass over x (memory-shaped projections, see desco_hip.h)."""
     m = x.shape[0]
     nb = planes.shape[0]
     assert x.shape[1] == 64 and planes.shape[1:] == (3, 64, 64) and planes.dtype == torch.int16
@@ -217,11 +217,11 @@ def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor]
     if bias is not None:
         bias = bias.contiguous()
     L = _lib.lib()
-    for j in range(nb):
-        with _Timed("shmp_layer_f32_kernel<1,0,x6>", 2.0 * m * 64 * 64, 512.0 * m, ("linear64", m)):
-            _lib.check(L.desco_linear64_bf16x6_f32(
-                xp, ldx, planes[j].data_ptr(), None if bias is None else bias.data_ptr() + 256 * j,
-                act, slope, op + 256 * j, ldo, m, _stream()), "linear64")
+    with _Timed("linear64_kernel", 2.0 * m * 64 * 64 * nb, 256.0 * m * ((nb + 1) // 2) + 256.0 * m * nb,
+                ("linear64", m, nb)):
+        _lib.check(L.desco_linear64_bf16x6_f32(xp, ldx, _dev(planes, "planes", torch.int16), nb,
+                                               _opt(bias, "bias"), act, slope, op, ldo, m, _stream()),
+                   "linear64")
     return out
 
 

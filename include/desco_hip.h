@@ -196,14 +196,14 @@ int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrow
                                 int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo, float* out2,
                                 int64_t ldo2, desco_stream_t stream);
 
-/* Row-wise Linear with 64 inputs and 64 outputs on the fused layer's streaming machinery (bf16x6
- * arithmetic, fp32-accurate): out[i, 0:64] = act(x[i, 0:64] * W^T + bias), w_planes[3][64 n][64 k] =
- * desco_split_bf16x3_f32 of the [out, in] block.  Memory-shaped projections (canonical table,
- * post_mp.0, count_model target half) are issued as one call per 64-column block of the output
- * (out + 64 j, ldo = N); x == out is not allowed. */
-int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int16_t* w_planes, const float* bias,
-                              int act, float slope, float* out, int64_t ldo, int64_t num_rows,
-                              desco_stream_t stream);
+/* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
+ * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);
+ * w_planes[num_blocks][3][64 n][64 k] = desco_split_bf16x3_f32 of every 64-row block of the
+ * [out, in] weight.  Memory-shaped projections (canonical table, post_mp.5, count_model target
+ * half): x is read once per two output blocks, rows stream at HBM rate.  x == out is not allowed. */
+int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int16_t* w_planes, int num_blocks,
+                              const float* bias, int act, float slope, float* out, int64_t ldo,
+                              int64_t num_rows, desco_stream_t stream);
 
 /* First SHMP layer (and first pooling block) when every node of a type has the same input row --
  * the default pipeline's all-zero node features (workload.py:431-440, transforms.py:380-384) make
