@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
 // (mostly broadcast) float4 global load.  Blocks stride over chunks of 256 (b, q) pairs so the
 // table is staged once per block.
 constexpr int HEAD_MAXQ = 32, HEAD_MAXHID = 256;
+// SLOPE01: 0 <= slope <= 1, where leaky(z) = max(z, slope*z) needs no compare/select
+template <bool SLOPE01>
 __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
                                                          const float* __restrict__ qh, int64_t ldq,
                                                          int hid, const float* __restrict__ w2,
@@ -171,10 +173,17 @@ __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict
       const float4 tv = tp[c];
       float z0 = tv.x + qp[(4 * c + 0) * HEAD_MAXQ], z1 = tv.y + qp[(4 * c + 1) * HEAD_MAXQ];
       float z2 = tv.z + qp[(4 * c + 2) * HEAD_MAXQ], z3 = tv.w + qp[(4 * c + 3) * HEAD_MAXQ];
-      z0 = z0 > 0.f ? z0 : z0 * slope;
-      z1 = z1 > 0.f ? z1 : z1 * slope;
-      z2 = z2 > 0.f ? z2 : z2 * slope;
-      z3 = z3 > 0.f ? z3 : z3 * slope;
+      if (SLOPE01) {
+        z0 = fmaxf(z0, z0 * slope);
+        z1 = fmaxf(z1, z1 * slope);
+        z2 = fmaxf(z2, z2 * slope);
+        z3 = fmaxf(z3, z3 * slope);
+      } else {
+        z0 = z0 > 0.f ? z0 : z0 * slope;
+        z1 = z1 > 0.f ? z1 : z1 * slope;
+        z2 = z2 > 0.f ? z2 : z2 * slope;
+        z3 = z3 > 0.f ? z3 : z3 * slope;
+      }
       a0 = fmaf(z0, w2[4 * c + 0], a0);
       a1 = fmaf(z1, w2[4 * c + 1], a1);
       a2 = fmaf(z2, w2[4 * c + 2], a2);
@@ -392,8 +401,14 @@ extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh
   int64_t blocks = (num_b * num_q + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_count_head_f32: too many rows");
-  hipLaunchKernelGGL(count_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo, num_b, num_q);
+  if (slope >= 0.f && slope <= 1.f)
+    hipLaunchKernelGGL(count_head_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo,
+                       num_b, num_q);
+  else
+    hipLaunchKernelGGL(count_head_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo,
+                       num_b, num_q);
   return launch_status("desco_count_head_f32");
 }
 
