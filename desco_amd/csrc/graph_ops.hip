@@ -168,27 +168,31 @@ __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict
     const int q = (int)(idx % num_q);
     const float4* tp = reinterpret_cast<const float4*>(t + b * ldt);
     const float* qp = qt + q;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    desco_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    const desco_f2 sl = {slope, slope};
     for (int c = 0; c < hid / 4; ++c) {
       const float4 tv = tp[c];
-      float z0 = tv.x + qp[(4 * c + 0) * HEAD_MAXQ], z1 = tv.y + qp[(4 * c + 1) * HEAD_MAXQ];
-      float z2 = tv.z + qp[(4 * c + 2) * HEAD_MAXQ], z3 = tv.w + qp[(4 * c + 3) * HEAD_MAXQ];
+      const desco_f2 q01 = {qp[(4 * c + 0) * HEAD_MAXQ], qp[(4 * c + 1) * HEAD_MAXQ]};
+      const desco_f2 q23 = {qp[(4 * c + 2) * HEAD_MAXQ], qp[(4 * c + 3) * HEAD_MAXQ]};
+      const desco_f2 t01 = {tv.x, tv.y}, t23 = {tv.z, tv.w};
+      const desco_f2 w01 = {w2[4 * c + 0], w2[4 * c + 1]}, w23 = {w2[4 * c + 2], w2[4 * c + 3]};
+      desco_f2 z01 = t01 + q01, z23 = t23 + q23;
       if (SLOPE01) {
-        z0 = fmaxf(z0, z0 * slope);
-        z1 = fmaxf(z1, z1 * slope);
-        z2 = fmaxf(z2, z2 * slope);
-        z3 = fmaxf(z3, z3 * slope);
+        const desco_f2 s01 = z01 * sl, s23 = z23 * sl;
+        z01.x = fmaxf(z01.x, s01.x);
+        z01.y = fmaxf(z01.y, s01.y);
+        z23.x = fmaxf(z23.x, s23.x);
+        z23.y = fmaxf(z23.y, s23.y);
       } else {
-        z0 = z0 > 0.f ? z0 : z0 * slope;
-        z1 = z1 > 0.f ? z1 : z1 * slope;
-        z2 = z2 > 0.f ? z2 : z2 * slope;
-        z3 = z3 > 0.f ? z3 : z3 * slope;
+        z01.x = z01.x > 0.f ? z01.x : z01.x * slope;
+        z01.y = z01.y > 0.f ? z01.y : z01.y * slope;
+        z23.x = z23.x > 0.f ? z23.x : z23.x * slope;
+        z23.y = z23.y > 0.f ? z23.y : z23.y * slope;
       }
-      a0 = fmaf(z0, w2[4 * c + 0], a0);
-      a1 = fmaf(z1, w2[4 * c + 1], a1);
-      a2 = fmaf(z2, w2[4 * c + 2], a2);
-      a3 = fmaf(z3, w2[4 * c + 3], a3);
+      acc01 = __builtin_elementwise_fma(z01, w01, acc01);
+      acc23 = __builtin_elementwise_fma(z23, w23, acc23);
     }
+    const float a0 = acc01.x, a1 = acc01.y, a2 = acc23.x, a3 = acc23.y;
     const float acc = (a0 + a1) + (a2 + a3) + b2;
     out[b * ldo + q] = exp2m1 ? exp2f(acc) - 1.f : acc;
   }
