@@ -60,3 +60,27 @@ def test_few_waves_and_many_waves_agree():
     a = build_partition_device(gs, 4, num_waves=4)
     b = build_partition_device(gs, 4, num_waves=4096)
     _same(a, b)
+
+
+def test_large_graphs_multiword_bitmaps_and_host_fallback():
+    """A 3000-node graph (94 bitmap words per wave, > 64 KB of dynamic LDS per block) is built on the
+    device; a 6000-node graph exceeds the per-wave LDS workspace: the device builder refuses it and
+    the pipeline's partition falls back to the host builder."""
+    rng = np.random.default_rng(5)
+    def tree_plus(n, extra):
+        edges = [(i, int(rng.integers(0, i))) for i in range(1, n)]
+        edges += [(int(a), int(b)) for a, b in rng.integers(0, n, size=(extra, 2)) if a != b]
+        return (n, edges)
+    mid = GraphSet.from_edge_lists([tree_plus(3000, 1500), tree_plus(40, 10)])
+    _same(build_partition_device(mid, 3), build_partition(mid, 3))
+    big = GraphSet.from_edge_lists([tree_plus(6000, 100)])
+    with pytest.raises(RuntimeError, match="does not fit the LDS workspace"):
+        build_partition_device(big, 2)
+    from helpers import make_models, standard_queries
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm = make_models(seed=0)
+    nm, gm = nm.to("cuda"), gm.to("cuda")
+    nm.set_queries(standard_queries()[0])
+    pipe = InferencePipeline(nm, gm, big, depth=2, device="cuda")
+    assert pipe.partition_backend == "host"
+    assert torch.isfinite(pipe.run()["graph_gossip_count"]).all()
