@@ -112,10 +112,33 @@ class GossipConv(nn.Module):
     def _gate_value(self, query_emb: torch.Tensor):
         return self.lin_gate(query_emb)            # gnn_model.py:357-359 ([Q,1]; tiny, host-side op)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(
-            "GossipConv is executed inside BaseGNN.forward (all queries and layers batched into the "
-            "HIP gossip kernels); a per-layer stand-alone call is not provided")
+    def forward(self, x, edge_index, edge_weight=None, size=None, res_n_id=None, query_emb=None):
+        """Stand-alone layer call with the reference's semantics (gnn_model.py:303-350) on device
+        tensors, for ONE query: ``out = lin_update([sum_j w_ji * lin_com(x_j) | x])`` with
+        ``w_ji = gate`` where ``edge_weight`` is True and ``1 - gate`` elsewhere.  (The model path
+        does not call this: ``BaseGNN.forward`` batches all queries and both layers into the fused
+        kernels.)  ``edge_weight`` must be the direction flag ``src < dst`` the reference computes
+        (gnn_model.py:246-248); it is derived when omitted."""
+        if edge_index.numel():
+            edge_index = edge_index[:, edge_index[0] != edge_index[1]]          # remove_self_loops
+        src, dst = edge_index[0], edge_index[1]
+        if edge_weight is None:
+            both = torch.cat([edge_index, edge_index.flip(0)], 1)               # to_undirected
+            both = torch.unique(both, dim=1)
+            src, dst = both[0], both[1]
+        elif not torch.equal(edge_weight.bool(), src < dst):
+            raise NotImplementedError("GossipConv.forward: edge_weight must be the flag src < dst")
+        n = x.shape[0]
+        gate = 0.5 if query_emb is None else float(self.lin_gate(query_emb.reshape(1, -1)).detach().reshape(()))
+        order = torch.argsort(dst, stable=True)
+        col = src[order].to(torch.int32)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=x.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+        msg = ops.gemm(x.float().contiguous(), self.lin_com.weight.t().contiguous(), self.lin_com.bias)
+        g = torch.tensor([gate], device=x.device, dtype=torch.float32)
+        agg = ops.gossip_gather(msg, rowptr.to(torch.int32), col, n, 1, g)      # [n, 64]
+        return ops.gemm(agg, self.lin_update.weight.t().contiguous(), self.lin_update.bias,
+                        a2=x.float().contiguous())
 
     def __repr__(self):
         return "{}({}, {})".format(self.__class__.__name__, self.in_channels, self.out_channels)
