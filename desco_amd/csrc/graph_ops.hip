@@ -259,34 +259,44 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
                   : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 c0 = *reinterpret_cast<const float4*>(coef + S * 64 + c4);
   const int64_t stride = (int64_t)gridDim.x * 16;
-  for (int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < num_rows; i += stride) {
-    const int32_t* vp = vrowptr + (row0 + i) * S;
-    float4 acc = c0;
-    int prev = vp[0];
+  // four independent rows per trip (row pointers of all four are loaded before the first store)
+  for (int64_t i0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i0 < num_rows; i0 += 4 * stride) {
+    int dptr[4][DA_MAXS + 1];
 #pragma unroll
-    for (int s = 0; s < DA_MAXS; ++s) {
-      if (s < S) {
-        const int nxt = vp[s + 1];
-        const float d = (float)(nxt - prev);
-        acc.x += d * cf[s].x;
-        acc.y += d * cf[s].y;
-        acc.z += d * cf[s].z;
-        acc.w += d * cf[s].w;
-        prev = nxt;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * stride < num_rows ? i0 + u * stride : num_rows - 1;
+      const int32_t* vp = vrowptr + (row0 + i) * S;
+#pragma unroll
+      for (int s = 0; s <= DA_MAXS; ++s) dptr[u][s] = vp[s <= S ? s : S];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= num_rows) break;
+      float4 acc = c0;
+#pragma unroll
+      for (int s = 0; s < DA_MAXS; ++s) {
+        if (s < S) {
+          const float d = (float)(dptr[u][s + 1] - dptr[u][s]);
+          acc.x += d * cf[s].x;
+          acc.y += d * cf[s].y;
+          acc.z += d * cf[s].z;
+          acc.w += d * cf[s].w;
+        }
       }
+      acc.x = apply_act(acc.x, act, slope);
+      acc.y = apply_act(acc.y, act, slope);
+      acc.z = apply_act(acc.z, act, slope);
+      acc.w = apply_act(acc.w, act, slope);
+      if (extra) {
+        const float4 e = *reinterpret_cast<const float4*>(extra + i * ld_extra + c4);
+        acc.x += e.x;
+        acc.y += e.y;
+        acc.z += e.z;
+        acc.w += e.w;
+      }
+      *reinterpret_cast<float4*>(out + (row0 + i) * ldo + c4) = acc;
     }
-    acc.x = apply_act(acc.x, act, slope);
-    acc.y = apply_act(acc.y, act, slope);
-    acc.z = apply_act(acc.z, act, slope);
-    acc.w = apply_act(acc.w, act, slope);
-    if (extra) {
-      const float4 e = *reinterpret_cast<const float4*>(extra + i * ld_extra + c4);
-      acc.x += e.x;
-      acc.y += e.y;
-      acc.z += e.z;
-      acc.w += e.w;
-    }
-    *reinterpret_cast<float4*>(out + (row0 + i) * ldo + c4) = acc;
   }
 }
 
