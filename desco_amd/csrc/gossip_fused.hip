@@ -86,15 +86,26 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
   const int q = lane < Q ? lane : Q - 1;
   float slo = 0.f, shi = 0.f;
   int dlo = 0;
-  for (int e = e0; e < e1; ++e) {
-    const int64_t j = col[e];
-    const float xv = x[j * ldx + q];
-    if (j < i) {
-      slo += xv;
-      ++dlo;
-    } else {
-      shi += xv;
-    }
+  // four neighbours per trip: their (dependent) index and value loads are in flight together;
+  // a short tail re-reads the last neighbour with weight 0
+  for (int e = e0; e < e1; e += 4) {
+    const int last = e1 - 1;
+    const int64_t j0 = col[e], j1 = col[e + 1 < e1 ? e + 1 : last];
+    const int64_t j2 = col[e + 2 < e1 ? e + 2 : last], j3 = col[e + 3 < e1 ? e + 3 : last];
+    const float x0 = x[j0 * ldx + q], x1 = x[j1 * ldx + q], x2 = x[j2 * ldx + q], x3 = x[j3 * ldx + q];
+    const bool v1 = e + 1 < e1, v2 = e + 2 < e1, v3 = e + 3 < e1;
+    slo += j0 < i ? x0 : 0.f;
+    shi += j0 < i ? 0.f : x0;
+    dlo += j0 < i ? 1 : 0;
+    slo += (v1 && j1 < i) ? x1 : 0.f;
+    shi += (v1 && !(j1 < i)) ? x1 : 0.f;
+    dlo += (v1 && j1 < i) ? 1 : 0;
+    slo += (v2 && j2 < i) ? x2 : 0.f;
+    shi += (v2 && !(j2 < i)) ? x2 : 0.f;
+    dlo += (v2 && j2 < i) ? 1 : 0;
+    slo += (v3 && j3 < i) ? x3 : 0.f;
+    shi += (v3 && !(j3 < i)) ? x3 : 0.f;
+    dlo += (v3 && j3 < i) ? 1 : 0;
   }
   const float flo = (float)dlo, fhi = (float)(e1 - e0 - dlo);
   const float a = g0[q], b = g1[q];
