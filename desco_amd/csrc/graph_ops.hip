@@ -99,6 +99,14 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   out[b * ldo + c] = acc0;
 }
 
+// streaming (read-once) 16-byte load: keeps the layer outputs from displacing the next kernel's
+// working set in L2 / MALL
+typedef float desco_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const desco_f4v v = __builtin_nontemporal_load(reinterpret_cast<const desco_f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // 64-column form (every pooling block of the SHMP path): a 16-lane group (float4 per lane) owns
 // one segment and keeps four row loads in flight; a wave serves four consecutive segments, so it
 // streams one contiguous row range.  Rows past the end of a segment re-read its last row and are
@@ -117,10 +125,10 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
   for (int r = r0; r < r1; r += 4) {
     const int last = r1 - 1;
-    const float4 v0 = *reinterpret_cast<const float4*>(xc + (int64_t)r * ldx);
-    const float4 v1 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 1 < r1 ? r + 1 : last) * ldx);
-    const float4 v2 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 2 < r1 ? r + 2 : last) * ldx);
-    const float4 v3 = *reinterpret_cast<const float4*>(xc + (int64_t)(r + 3 < r1 ? r + 3 : last) * ldx);
+    const float4 v0 = nt_load4(xc + (int64_t)r * ldx);
+    const float4 v1 = nt_load4(xc + (int64_t)(r + 1 < r1 ? r + 1 : last) * ldx);
+    const float4 v2 = nt_load4(xc + (int64_t)(r + 2 < r1 ? r + 2 : last) * ldx);
+    const float4 v3 = nt_load4(xc + (int64_t)(r + 3 < r1 ? r + 3 : last) * ldx);
     const float m1 = r + 1 < r1 ? 1.f : 0.f, m2 = r + 2 < r1 ? 1.f : 0.f, m3 = r + 3 < r1 ? 1.f : 0.f;
     a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     a1.x += r + 1 < r1 ? v1.x : 0.f; a1.y += r + 1 < r1 ? v1.y : 0.f;
