@@ -173,3 +173,29 @@ def test_syn_edgelist_text_format_round_trip(tmp_path):
     again = read_syn_edgelist(raw / "w_edgelist.txt", raw / "w_graph_indicator.txt")
     assert again.num_graphs == 3 and again.num_nodes == 12
     assert sorted(np.diff(again.rowptr).tolist()) == sorted(np.diff(ref.rowptr).tolist())
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The newest committed bench line (profiles/r1_*_bench.json) carries every field of the
+    driver's contract plus the roofline / cpu_baseline objects, with consistent values."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r1_*_bench.json")) if "unfused" not in f and "fused" not in f)
+    assert files, "no committed bench line"
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "graphs/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["graphs_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
