@@ -162,6 +162,21 @@ def test_gossip_conv_standalone_forward(setup):
     torch.testing.assert_close(out2, out, rtol=1e-5, atol=1e-5)
 
 
+def test_repeated_runs_are_bitwise_identical(setup):
+    """No floating-point atomics, fixed reduction orders, race-free LDS protocols: 25 passes over the
+    same shard (COX2-shaped x8) give bit-identical results (also a soak test of the persistent
+    kernels' barriers and prefetch hand-offs)."""
+    from desco_amd import synthetic
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    pipe = InferencePipeline(nm, gm, synthetic.WORKLOADS["cox2"]().replicate(8), depth=4, device=DEV)
+    first = {k: v.clone() for k, v in pipe.run().items() if torch.is_tensor(v)}
+    for _ in range(24):
+        out = pipe.run()
+        for k, v in first.items():
+            assert torch.equal(out[k], v), k
+
+
 def test_fused_gossip_equals_unfused_incl_hubs(setup):
     """The on-chip gossip kernel vs the 7-launch path on a graph set with hub nodes whose tile
     holds more neighbour records than one staging pass (ECAP = 768)."""
