@@ -282,20 +282,38 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     pk = {"pre": {}, "layers": []}
     for t in core.node_types:
         pk["pre"][t] = _lin_t(core.pre_mp[0][t])
+    # Folding (U_n W_s)^T for every (layer, destination type, slot) and U_n sum_s b_s + c for every
+    # (layer, type): two batched matmuls instead of ~100 tiny ones (the training step re-folds the
+    # weights every step; per-product launches made it host-bound).  Differentiable.
+    items, un_items, bias_items, un_rows = [], [], [], []
+    for l in range(core.layer_num):
+        for t in core.node_types:
+            Un = core.updates[l][t].weight[:, :H]
+            bsum, seen = 0, set()
+            for key in core.slot_keys(t):
+                conv = core.convs[l][key]
+                items.append(conv.lin.weight)
+                un_items.append(Un)
+                if key not in seen:      # one bias per edge TYPE (use_tconv=False ties two slots)
+                    bsum = bsum + conv.lin.bias
+                    seen.add(key)
+            bias_items.append(bsum)
+            un_rows.append(Un)
+    folded = torch.bmm(torch.stack(un_items), torch.stack(items)).transpose(1, 2)    # (U_n W_s)^T
+    fbias = torch.bmm(torch.stack(un_rows), torch.stack(bias_items).unsqueeze(2)).squeeze(2)
+    it = ib = 0
     for l in range(core.layer_num):
         per_type = {}
         for t in core.node_types:
             U, c = core.updates[l][t].weight, core.updates[l][t].bias
-            Un, Ux = U[:, :H], U[:, H:]
-            blocks, bsum, seen = [], 0, set()
-            for key in core.slot_keys(t):
-                conv = core.convs[l][key]
-                blocks.append((Un @ conv.lin.weight).t())        # (U_n W_s)^T
-                if key not in seen:      # one bias per edge TYPE (use_tconv=False ties two slots)
-                    bsum = bsum + conv.lin.bias
-                    seen.add(key)
+            Ux = U[:, H:]
+            nslots = len(core.slot_keys(t))
+            blocks = [folded[it + k] for k in range(nslots)]
+            it += nslots
             blocks.append(Ux.t())
-            entry = {"wt": torch.cat(blocks, 0).contiguous(), "b": (Un @ bsum + c).contiguous()}
+            fb = fbias[ib] + c
+            ib += 1
+            entry = {"wt": torch.cat(blocks, 0).contiguous(), "b": fb.contiguous()}
             if len(blocks) == 5:
                 # count destinations: the two canonical->count relations have at most one source
                 # per row; apply them from a pre-transformed table (K 320 -> 192)
