@@ -110,6 +110,50 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     partial[(int64_t)blockIdx.y * N + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// same for 16-byte aligned rows: 16 lanes x float4 per row, 16 rows per block step, four steps in
+// flight; the 16 row-group partials are folded in a fixed order
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x,
+                                                              int64_t ldx, int64_t M, int N,
+                                                              int64_t slab,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[16][64];
+  const int rsub = threadIdx.x >> 4, c4 = 4 * (threadIdx.x & 15);
+  const int c = blockIdx.x * 64 + c4;
+  const int64_t m_beg = (int64_t)blockIdx.y * slab;
+  const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c < N) {
+    const float* xc = x + c;
+    int64_t m = m_beg + rsub;
+    for (; m + 48 < m_end; m += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xc + m * ldx);
+      const float4 v1 = *reinterpret_cast<const float4*>(xc + (m + 16) * ldx);
+      const float4 v2 = *reinterpret_cast<const float4*>(xc + (m + 32) * ldx);
+      const float4 v3 = *reinterpret_cast<const float4*>(xc + (m + 48) * ldx);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+      s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+      s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+    }
+    for (; m < m_end; m += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xc + m * ldx);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    }
+  }
+  red[rsub][c4] = (s0.x + s1.x) + (s2.x + s3.x);
+  red[rsub][c4 + 1] = (s0.y + s1.y) + (s2.y + s3.y);
+  red[rsub][c4 + 2] = (s0.z + s1.z) + (s2.z + s3.z);
+  red[rsub][c4 + 3] = (s0.w + s1.w) + (s2.w + s3.w);
+  __syncthreads();
+  const int cc = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && cc < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+    partial[(int64_t)blockIdx.y * N + cc] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_grad_kernel(const float* __restrict__ dc,
                                                        const float* __restrict__ c, int act,
                                                        float slope, float* __restrict__ dz,
@@ -211,13 +255,17 @@ extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, f
                                 int accumulate, float* workspace, desco_stream_t stream) {
   if (!x || !out || !workspace || m < 0 || n <= 0)
     return fail(DESCO_EINVAL, "desco_colsum_f32: bad argument");
-  int64_t splits = (m + 2047) / 2048;
+  int64_t splits = (m + 255) / 256;          // enough slabs to fill the chip (workspace: 512 * n floats)
   if (splits > 512) splits = 512;
   if (splits < 1) splits = 1;
   const int64_t slab = (m + splits - 1) / splits;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, (unsigned)splits), dim3(256), 0, st, x,
-                     ldx, m, n, slab > 0 ? slab : 1, workspace);
+  if (n % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((n + 63) / 64, (unsigned)splits), dim3(256), 0, st, x,
+                       ldx, m, n, slab > 0 ? slab : 1, workspace);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, (unsigned)splits), dim3(256), 0, st, x,
+                       ldx, m, n, slab > 0 ? slab : 1, workspace);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      workspace, (int64_t)n, (int)splits, out, (int64_t)n, n, accumulate);
   return launch_status("desco_colsum_f32");
