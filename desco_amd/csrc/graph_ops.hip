@@ -36,39 +36,82 @@ __device__ __forceinline__ void vzero(float2& a) { a = make_float2(0.f, 0.f); }
 __device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // SAGEConv message + aggregate (gnn_model.py:392-394, 402-404) for S relation slots per row.
-// Wave = one destination row; lane group of 64/S lanes = one slot; each lane carries S floats.
+// Batched, branch-free form of the gather (the lessons of shmp_layer.hip applied to the stand-alone
+// kernel of the training path): a 16-lane group (float4 per lane) owns one destination row, a wave
+// four rows; per slot the first W = 8/S sources are fetched unconditionally -- absent ones read a
+// row of zeros -- so eight 16-byte loads per lane are in flight before the first add; longer slots
+// continue W sources at a time.  vcol must be readable at index 0 even when there is no edge.
+__device__ __attribute__((aligned(16))) float gather_zero_row[64];
+
 template <int S>
-__global__ __launch_bounds__(256) void csr_gather_sum_kernel(const float* __restrict__ x,
-                                                             int64_t ldx,
-                                                             const int32_t* __restrict__ vrowptr,
-                                                             const int32_t* __restrict__ vcol,
-                                                             int64_t num_rows,
-                                                             float* __restrict__ out) {
-  using V = typename VecOf<S>::type;
-  constexpr int LG = 64 / S;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  if (row >= num_rows) return;
-  const int group = lane / LG, foff = (lane % LG) * S;
-  const int64_t v = row * S + group;
-  const int e0 = vrowptr[v], e1 = vrowptr[v + 1];
-  V acc0, acc1;
-  vzero(acc0);
-  vzero(acc1);
-  int e = e0;
-  for (; e + 1 < e1; e += 2) {
-    const int64_t j0 = vcol[e], j1 = vcol[e + 1];
-    const V a = *reinterpret_cast<const V*>(x + j0 * ldx + foff);
-    const V b = *reinterpret_cast<const V*>(x + j1 * ldx + foff);
-    vadd(acc0, a);
-    vadd(acc1, b);
+__global__ __launch_bounds__(256) void csr_gather_sum_v2_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const int32_t* __restrict__ vrowptr,
+                                                                const int32_t* __restrict__ vcol,
+                                                                int64_t num_rows,
+                                                                float* __restrict__ out) {
+  constexpr int W = 8 / S;
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
+  const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool live = row_raw < num_rows;
+  const int64_t row = live ? row_raw : num_rows - 1;
+  const float* xc = x + 4 * l16;
+  const float* zr = gather_zero_row + 4 * l16;
+  int e[S], n[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    e[s] = vrowptr[row * S + s];
+    n[s] = vrowptr[row * S + s + 1];
   }
-  if (e < e1) {
-    const int64_t j0 = vcol[e];
-    vadd(acc0, *reinterpret_cast<const V*>(x + j0 * ldx + foff));
+  float4 acc[S];
+  float4 v[S][W];
+  // first step of every slot: S*W = 8 loads in flight
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const bool ok = e[s] + k < n[s];
+      const int j = vcol[ok ? e[s] + k : (n[s] > 0 ? n[s] - 1 : 0)];
+      v[s][k] = *reinterpret_cast<const float4*>(ok ? xc + (int64_t)j * ldx : zr);
+    }
   }
-  vadd(acc0, acc1);
-  *reinterpret_cast<V*>(out + v * 64 + foff) = acc0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    acc[s] = v[s][0];
+#pragma unroll
+    for (int k = 1; k < W; ++k) {
+      acc[s].x += v[s][k].x;
+      acc[s].y += v[s][k].y;
+      acc[s].z += v[s][k].z;
+      acc[s].w += v[s][k].w;
+    }
+    e[s] += W;
+  }
+  // longer slots: W more sources per trip, all lane groups of the wave in step
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    while (__any(e[s] < n[s])) {
+      float4 t[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const bool ok = e[s] + k < n[s];
+        const int j = vcol[ok ? e[s] + k : (n[s] > 0 ? n[s] - 1 : 0)];
+        t[k] = *reinterpret_cast<const float4*>(ok ? xc + (int64_t)j * ldx : zr);
+      }
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        acc[s].x += t[k].x;
+        acc[s].y += t[k].y;
+        acc[s].z += t[k].z;
+        acc[s].w += t[k].w;
+      }
+      e[s] += W;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      *reinterpret_cast<float4*>(out + (row * S + s) * 64 + 4 * l16) = acc[s];
+  }
 }
 
 // global_add_pool over contiguous segments (+ one extra row per segment, added last to mirror the
@@ -373,17 +416,18 @@ extern "C" int desco_csr_gather_sum_f32(const float* x, int64_t ldx, const int32
   if (!x || !vrowptr || !out || num_rows < 0 || ldx % 4 || (reinterpret_cast<uintptr_t>(x) & 15) ||
       (reinterpret_cast<uintptr_t>(out) & 15) || !(slots == 1 || slots == 2 || slots == 4))
     return fail(DESCO_EINVAL, "desco_csr_gather_sum_f32: bad argument");
-  const int64_t blocks = (num_rows + 3) / 4;
+  if (!vcol) return fail(DESCO_EINVAL, "desco_csr_gather_sum_f32: vcol must be readable at index 0");
+  const int64_t blocks = (num_rows + 15) / 16;
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_csr_gather_sum_f32: too many rows");
   hipStream_t st = (hipStream_t)stream;
   if (slots == 4)
-    hipLaunchKernelGGL(csr_gather_sum_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+    hipLaunchKernelGGL(csr_gather_sum_v2_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
                        vrowptr, vcol, num_rows, out);
   else if (slots == 2)
-    hipLaunchKernelGGL(csr_gather_sum_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+    hipLaunchKernelGGL(csr_gather_sum_v2_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
                        vrowptr, vcol, num_rows, out);
   else
-    hipLaunchKernelGGL(csr_gather_sum_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
+    hipLaunchKernelGGL(csr_gather_sum_v2_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
                        vrowptr, vcol, num_rows, out);
   return launch_status("desco_csr_gather_sum_f32");
 }

@@ -119,6 +119,8 @@ def csr_gather_sum(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, n
     # algorithmic bytes: every source row once + indices + the S aggregate rows
     nb = 256.0 * x.shape[0] + 4.0 * (vcol.numel() + num_rows * slots + 1) + 256.0 * num_rows * slots
     with _Timed("csr_gather_sum_kernel", float(vcol.numel()) * 64, nb):
+        if vcol.numel() == 0:       # the kernel reads vcol[0] unconditionally (branch-free loads)
+            vcol = torch.zeros(1, device=x.device, dtype=torch.int32)
         _lib.check(L.desco_csr_gather_sum_f32(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
                                               _dev(vcol, "vcol", torch.int32), num_rows, slots,
                                               _dev(out, "out"), _stream()), "csr_gather_sum")

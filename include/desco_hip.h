@@ -132,7 +132,9 @@ int desco_linear_smallk_f32(const float* feat, int64_t ldf, int k, const float* 
 
 /* K2/K3  SAGEConv message+aggregate for all relation slots at once (gnn_model.py:392-394,
  * 402-404: index_select + scatter_add):  out[v, 0:64] = sum_{e in vrow v} x[vcol[e], 0:64].
- * One wavefront per destination row, one 16-lane group (float4 per lane) per slot; S in {1,2,4}.
+ * A 16-lane group (float4 per lane) per destination row, eight unconditional source loads in
+ * flight per lane (absent sources read a zero row); S in {1,2,4}; vcol must be readable at
+ * index 0 even when there is no edge.
  * out is [num_rows*S, 64] contiguous (== [num_rows, S*64]). */
 int desco_csr_gather_sum_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
                              const int32_t* vcol, int64_t num_rows, int slots, float* out,
