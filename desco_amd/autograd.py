@@ -130,7 +130,7 @@ class CountHead(torch.autograd.Function):
     def forward(ctx, t, qh, w2, b2, slope):
         ctx.save_for_backward(t, qh, w2)
         ctx.slope = slope
-        return ops.count_head(t, qh, w2, float(b2), slope, False)
+        return ops.count_head(t, qh, w2, b2, slope, False)       # b2 read on the device: capturable
 
     @staticmethod
     def backward(ctx, dl):

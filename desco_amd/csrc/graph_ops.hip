@@ -203,10 +203,12 @@ template <bool SLOPE01>
 __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
                                                          const float* __restrict__ qh, int64_t ldq,
                                                          int hid, const float* __restrict__ w2,
-                                                         float b2, float slope, int exp2m1,
+                                                         float b2, const float* __restrict__ b2_dev,
+                                                         float slope, int exp2m1,
                                                          float* __restrict__ out, int64_t ldo,
                                                          int64_t num_b, int num_q) {
   __shared__ float qt[HEAD_MAXHID * HEAD_MAXQ];
+  if (b2_dev) b2 = *b2_dev;        // bias read on the device (training: no host copy of a parameter)
   for (int i = threadIdx.x; i < hid * num_q; i += 256) {
     const int q = i / hid, c = i % hid;
     qt[c * HEAD_MAXQ + q] = qh[(int64_t)q * ldq + c];
@@ -457,9 +459,9 @@ extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,
 }
 
 extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq,
-                                    int hid, const float* w2, float b2, float slope,
-                                    int exp2_minus_1, float* out, int64_t ldo, int64_t num_b,
-                                    int num_q, desco_stream_t stream) {
+                                    int hid, const float* w2, float b2, const float* b2_dev,
+                                    float slope, int exp2_minus_1, float* out, int64_t ldo,
+                                    int64_t num_b, int num_q, desco_stream_t stream) {
   if (num_b == 0 || num_q == 0) return 0;
   if (!t || !qh || !w2 || !out || num_b < 0 || num_q < 0 || num_q > HEAD_MAXQ || hid <= 0 ||
       hid % 64 || hid > HEAD_MAXHID || ldt % 4 || (reinterpret_cast<uintptr_t>(t) & 15))
@@ -469,11 +471,11 @@ extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_count_head_f32: too many rows");
   if (slope >= 0.f && slope <= 1.f)
     hipLaunchKernelGGL(count_head_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo,
+                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo,
                        num_b, num_q);
   else
     hipLaunchKernelGGL(count_head_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, slope, exp2_minus_1, out, ldo,
+                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo,
                        num_b, num_q);
   return launch_status("desco_count_head_f32");
 }

@@ -358,9 +358,10 @@ def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
     return out
 
 
-def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2: float, slope: float,
+def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2, slope: float,
                exp2_minus_1: bool) -> torch.Tensor:
-    """[B,Q] logits (or 2**logit - 1) of the separable count head (lightning_model.py:176-221)."""
+    """[B,Q] logits (or 2**logit - 1) of the separable count head (lightning_model.py:176-221).
+    ``b2``: a float, or a 0-d / 1-element device tensor read by the kernel (no host sync)."""
     B, hid = t.shape
     Q = qh.shape[0]
     out = torch.empty((B, Q), device=t.device, dtype=torch.float32)
@@ -368,8 +369,11 @@ def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2: float, s
     qp, ldq = _rows(qh, "qh")
     L = _lib.lib()
     with _Timed("count_head_kernel", 4.0 * B * Q * hid, 4.0 * (B * hid + Q * hid + B * Q)):
+        b2_dev = None
+        if isinstance(b2, torch.Tensor):
+            b2_dev, b2 = _dev(b2.detach().reshape(1).contiguous(), "b2"), 0.0
         _lib.check(L.desco_count_head_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"), b2,
-                                          slope, int(exp2_minus_1), _dev(out, "out"), Q, B, Q,
+                                          b2_dev, slope, int(exp2_minus_1), _dev(out, "out"), Q, B, Q,
                                           _stream()), "count_head")
     return out
 

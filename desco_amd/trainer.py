@@ -25,10 +25,15 @@ class ModelCheckpoint:
 class Trainer:
     def __init__(self, max_epochs: int = 1, accelerator: str = "gpu", devices=None,
                  default_root_dir: str = ".", callbacks=None, strategy: Optional[str] = None,
-                 grad_reduce: str = "mean", precision: str = "fp32", **unused):
+                 grad_reduce: str = "mean", precision: str = "fp32", graph_capture: bool = False,
+                 **unused):
         # precision: "fp32" | "bf16" (Lightning's "32" / "bf16-mixed" spellings accepted): matrix
         # products of the training step in fp32 or bf16 MFMA (desco_amd.autograd.set_precision)
         self.precision = precision
+        # graph_capture: after one eager epoch, every training batch's step (forward, backward, Adam)
+        # is captured in a hipGraph and replayed in later epochs -- the ~400 launches of a step are
+        # host-bound otherwise.  Single process, models without dropout (the neighborhood model).
+        self.graph_capture = graph_capture
         self.max_epochs = max_epochs
         self.root = default_root_dir
         self.callbacks = callbacks or []
@@ -65,6 +70,26 @@ class Trainer:
             tot, cnt = float(t[0]), float(t[1])
         return tot / max(cnt, 1)
 
+    def _graph_epoch(self, model, opt, batches, graphs, side, capture: bool):
+        """One epoch on the side stream: eager (epoch 0), then capture-once / replay per batch."""
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for i, batch in enumerate(batches):
+                if not capture:
+                    opt.zero_grad(set_to_none=True)
+                    model.train_forward(batch, i).backward()
+                    opt.step()
+                    continue
+                if i not in graphs:
+                    opt.zero_grad(set_to_none=True)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):      # (the capture does not execute the step)
+                        model.train_forward(batch, i).backward()
+                        opt.step()
+                    graphs[i] = g
+                graphs[i].replay()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+
     # ---- API ----------------------------------------------------------------------------------
     def fit(self, model, datamodule):
         from . import autograd as AG
@@ -74,18 +99,44 @@ class Trainer:
         opt, sched = cfg["optimizer"], cfg["lr_scheduler"]
         ckpt = next((c for c in self.callbacks if isinstance(c, ModelCheckpoint)), None)
         os.makedirs(self.root, exist_ok=True)
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        use_graphs = self.graph_capture and not multi and float(getattr(model, "dropout", 0.0) or 0.0) == 0.0
+        # shuffle=False (main.py:195): the batch stream is the same every epoch, so the device-resident
+        # batches (and their backward indices) are built once
+        train_batches = [b.to(self.device) for b in self._shard(list(datamodule.train_dataloader()))]
+        graphs = {}
+        # capture happens on a side stream, and autograd's AccumulateGrad nodes must have been created
+        # on that same stream: with graph_capture the whole training loop runs on it
+        side = torch.cuda.Stream(self.device) if use_graphs else None
+        if use_graphs:
+            for g_ in opt.param_groups:       # Adam state and lr as device tensors: capturable
+                g_["capturable"] = True
+                g_["lr"] = torch.tensor(float(g_["lr"]), device=self.device)
         for epoch in range(self.max_epochs):
             model.train()
-            for i, batch in enumerate(self._shard(list(datamodule.train_dataloader()))):
-                opt.zero_grad(set_to_none=True)
-                loss = model.training_step(batch.to(self.device), i)
-                loss.backward()
-                D.allreduce_grads(list(model.parameters()), mode=self.grad_reduce)
-                opt.step()
+            if use_graphs:
+                self._graph_epoch(model, opt, train_batches, graphs, side, capture=epoch >= 1)
+            else:
+                for i, batch in enumerate(train_batches):
+                    opt.zero_grad(set_to_none=True)
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    D.allreduce_grads(list(model.parameters()), mode=self.grad_reduce)
+                    opt.step()
             model.eval()
             val = self._mean_loss(model, datamodule.val_dataloader(), "validation_step")
-            sched.step(val)
-            self.history.append({"epoch": epoch, cfg["monitor"]: val, "lr": opt.param_groups[0]["lr"]})
+            if use_graphs:       # keep the captured graphs' lr tensor; the scheduler works on floats
+                lr_t = [g_["lr"] for g_ in opt.param_groups]
+                for g_, t_ in zip(opt.param_groups, lr_t):
+                    g_["lr"] = float(t_)
+                sched.step(val)
+                for g_, t_ in zip(opt.param_groups, lr_t):
+                    t_.fill_(float(g_["lr"]))
+                    g_["lr"] = t_
+            else:
+                sched.step(val)
+            self.history.append({"epoch": epoch, cfg["monitor"]: val, "lr": float(opt.param_groups[0]["lr"])})
             if ckpt is not None and self._rank0():
                 if ckpt.save_last:
                     model.save_checkpoint(os.path.join(self.root, "last.ckpt"))

@@ -242,8 +242,9 @@ int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols, const int32_t*
  * T: [B, hid] (target half of count_model.0), Qh: [Q, hid] (query half + bias);
  * hid % 64 == 0, hid <= 256, Q <= 32 */
 int desco_count_head_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq, int hid,
-                         const float* w2, float b2, float slope, int exp2_minus_1, float* out,
-                         int64_t ldo, int64_t num_b, int num_q, desco_stream_t stream);
+                         const float* w2, float b2, const float* b2_dev, float slope,
+                         int exp2_minus_1, float* out, int64_t ldo, int64_t num_b, int num_q,
+                         desco_stream_t stream);   /* b2_dev != NULL: the bias is read from the device */
 
 /* K14  GossipDataset.apply_neighborhood_count (workload.py:107-112): dst[rows[b], :] = src[b, :] */
 int desco_scatter_rows_f32(const float* src, int64_t lds, const int32_t* rows, int64_t num_src,

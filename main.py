@@ -70,7 +70,8 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
     neigh_trainer = Trainer(max_epochs=args_neighborhood.epoch_num, accelerator="gpu", devices=devices,
                             default_root_dir=args_neighborhood.model_path, callbacks=[neigh_ckpt],
                             strategy="ddp" if len(devices) > 1 else None, grad_reduce="mean",
-                            precision=getattr(args_opt, "precision", "fp32"))
+                            precision=getattr(args_opt, "precision", "fp32"),
+                            graph_capture=getattr(args_opt, "graph_capture", False))
     if train_neighborhood and neighborhood_checkpoint is None:
         neigh_model = NeighborhoodCountingModel(input_dim=args_neighborhood.input_dim,
                                                 hidden_dim=args_neighborhood.hidden_dim,
@@ -187,10 +188,13 @@ if __name__ == "__main__":
     parser.add_argument("--data_root", type=str, default="data")
     parser.add_argument("--precision", type=str, default="fp32", choices=["fp32", "bf16"],
                         help="matrix-product precision of the training steps (bf16: BASELINE config 3)")
+    parser.add_argument("--graph_capture", action="store_true",
+                        help="replay each neighborhood training batch's step from a hipGraph after epoch 0")
     args = parser.parse_args()
     print(args)
     args_neighborhood, args_gossip, args_opt = split_namespaces(args)
-    args_opt.precision = args.precision          # this build's flag (not in the reference's groups)
+    args_opt.precision = args.precision          # this build's flags (not in the reference's groups)
+    args_opt.graph_capture = args.graph_capture
     assert args_neighborhood.use_hetero
     query_ids = gen_query_ids(query_size=[3, 4, 5])
     output_dir = args_opt.output_dir or os.path.join(

@@ -329,6 +329,41 @@ def test_bf16_training_mode_tracks_fp32(setup):
         AG.set_precision("fp32")
 
 
+def test_trainer_graph_capture_matches_eager(tmp_path, setup):
+    """Trainer(graph_capture=True): epochs >= 1 replay one hipGraph per training batch (forward,
+    backward, Adam).  Same kernels in the same order; the only arithmetic difference is Adam's
+    capturable form (step count and bias corrections as fp32 device tensors instead of Python
+    doubles).  Adam's m/sqrt(v) amplifies that round-off where gradients are tiny, so the parameters
+    after 12 steps (each moving a weight by up to lr = 1e-3) agree to 1e-4, not bit for bit."""
+    from desco_amd.trainer import Trainer
+    nm0, gm, qids, queries = setup
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=41)[:12]), 4)
+    g = torch.Generator().manual_seed(9)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) ** 3 * 40)
+    cuts = [0, part.num_neigh // 3, 2 * part.num_neigh // 3, part.num_neigh]
+
+    class DM:
+        def _mk(self):
+            return [NeighborhoodBatch(part.slice(a, b), DEV, y=y[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        def train_dataloader(self):
+            return self._mk()
+        def val_dataloader(self):
+            return self._mk()[:1]
+
+    finals = []
+    for capture in (False, True):
+        nm, _ = make_models(seed=2)
+        nm = nm.to(DEV)
+        nm.set_queries(qids)
+        tr = Trainer(max_epochs=4, devices=[0], default_root_dir=str(tmp_path / f"c{int(capture)}"),
+                     graph_capture=capture)
+        tr.fit(nm, DM())
+        finals.append({k: v.detach().clone() for k, v in nm.state_dict().items()})
+        assert tr.history[-1]["neighborhood_counting_val_loss"] < tr.history[0]["neighborhood_counting_val_loss"]
+    for k in finals[0]:
+        torch.testing.assert_close(finals[1][k], finals[0][k], rtol=1e-3, atol=1e-4, msg=lambda m: f"{k}: {m}")
+
+
 def test_gossip_training_loss_and_gradients(setup):
     """GossipCountingModel.train_forward + backward vs torch autograd through the CPU oracle
     (lightning_model.py:585-608, 630-635)."""

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=512, help="neighborhoods per training step")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture each batch's step (forward, backward, Adam) in a hipGraph and time replays "
+                         "(what Trainer(graph_capture=True) does)")
     ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event breakdown of the timed steps")
     args = ap.parse_args()
     from desco_amd import autograd as AG
@@ -50,7 +53,29 @@ def main():
         loss.backward()
         opt.step()
         return loss
-    for b in batches[:2]:
+    if args.graph:
+        for g_ in opt.param_groups:
+            g_["capturable"] = True
+            g_["lr"] = torch.tensor(float(g_["lr"]), device=dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graphs = {}
+        with torch.cuda.stream(side):
+            for b in batches:
+                opt.zero_grad(set_to_none=True)
+                nm.train_forward(b, 0).backward()
+                opt.step()
+            for b in batches:
+                opt.zero_grad(set_to_none=True)
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg, stream=side):
+                    nm.train_forward(b, 0).backward()
+                    opt.step()
+                graphs[id(b)] = cg
+        torch.cuda.current_stream().wait_stream(side)
+        def step(b):            # noqa: F811
+            graphs[id(b)].replay()
+    for b in batches:           # first epoch untimed: builds the per-batch backward indices, warms caches
         step(b)
     torch.cuda.synchronize()
     from desco_amd import ops
@@ -71,7 +96,8 @@ def main():
         print(f"profiled kernel time {tot / (len(batches) - 2):.1f} ms/step:")
         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]:
             print(f"   {k:32s} {v['calls'] // (len(batches) - 2):4d} launches/step {v['ms'] / (len(batches) - 2):7.2f} ms/step")
-    print(f"neighborhood training ({args.workload}-shaped, batch {args.batch}, {args.precision}): {len(batches) - 2} steps, "
+    mode = ", hipGraph replay" if args.graph else ""
+    print(f"neighborhood training ({args.workload}-shaped, batch {args.batch}, {args.precision}{mode}): {len(batches) - 2} steps, "
           f"{n / dt:.0f} neighborhoods/s, {rows / dt / 1e6:.2f} M rows/s, {1e3 * dt / (len(batches) - 2):.1f} ms/step")
     # gossip
     x = torch.rand(gs.num_nodes, Q, generator=g) * 20
