@@ -227,6 +227,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   {                                                                                        \
     if ((b_) < KB - 1) {                                                                   \
       DESCO_CURS(b_)                                                                       \
+      live = (live & ~(1 << (b_))) | (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3)) ? 1 << (b_) : 0); \
       DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                \
       DESCO_ISSUE2(2, xb, LDX) DESCO_ISSUE2(3, xb, LDX)                                \
     } else if ((b_) == KB - 1) {                                                           \
@@ -374,6 +375,10 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   float4 w00, w01, w10, w11, w20, w21, w30, w31;           // in flight: second source
   w00 = w01 = w10 = w11 = w20 = w21 = w30 = w31 = make_float4(0.f, 0.f, 0.f, 0.f);
   int c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;   // cursors [c, n) rel. to ebase
+  // bit b: relation slot b has at least one source among this wave's 32 rows.  A slot that is empty
+  // for the whole wave tile (triangle edges in molecule graphs, tride edges in clique unions) is an
+  // all-zero K block: its splits and MFMAs are skipped (wave-uniform branch; adds exact zeros otherwise)
+  int live = 0;
   DESCO_ISSUE_BLOCK(0)
 
   for (;;) {
@@ -444,30 +449,35 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
-      if (X6 && b < KB) {
-        DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1) DESCO_PUT_X6(lo2, 2) DESCO_PUT_X6(lo3, 3)
-      } else {
-        DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1) DESCO_PUT_F32(lo2, 2) DESCO_PUT_F32(lo3, 3)
+      const bool block_live = b >= KB - 1 || ((live >> b) & 1);      // wave-uniform
+      if (block_live) {
+        if (X6 && b < KB) {
+          DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1) DESCO_PUT_X6(lo2, 2) DESCO_PUT_X6(lo3, 3)
+        } else {
+          DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1) DESCO_PUT_F32(lo2, 2) DESCO_PUT_F32(lo3, 3)
+        }
       }
       if (b + 1 < NB) DESCO_ISSUE_BLOCK(b + 1)
-      if (b >= KB) {
-        DESCO_TAB_HALF(acc0)
-      } else if (X6) {
-        DESCO_MFMA_HALF_X6(b, 0)
-      } else {
-        DESCO_MFMA_HALF_F32(b, 0)
-      }
-      if (X6 && b < KB) {
-        DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1) DESCO_PUT_X6(hi2, 2) DESCO_PUT_X6(hi3, 3)
-      } else {
-        DESCO_PUT_F32(hi0, 0) DESCO_PUT_F32(hi1, 1) DESCO_PUT_F32(hi2, 2) DESCO_PUT_F32(hi3, 3)
-      }
-      if (b >= KB) {
-        DESCO_TAB_HALF(acc1)
-      } else if (X6) {
-        DESCO_MFMA_HALF_X6(b, 1)
-      } else {
-        DESCO_MFMA_HALF_F32(b, 1)
+      if (block_live) {
+        if (b >= KB) {
+          DESCO_TAB_HALF(acc0)
+        } else if (X6) {
+          DESCO_MFMA_HALF_X6(b, 0)
+        } else {
+          DESCO_MFMA_HALF_F32(b, 0)
+        }
+        if (X6 && b < KB) {
+          DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1) DESCO_PUT_X6(hi2, 2) DESCO_PUT_X6(hi3, 3)
+        } else {
+          DESCO_PUT_F32(hi0, 0) DESCO_PUT_F32(hi1, 1) DESCO_PUT_F32(hi2, 2) DESCO_PUT_F32(hi3, 3)
+        }
+        if (b >= KB) {
+          DESCO_TAB_HALF(acc1)
+        } else if (X6) {
+          DESCO_MFMA_HALF_X6(b, 1)
+        } else {
+          DESCO_MFMA_HALF_F32(b, 1)
+        }
       }
     }
 
