@@ -192,14 +192,17 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + b * ldo + 4 * (lane & 15)) = o;
 }
 
-// count head, separable form of lightning_model.py:176-193, 210-221.
-// One thread per (b, q), 256-long dot product.  The Qh table is staged TRANSPOSED in LDS
-// ([c][32], consecutive q on consecutive banks: conflict-free), w2 is wave-uniform, the T row is a
-// (mostly broadcast) float4 global load.  Blocks stride over chunks of 256 (b, q) pairs so the
-// table is staged once per block.
-constexpr int HEAD_MAXQ = 32, HEAD_MAXHID = 256;
-// SLOPE01: 0 <= slope <= 1, where leaky(z) = max(z, slope*z) needs no compare/select
-template <bool SLOPE01>
+// count head, separable form of lightning_model.py:176-193, 210-221:
+//   out[b,q] = b2 + sum_c w2[c] leaky(T[b,c] + Qh[q,c]),   leaky(z) = slope z + (1 - slope) relu(z)
+//            = b2 + slope (w2.T[b]) + slope (w2.Qh[q]) + sum_c (1 - slope) w2[c] relu(T[b,c] + Qh[q,c])
+// so the inner loop is add, max, fma (two packed + two scalar VALU per element pair).  One thread
+// per target row b keeps all NQ query accumulators in registers.  A block's 256 T rows stream
+// through LDS in 16-column chunks: loaded coalesced (4 lanes x 16 B per row), read back one row per
+// thread (row stride 80 B: conflict-free ds_read_b128); the Qh rows and w2 are wave-uniform
+// ds_read_b128 broadcasts.  T crosses HBM once.  (One thread per (b, q) pair re-fetched the T row 29
+// times through the vector memory path, which then set the time.)
+constexpr int HEAD_MAXQ = 32, HEAD_MAXHID = 256, HEAD_TS = 20;
+template <int NQ>
 __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
                                                          const float* __restrict__ qh, int64_t ldq,
                                                          int hid, const float* __restrict__ w2,
@@ -207,47 +210,88 @@ __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict
                                                          float slope, int exp2m1,
                                                          float* __restrict__ out, int64_t ldo,
                                                          int64_t num_b, int num_q) {
-  __shared__ float qt[HEAD_MAXHID * HEAD_MAXQ];
+  __shared__ __attribute__((aligned(16))) float qt[NQ * HEAD_MAXHID];     // [q][hid], rows >= num_q zero
+  __shared__ __attribute__((aligned(16))) float ws[HEAD_MAXHID];          // w2
+  __shared__ __attribute__((aligned(16))) float wr[HEAD_MAXHID];          // (1 - slope) w2
+  __shared__ __attribute__((aligned(16))) float tch[256 * HEAD_TS];       // T chunk [256 rows][16 (+4 pad)]
+  __shared__ float sq[HEAD_MAXQ];                                         // b2 + slope (w2.Qh[q])
+  const int tid = threadIdx.x;
   if (b2_dev) b2 = *b2_dev;        // bias read on the device (training: no host copy of a parameter)
-  for (int i = threadIdx.x; i < hid * num_q; i += 256) {
-    const int q = i / hid, c = i % hid;
-    qt[c * HEAD_MAXQ + q] = qh[(int64_t)q * ldq + c];
+  for (int i = tid; i < NQ * hid; i += 256) {
+    const int q = i / hid, c = i - q * hid;
+    qt[i] = q < num_q ? qh[(int64_t)q * ldq + c] : 0.f;
+  }
+  for (int i = tid; i < hid; i += 256) {
+    ws[i] = w2[i];
+    wr[i] = (1.f - slope) * w2[i];
   }
   __syncthreads();
-  const int64_t total = num_b * num_q;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * 256) {
-    const int64_t b = idx / num_q;
-    const int q = (int)(idx % num_q);
-    const float4* tp = reinterpret_cast<const float4*>(t + b * ldt);
-    const float* qp = qt + q;
-    desco_f2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-    const desco_f2 sl = {slope, slope};
-    for (int c = 0; c < hid / 4; ++c) {
-      const float4 tv = tp[c];
-      const desco_f2 q01 = {qp[(4 * c + 0) * HEAD_MAXQ], qp[(4 * c + 1) * HEAD_MAXQ]};
-      const desco_f2 q23 = {qp[(4 * c + 2) * HEAD_MAXQ], qp[(4 * c + 3) * HEAD_MAXQ]};
-      const desco_f2 t01 = {tv.x, tv.y}, t23 = {tv.z, tv.w};
-      const desco_f2 w01 = {w2[4 * c + 0], w2[4 * c + 1]}, w23 = {w2[4 * c + 2], w2[4 * c + 3]};
-      desco_f2 z01 = t01 + q01, z23 = t23 + q23;
-      if (SLOPE01) {
-        const desco_f2 s01 = z01 * sl, s23 = z23 * sl;
-        z01.x = fmaxf(z01.x, s01.x);
-        z01.y = fmaxf(z01.y, s01.y);
-        z23.x = fmaxf(z23.x, s23.x);
-        z23.y = fmaxf(z23.y, s23.y);
-      } else {
-        z01.x = z01.x > 0.f ? z01.x : z01.x * slope;
-        z01.y = z01.y > 0.f ? z01.y : z01.y * slope;
-        z23.x = z23.x > 0.f ? z23.x : z23.x * slope;
-        z23.y = z23.y > 0.f ? z23.y : z23.y * slope;
+  if (tid < NQ) {
+    float s = 0.f;
+    for (int c = 0; c < hid; ++c) s = fmaf(ws[c], qt[tid * hid + c], s);
+    sq[tid] = slope * s + b2;
+  }
+  const int nch = hid / 16;
+  const int lrow = tid >> 2, lpart = 4 * (tid & 3);      // coalesced load map: rows lrow + 64 p
+  for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < num_b; b0 += (int64_t)gridDim.x * 256) {
+    desco_f2 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) acc[j] = desco_f2{0.f, 0.f};
+    desco_f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+    float4 nv0, nv1, nv2, nv3;                            // next chunk in flight
+#define HEAD_LOAD(ch_)                                                                         \
+  {                                                                                            \
+    const float* p_ = t + (ch_) * 16 + lpart;                                                  \
+    const int64_t r0_ = b0 + lrow, last_ = num_b - 1;                                          \
+    nv0 = *reinterpret_cast<const float4*>(p_ + (r0_ < num_b ? r0_ : last_) * ldt);            \
+    nv1 = *reinterpret_cast<const float4*>(p_ + (r0_ + 64 < num_b ? r0_ + 64 : last_) * ldt);  \
+    nv2 = *reinterpret_cast<const float4*>(p_ + (r0_ + 128 < num_b ? r0_ + 128 : last_) * ldt); \
+    nv3 = *reinterpret_cast<const float4*>(p_ + (r0_ + 192 < num_b ? r0_ + 192 : last_) * ldt); \
+  }
+    HEAD_LOAD(0)
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();                                    // the previous chunk has been consumed
+      *reinterpret_cast<float4*>(tch + lrow * HEAD_TS + lpart) = nv0;
+      *reinterpret_cast<float4*>(tch + (lrow + 64) * HEAD_TS + lpart) = nv1;
+      *reinterpret_cast<float4*>(tch + (lrow + 128) * HEAD_TS + lpart) = nv2;
+      *reinterpret_cast<float4*>(tch + (lrow + 192) * HEAD_TS + lpart) = nv3;
+      __syncthreads();
+      if (ch + 1 < nch) HEAD_LOAD(ch + 1)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int c = ch * 16 + 4 * g4;
+        const float4 tv = *reinterpret_cast<const float4*>(tch + tid * HEAD_TS + 4 * g4);
+        const float4 wv = *reinterpret_cast<const float4*>(ws + c);
+        const float4 rv = *reinterpret_cast<const float4*>(wr + c);
+        const desco_f2 t01 = {tv.x, tv.y}, t23 = {tv.z, tv.w};
+        const desco_f2 r01 = {rv.x, rv.y}, r23 = {rv.z, rv.w};
+        s01 = __builtin_elementwise_fma(t01, desco_f2{wv.x, wv.y}, s01);
+        s23 = __builtin_elementwise_fma(t23, desco_f2{wv.z, wv.w}, s23);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          const float4 qv = *reinterpret_cast<const float4*>(qt + j * hid + c);
+          desco_f2 z01 = t01 + desco_f2{qv.x, qv.y}, z23 = t23 + desco_f2{qv.z, qv.w};
+          z01.x = fmaxf(z01.x, 0.f);
+          z01.y = fmaxf(z01.y, 0.f);
+          z23.x = fmaxf(z23.x, 0.f);
+          z23.y = fmaxf(z23.y, 0.f);
+          acc[j] = __builtin_elementwise_fma(z01, r01, acc[j]);
+          acc[j] = __builtin_elementwise_fma(z23, r23, acc[j]);
+        }
       }
-      acc01 = __builtin_elementwise_fma(z01, w01, acc01);
-      acc23 = __builtin_elementwise_fma(z23, w23, acc23);
     }
-    const float a0 = acc01.x, a1 = acc01.y, a2 = acc23.x, a3 = acc23.y;
-    const float acc = (a0 + a1) + (a2 + a3) + b2;
-    out[b * ldo + q] = exp2m1 ? exp2f(acc) - 1.f : acc;
+#undef HEAD_LOAD
+    const int64_t b = b0 + tid;
+    if (b < num_b) {
+      const float st = slope * ((s01.x + s01.y) + (s23.x + s23.y));
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        if (j < num_q) {
+          const float v = (acc[j].x + acc[j].y) + (st + sq[j]);
+          out[b * ldo + j] = exp2m1 ? exp2f(v) - 1.f : v;
+        }
+      }
+    }
   }
 }
 
@@ -466,17 +510,14 @@ extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh
   if (!t || !qh || !w2 || !out || num_b < 0 || num_q < 0 || num_q > HEAD_MAXQ || hid <= 0 ||
       hid % 64 || hid > HEAD_MAXHID || ldt % 4 || (reinterpret_cast<uintptr_t>(t) & 15))
     return fail(DESCO_EINVAL, "desco_count_head_f32: bad argument (num_q <= 32, hid%64, hid <= 256)");
-  int64_t blocks = (num_b * num_q + 255) / 256;
+  int64_t blocks = (num_b + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_count_head_f32: too many rows");
-  if (slope >= 0.f && slope <= 1.f)
-    hipLaunchKernelGGL(count_head_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo,
-                       num_b, num_q);
+  if (num_q == 29)            // the standard 29 queries of sizes 3-5 (data.py:37): no padded accumulators
+    hipLaunchKernelGGL(count_head_kernel<29>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t,
+                       ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo, num_b, num_q);
   else
-    hipLaunchKernelGGL(count_head_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo,
-                       num_b, num_q);
+    hipLaunchKernelGGL(count_head_kernel<HEAD_MAXQ>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t,
+                       ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo, num_b, num_q);
   return launch_status("desco_count_head_f32");
 }
 
