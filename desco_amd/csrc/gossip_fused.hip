@@ -232,6 +232,9 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   // item is done: a tile does not start with three dependent global-memory latencies.
   float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow;
   int n_rp = 0, n_col = 0, n_ebeg = 0, n_cnt = 0;
+  float n_zp = 0.f, n_gq = 0.f;            // the next item's per-query vectors (this lane's slice)
+  float2 n_pc = make_float2(0.f, 0.f), n_zc = n_pc;
+  const int f0 = 2 * (lane & 31);          // phase-1 lane map: features (f0, f0+1)
 #define GF_STAGE1(it_)                                                                     \
   {                                                                                        \
     const int q_ = (int)((it_) % Q);                                                       \
@@ -242,6 +245,10 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     n_ebeg = g.rowptr[t0_];                                                                \
     n_cnt = g.rowptr[t0_ + nr_] - n_ebeg;                                                  \
     n_cnt = n_cnt < PCAP ? n_cnt : PCAP;                                                   \
+    if (tid < 64) n_zp = g.zp[q_ * 64 + tid];                                              \
+    n_gq = g.g1[q_];                                                                       \
+    n_pc = *reinterpret_cast<const float2*>(g.p + q_ * 64 + f0);                           \
+    n_zc = *reinterpret_cast<const float2*>(g.z + q_ * 64 + f0);                           \
   }
 #define GF_STAGE2() \
   if (tid < n_cnt) n_col = g.col[n_ebeg + tid];
@@ -252,7 +259,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   GF_STAGE2()
   GF_STAGE3(item)
   // phase-1 lane map: two adjacent features (f0, f0+1) of rows wave*16 + 2*i + (lane>>5), i = 0..7
-  const int f0 = 2 * (lane & 31);
   const float2 rc = *reinterpret_cast<const float2*>(g.r + f0);
   const float2 tc = *reinterpret_cast<const float2*>(g.t + f0);
   uint4 q0, q1, q2;                       // weight block in flight (one 16-byte chunk per plane)
@@ -267,7 +273,9 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
       ecol[tid] = n_col;
       escal[tid] = n_scal;
     }
-    if (tid < 64) cst[768 + tid] = g.zp[q * 64 + tid];
+    if (tid < 64) cst[768 + tid] = n_zp;
+    const float gq = n_gq;                 // (a tile does not start with a global-memory round trip)
+    const float2 pc = n_pc, zc = n_zc;
     const int cnt0 = n_cnt;
     const int64_t n0 = (item / Q) * GT;
     const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
@@ -285,9 +293,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
       int lane1 = lane;
       asm volatile("" : "+v"(lane1));
       const int half1 = lane1 >> 5, f1 = 2 * (lane1 & 31);
-      const float gq = g.g1[q];
-      const float2 pc = *reinterpret_cast<const float2*>(g.p + q * 64 + f0);
-      const float2 zc = *reinterpret_cast<const float2*>(g.z + q * 64 + f0);
       float2 hh[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) hh[i] = make_float2(0.f, 0.f);
