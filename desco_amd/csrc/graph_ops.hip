@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
 // through LDS in 16-column chunks: loaded coalesced (4 lanes x 16 B per row), read back one row per
 // thread (row stride 80 B: conflict-free ds_read_b128); the Qh rows and w2 are wave-uniform
 // ds_read_b128 broadcasts.  T crosses HBM once.  (One thread per (b, q) pair re-fetched the T row 29
-// times through the vector memory path, which then set the time.)
+// times through the vector memory path, which then set the time.)  blockIdx.y selects a group of NQ
+// queries: small batches are launched with NQ = 8 and four query groups to fill the chip.
 constexpr int HEAD_MAXQ = 32, HEAD_MAXHID = 256, HEAD_TS = 20;
 template <int NQ>
 __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict__ t, int64_t ldt,
@@ -210,16 +211,17 @@ __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict
                                                          float slope, int exp2m1,
                                                          float* __restrict__ out, int64_t ldo,
                                                          int64_t num_b, int num_q) {
-  __shared__ __attribute__((aligned(16))) float qt[NQ * HEAD_MAXHID];     // [q][hid], rows >= num_q zero
+  __shared__ __attribute__((aligned(16))) float qt[NQ * HEAD_MAXHID];     // [q - q0][hid], rows >= num_q zero
   __shared__ __attribute__((aligned(16))) float ws[HEAD_MAXHID];          // w2
   __shared__ __attribute__((aligned(16))) float wr[HEAD_MAXHID];          // (1 - slope) w2
   __shared__ __attribute__((aligned(16))) float tch[256 * HEAD_TS];       // T chunk [256 rows][16 (+4 pad)]
   __shared__ float sq[HEAD_MAXQ];                                         // b2 + slope (w2.Qh[q])
   const int tid = threadIdx.x;
+  const int q0 = blockIdx.y * NQ;  // this block's query group
   if (b2_dev) b2 = *b2_dev;        // bias read on the device (training: no host copy of a parameter)
   for (int i = tid; i < NQ * hid; i += 256) {
     const int q = i / hid, c = i - q * hid;
-    qt[i] = q < num_q ? qh[(int64_t)q * ldq + c] : 0.f;
+    qt[i] = q0 + q < num_q ? qh[(int64_t)(q0 + q) * ldq + c] : 0.f;
   }
   for (int i = tid; i < hid; i += 256) {
     ws[i] = w2[i];
@@ -286,9 +288,9 @@ __global__ __launch_bounds__(256) void count_head_kernel(const float* __restrict
       const float st = slope * ((s01.x + s01.y) + (s23.x + s23.y));
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
-        if (j < num_q) {
+        if (q0 + j < num_q) {
           const float v = (acc[j].x + acc[j].y) + (st + sq[j]);
-          out[b * ldo + j] = exp2m1 ? exp2f(v) - 1.f : v;
+          out[b * ldo + q0 + j] = exp2m1 ? exp2f(v) - 1.f : v;
         }
       }
     }
@@ -512,7 +514,11 @@ extern "C" int desco_count_head_f32(const float* t, int64_t ldt, const float* qh
     return fail(DESCO_EINVAL, "desco_count_head_f32: bad argument (num_q <= 32, hid%64, hid <= 256)");
   int64_t blocks = (num_b + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (num_q == 29)            // the standard 29 queries of sizes 3-5 (data.py:37): no padded accumulators
+  if (blocks < 512)           // small batch: four times the blocks, a quarter of the queries each
+    hipLaunchKernelGGL(count_head_kernel<8>, dim3((unsigned)blocks, (unsigned)((num_q + 7) / 8)), dim3(256), 0,
+                       (hipStream_t)stream, t, ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo,
+                       num_b, num_q);
+  else if (num_q == 29)       // the standard 29 queries of sizes 3-5 (data.py:37): no padded accumulators
     hipLaunchKernelGGL(count_head_kernel<29>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t,
                        ldt, qh, ldq, hid, w2, b2, b2_dev, slope, exp2_minus_1, out, ldo, num_b, num_q);
   else

@@ -105,17 +105,23 @@ def test_segment_sum_and_extra():
     _close(out[:, 64:128], ref, atol=1e-5)
 
 
-def test_count_head():
+@pytest.mark.parametrize("B,Q,hid,slope", [(333, 29, 256, 0.01),        # small batch: query groups of 8
+                                            (140_000, 29, 256, 0.01),   # the 29-accumulator kernel
+                                            (135_000, 7, 128, 0.01),    # padded accumulators, hid < 256
+                                            (500, 32, 64, 1.5),         # slope outside [0, 1]
+                                            (131_073, 29, 256, 0.0)])   # ragged last block, plain relu
+def test_count_head(B, Q, hid, slope):
     g = torch.Generator().manual_seed(6)
-    B, Q = 333, 29
-    t, qh = torch.randn(B, 256, generator=g), torch.randn(Q, 256, generator=g)
-    w2, b2 = torch.randn(256, generator=g) / 16, 0.3
-    pre = torch.nn.functional.leaky_relu(t.double()[:, None, :] + qh.double()[None], 0.01)
+    t, qh = torch.randn(B, hid, generator=g), torch.randn(Q, hid, generator=g)
+    w2, b2 = torch.randn(hid, generator=g) / 16, 0.3
+    idx = torch.randperm(B, generator=g)[:300]         # reference on a row sample (fp64, CPU)
+    pre = torch.nn.functional.leaky_relu(t[idx].double()[:, None, :] + qh.double()[None], slope)
     ref = pre @ w2.double() + b2
-    got = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), b2, 0.01, False)
-    _close(got, ref)
-    got2 = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), b2, 0.01, True)
-    _close(got2, 2 ** ref - 1, rtol=1e-4, atol=1e-4)
+    got = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), b2, slope, False)
+    assert got.shape == (B, Q)
+    _close(got[idx.to(DEV)], ref)
+    got2 = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), torch.tensor(b2, device=DEV), slope, True)
+    _close(got2[idx.to(DEV)], 2 ** ref - 1, rtol=1e-4, atol=1e-4)
 
 
 def test_scatter_rows_and_linear_smallk_and_rowdot():
