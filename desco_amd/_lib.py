@@ -29,6 +29,8 @@ SIGNATURES = {
     "desco_partition_export": (c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "desco_partition_free": (None, [vp]),
     "desco_canonical_counts": (c_int, [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "desco_canonical_class_table": (c_int, [vp, vp, vp, i32, vp, vp]),
+    "desco_canonical_counts_dev": (c_int, [vp, i64, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp]),
     "desco_linear_smallk_f32": (c_int, [vp, i64, i32, vp, vp, vp, i64, i64, i32, vp]),
     "desco_csr_gather_sum_f32": (c_int, [vp, i64, vp, vp, i64, i32, vp, vp]),
     "desco_gemm_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,

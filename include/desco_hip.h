@@ -120,6 +120,24 @@ int desco_canonical_counts(const int64_t* graph_ptr, int64_t num_graphs, const i
                            const int32_t* q_edges, int num_queries, int num_threads,
                            int64_t* out);
 
+/* The same counts on the GPU (csrc/groundtruth_dev.hip): queries of 2..5 nodes, at most 32, pairwise
+ * non-isomorphic (the host entry above takes the general case).
+ * HOST helper: table[1098] = for k = 2..5 nodes and every adjacency mask on k nodes (bit
+ * b(b-1)/2 + a for the pair a < b; the masks of k nodes start at offsets 0, 2, 10, 74) the index of
+ * the query of that isomorphism class, or -1; *kmax = the largest query. */
+int desco_canonical_class_table(const int32_t* q_nodes, const int32_t* q_edge_ptr,
+                                const int32_t* q_edges, int num_queries, int16_t* table, int* kmax);
+/* DEVICE: graph_ptr [G+1], rowptr [N+1] (int64), col [num_entries] (global node ids, rows ascending),
+ * node_graph [N] (graph of every node), bit_off [G] (first word of graph g's adjacency bitset: rows of
+ * ceil(n_g/64) words), bits [num_words] workspace, cls = the table above; all device pointers.
+ * out: int64 [N][num_queries], zeroed and filled by the call.  Enqueues on `stream`, does not
+ * allocate or synchronise. */
+int desco_canonical_counts_dev(const int64_t* graph_ptr, int64_t num_graphs, int64_t num_nodes,
+                               const int64_t* rowptr, int64_t num_entries, const int32_t* col,
+                               const int32_t* node_graph, const int64_t* bit_off, uint64_t* bits,
+                               int64_t num_words, const int16_t* cls, int kmax, int num_queries,
+                               int64_t* out, desco_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * DEVICE kernels
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,73 @@
+"""Device canonical-count enumerator (csrc/groundtruth_dev.hip) vs the reference's VF2 golden counts,
+the brute-force oracle and the host enumerator -- integers, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from desco_amd import synthetic  # noqa: E402
+from desco_amd.graphs import GraphSet  # noqa: E402
+from desco_amd.groundtruth import canonical_counts, canonical_counts_device  # noqa: E402
+from oracle import partition as OP  # noqa: E402
+from helpers import golden_graphs, standard_queries  # noqa: E402
+
+
+def test_device_counts_match_reference_vf2_golden(partition_golden, queries_golden, counts_golden):
+    qs = [(q["n"], [tuple(e) for e in q["edges"]]) for q in queries_golden["queries"]]
+    by_name = {g["name"]: g for g in partition_golden["graphs"]}
+    graphs = [(by_name[c["name"]]["n"], [tuple(e) for e in by_name[c["name"]]["edges"]])
+              for c in counts_golden]
+    got = canonical_counts_device(GraphSet.from_edge_lists(graphs), qs).cpu()
+    want = torch.tensor(np.concatenate([np.array(c["count"]) for c in counts_golden]), dtype=torch.int64)
+    assert got.shape == want.shape and want.sum() > 1000
+    assert torch.equal(got, want)
+
+
+def test_device_counts_vs_bruteforce_sizes_2_to_5():
+    rng = np.random.default_rng(3)
+    edges = sorted({(int(min(a, b)), int(max(a, b))) for a, b in rng.integers(0, 12, size=(30, 2)) if a != b})
+    qs = [(2, [(0, 1)]), (3, [(0, 1), (1, 2)]), (4, [(0, 1), (0, 2), (0, 3)]),
+          (5, [(i, (i + 1) % 5) for i in range(5)]), (5, [(a, b) for a in range(5) for b in range(a + 1, 5)]),
+          (4, [(0, 1), (1, 2), (2, 3), (3, 0), (0, 2)])]
+    got = canonical_counts_device(GraphSet.from_edge_lists([(12, edges)]), qs).cpu()
+    want = OP.canonical_counts_bruteforce(12, edges, qs)
+    assert got.tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("case", ["golden", "dense", "syn", "cox2"])
+def test_device_counts_equal_host_enumerator(case):
+    _, queries = standard_queries()
+    if case == "golden":
+        gs = GraphSet.from_edge_lists(golden_graphs())
+    elif case == "dense":          # dense random graphs, hubs, an isolated node, a single-node graph
+        rng = np.random.default_rng(1)
+        graphs = []
+        for n, p in [(30, 0.4), (70, 0.15), (1, 0.0), (45, 0.25), (2, 1.0)]:
+            e = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.random() < p and b != n - 1]
+            graphs.append((n, e))
+        gs = GraphSet.from_edge_lists(graphs)
+    elif case == "syn":
+        full = synthetic.WORKLOADS["syn_1827"]()
+        gs = full.subset(300, 420)
+    else:
+        gs = synthetic.WORKLOADS["cox2"]()
+    host = canonical_counts(gs, queries, backend="host")
+    dev = canonical_counts_device(gs, queries).cpu()
+    assert dev.shape == host.shape
+    assert torch.equal(dev.double(), host), (dev.double() - host).abs().max()
+    assert torch.equal(canonical_counts(gs, queries, backend="auto"), host)     # auto -> device on this box
+
+
+def test_device_path_rejections_and_fallback():
+    g = GraphSet.from_edge_lists([(6, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)])])
+    six = [(6, [(i, i + 1) for i in range(5)])]
+    with pytest.raises(RuntimeError, match="2..5 nodes"):
+        canonical_counts_device(g, six)
+    assert canonical_counts(g, six).sum() == 1                    # auto: host path for 6-node queries
+    dup = [(3, [(0, 1), (1, 2)]), (3, [(0, 2), (2, 1)])]          # the same class twice
+    with pytest.raises(RuntimeError, match="isomorphic"):
+        canonical_counts_device(g, dup)
+    assert canonical_counts(g, dup).tolist() == canonical_counts(g, dup, backend="host").tolist()
+    empty = GraphSet.from_edge_lists([(3, [])])
+    assert canonical_counts_device(empty, [(3, [(0, 1), (1, 2)])]).sum() == 0
