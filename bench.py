@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--graph", action="store_true",
                     help="replay the pass from a captured hipGraph (implies --no-profile)")
+    ap.add_argument("--neigh-rows", type=int, default=6_000_000,
+                    help="row budget of a neighborhood block (InferencePipeline max_neigh_rows)")
+    ap.add_argument("--gossip-rows", type=int, default=4_000_000,
+                    help="(node x query) row budget of a gossip block (InferencePipeline max_gossip_rows)")
     ap.add_argument("--by-shape", action="store_true",
                     help="diagnostic: key GEMM launches by shape in the kernel table")
     args = ap.parse_args()
@@ -149,7 +153,8 @@ def main():
     nm, gm = build_models(device)
     nm.set_queries(STANDARD_QUERY_IDS)
     t0 = time.perf_counter()
-    pipe = InferencePipeline(nm, gm, graphs, depth=4, device=device)
+    pipe = InferencePipeline(nm, gm, graphs, depth=4, device=device, max_neigh_rows=args.neigh_rows,
+                             max_gossip_rows=args.gossip_rows)
     t_build = time.perf_counter() - t0
     part = pipe.partition
 
