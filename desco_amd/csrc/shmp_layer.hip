@@ -227,13 +227,47 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   {                                                                                        \
     if ((b_) < KB - 1) {                                                                   \
       DESCO_CURS(b_)                                                                       \
-      live = (live & ~(1 << (b_))) | (__any((c0 < n0) | (c1 < n1) | (c2 < n2) | (c3 < n3)) ? 1 << (b_) : 0); \
       DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                \
       DESCO_ISSUE2(2, xb, LDX) DESCO_ISSUE2(3, xb, LDX)                                \
     } else if ((b_) == KB - 1) {                                                           \
       DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1) DESCO_ISSUE_SELF(2) DESCO_ISSUE_SELF(3)      \
     } else {                                                                               \
       DESCO_ISSUE_TAB(0) DESCO_ISSUE_TAB(1) DESCO_ISSUE_TAB(2) DESCO_ISSUE_TAB(3)          \
+    }                                                                                      \
+  }
+// bit s of `live`: relation slot s (an MFMA slot) has at least one source among the wave's 32 rows
+#define DESCO_SLOT_LIVE(s_)                                                                \
+  (__any((rp[(0 * 8 + g8) * S + (s_) + 1] > rp[(0 * 8 + g8) * S + (s_)]) |                  \
+         (rp[(1 * 8 + g8) * S + (s_) + 1] > rp[(1 * 8 + g8) * S + (s_)]) |                  \
+         (rp[(2 * 8 + g8) * S + (s_) + 1] > rp[(2 * 8 + g8) * S + (s_)]) |                  \
+         (rp[(3 * 8 + g8) * S + (s_) + 1] > rp[(3 * 8 + g8) * S + (s_)]))                   \
+       ? 1 << (s_) : 0)
+#define DESCO_TILE_LIVE()                                        \
+  {                                                              \
+    live = 0;                                                    \
+    if (KB - 1 > 0) live |= DESCO_SLOT_LIVE(0);                  \
+    if (KB - 1 > 1) live |= DESCO_SLOT_LIVE(1);                  \
+    if (KB - 1 > 2) live |= DESCO_SLOT_LIVE(2);                  \
+  }
+// first step of the first LIVE block after block a_ (a_ = -1: of the tile); dead slots are left
+// out of the software pipeline altogether, so the block behind one is not issued late.  The slot
+// index is a wave-uniform runtime value here (one copy of the gather issue code per site).
+#define DESCO_ISSUE_AFTER(a_)                                                              \
+  {                                                                                        \
+    if ((a_) < KB - 1) {                                                                   \
+      int nb_ = KB - 1;                                                                    \
+      if ((a_) + 3 < KB - 1 && ((live >> ((a_) + 3)) & 1)) nb_ = (a_) + 3;                  \
+      if ((a_) + 2 < KB - 1 && ((live >> ((a_) + 2)) & 1)) nb_ = (a_) + 2;                  \
+      if ((a_) + 1 < KB - 1 && ((live >> ((a_) + 1)) & 1)) nb_ = (a_) + 1;                  \
+      if (nb_ < KB - 1) {                                                                  \
+        DESCO_CURS(nb_)                                                                    \
+        DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                  \
+        DESCO_ISSUE2(2, xb, LDX) DESCO_ISSUE2(3, xb, LDX)                                  \
+      } else {                                                                             \
+        DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1) DESCO_ISSUE_SELF(2) DESCO_ISSUE_SELF(3)    \
+      }                                                                                    \
+    } else if ((a_) + 1 < NB) {                                                            \
+      DESCO_ISSUE_BLOCK((a_) + 1)                                                          \
     }                                                                                      \
   }
 // write one fp32 half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
@@ -377,9 +411,11 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   int c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;   // cursors [c, n) rel. to ebase
   // bit b: relation slot b has at least one source among this wave's 32 rows.  A slot that is empty
   // for the whole wave tile (triangle edges in molecule graphs, tride edges in clique unions) is an
-  // all-zero K block: its splits and MFMAs are skipped (wave-uniform branch; adds exact zeros otherwise)
+  // all-zero K block: it is left out of the tile's block sequence (wave-uniform; it would add exact
+  // zeros), and the first gather step of the block behind it is issued in its place
   int live = 0;
-  DESCO_ISSUE_BLOCK(0)
+  DESCO_TILE_LIVE()
+  DESCO_ISSUE_AFTER(-1)
 
   for (;;) {
     int* rpn = rpb + (cur ^ 1) * RPN;
@@ -414,6 +450,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      if (b < KB - 1 && !((live >> b) & 1)) continue;      // empty relation slot (wave-uniform)
       // ---- complete the gather of block b ------------------------------------------------------
       DESCO_ZERO_SUMS()
       if (b < KB - 1) {
@@ -437,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
           DESCO_COOP(3, yb + 64, LDY)
         }
       }
-      if (b == 0 && has_next) {
+      if (b == KB - 1 && has_next) {
         // next tile's row pointers have landed: publish them, then fetch its source ids
         rpn[lane] = p0;
         if (lane + 64 < nslot) rpn[lane + 64] = p1;
@@ -449,16 +486,15 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
-      const bool block_live = b >= KB - 1 || ((live >> b) & 1);      // wave-uniform
-      if (block_live) {
+      {
         if (X6 && b < KB) {
           DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1) DESCO_PUT_X6(lo2, 2) DESCO_PUT_X6(lo3, 3)
         } else {
           DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1) DESCO_PUT_F32(lo2, 2) DESCO_PUT_F32(lo3, 3)
         }
       }
-      if (b + 1 < NB) DESCO_ISSUE_BLOCK(b + 1)
-      if (block_live) {
+      DESCO_ISSUE_AFTER(b)
+      {
         if (b >= KB) {
           DESCO_TAB_HALF(acc0)
         } else if (X6) {
@@ -495,7 +531,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       w0 = w0n;
       nr = nrn;
       grow0 = g.row0 + w0n;
-      DESCO_ISSUE_BLOCK(0)
+      DESCO_TILE_LIVE()
+      DESCO_ISSUE_AFTER(-1)
     }
 
     // ---- epilogue: relu + store; C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5) ----
@@ -621,6 +658,9 @@ __global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
 #undef DESCO_COOP
 #undef DESCO_FINISH
 #undef DESCO_ISSUE_BLOCK
+#undef DESCO_ISSUE_AFTER
+#undef DESCO_TILE_LIVE
+#undef DESCO_SLOT_LIVE
 #undef DESCO_PUT_F32
 #undef DESCO_PUT_X6
 #undef DESCO_MFMA_HALF_F32
