@@ -49,9 +49,10 @@ constexpr int APS = 40;       // half-K bf16 plane row stride (shorts, 80 B): co
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
 constexpr int EXTRA_STEPS = 5; // batched 2-source steps after the prefetched one (<= 12 sources per row)
-constexpr int WCAP = 128;     // source ids staged per wave (longer slices fall back to global)
+constexpr int WCAP = 256;     // source ids staged per wave (longer slices fall back to global);
+                              // one buffer: the next tile's ids wait in registers until the switch
 constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(32*33, 3*32*40/2) floats
-constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
+constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + WCAP;      // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
 
 // absent sources of a batched gather step read this row instead of being predicated away
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   float* Aw = lds + W_FLOATS + wave * WAVE_LDS;            // fp32 half image [32][33] (f32 mode, table block)
   short* Ap = reinterpret_cast<short*>(Aw);                // x6: bf16 planes [3][32][40] of a half image
   int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [32*S+1] row pointers (absolute)
-  int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids
+  int* ec = rpb + 2 * RPN;                                 // [WCAP] source ids of the current tile
   (void)Bimg; (void)Wp; (void)Ap;
 
   // ---- resident weights -------------------------------------------------------------------
@@ -391,7 +392,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   int64_t grow0 = g.row0 + w0;
   int cur = 0;
   int* rp = rpb;
-  int* ec = ecb;
   if (S > 0) {                                             // S == 0: no CSR at all (plain row-wise Linear)
     const int nptr = nr * S + 1;
     for (int i = lane; i < nslot; i += 64)
@@ -419,7 +419,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
 
   for (;;) {
     int* rpn = rpb + (cur ^ 1) * RPN;
-    int* ecn = ecb + (cur ^ 1) * WCAP;
     // ---- prefetch the row pointers of the next tile (registers now, LDS later) --------------
     const int64_t tn = tile + gridDim.x;
     const int64_t w0n = tn * (NW * WR) + wave * WR;
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
       if (lane + 128 < nslot) p2 = src[lane + 128 < nptr ? lane + 128 : nptr - 1];
     }
-    int qn0 = 0, qn1 = 0;      // source ids of the next tile (registers until the tile ends)
+    int qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0;   // source ids of the next tile (registers until the tile ends)
     int ebn = 0, ecntn = 0;
 
     // ---- accumulator init: bias ----------------------------------------------------------------
@@ -483,6 +482,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
         ecntn = rpn[WR * S] - ebn;
         if (lane < ecntn) qn0 = g.vcol[ebn + lane];
         if (lane + 64 < ecntn) qn1 = g.vcol[ebn + lane + 64];
+        if (lane + 128 < ecntn) qn2 = g.vcol[ebn + lane + 128];
+        if (lane + 192 < ecntn) qn3 = g.vcol[ebn + lane + 192];
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
@@ -521,11 +522,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     const int64_t grow_out = grow0;
     const int nr_out = nr;
     if (has_next) {
-      if (lane < ecntn) ecn[lane] = qn0;
-      if (lane + 64 < ecntn && lane + 64 < WCAP) ecn[lane + 64] = qn1;
+      if (lane < ecntn) ec[lane] = qn0;            // (the current tile's ids are dead by now)
+      if (lane + 64 < ecntn) ec[lane + 64] = qn1;
+      if (lane + 128 < ecntn) ec[lane + 128] = qn2;
+      if (lane + 192 < ecntn) ec[lane + 192] = qn3;
       cur ^= 1;
       rp = rpn;
-      ec = ecn;
       ebase = ebn;
       tile = tn;
       w0 = w0n;
