@@ -48,7 +48,7 @@ constexpr int AH = 33;        // half-K fp32 A image row stride (floats): confli
 constexpr int APS = 40;       // half-K bf16 plane row stride (shorts, 80 B): conflict-free ds_read_b128
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
-constexpr int EXTRA_STEPS = 5; // batched 2-source steps after the prefetched one (<= 12 sources per row)
+constexpr int EXTRA_STEPS = 9; // batched 2-source steps after the prefetched one (<= 20 sources per row)
 constexpr int WCAP = 512;     // source ids staged per wave (longer slices fall back to global);
                               // one buffer: the next tile's first 256 ids wait in registers until
                               // the switch, a denser tile fetches the rest then

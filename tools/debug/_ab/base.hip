@@ -49,8 +49,9 @@ constexpr int APS = 40;       // half-K bf16 plane row stride (shorts, 80 B): co
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 1;
 constexpr int EXTRA_STEPS = 5; // batched 2-source steps after the prefetched one (<= 12 sources per row)
-constexpr int WCAP = 256;     // source ids staged per wave (longer slices fall back to global);
-                              // one buffer: the next tile's ids wait in registers until the switch
+constexpr int WCAP = 512;     // source ids staged per wave (longer slices fall back to global);
+                              // one buffer: the next tile's first 256 ids wait in registers until
+                              // the switch, a denser tile fetches the rest then
 constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(32*33, 3*32*40/2) floats
 constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + WCAP;      // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
@@ -526,6 +527,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
       if (lane + 64 < ecntn) ec[lane + 64] = qn1;
       if (lane + 128 < ecntn) ec[lane + 128] = qn2;
       if (lane + 192 < ecntn) ec[lane + 192] = qn3;
+      if (ecntn > 256) {                           // dense tile (wave-uniform): ids 256..511 now
+        for (int i = 256 + lane; i < ecntn && i < WCAP; i += 64) ec[i] = g.vcol[ebn + i];
+      }
       cur ^= 1;
       rp = rpn;
       ebase = ebn;
