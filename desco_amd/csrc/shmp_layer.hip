@@ -15,17 +15,21 @@
 //     are loaded into LDS ONCE per block and stay resident while the block strides over 256-row tiles;
 //   * every wave owns 32 destination rows of a tile end to end and never meets a block barrier in
 //     the tile loop;
-//   * the CSR slice of the wave's NEXT tile (row pointers, then up to WCAP source ids) is
-//     prefetched into a second private LDS buffer under the current tile's work;
+//   * the CSR slice of the wave's NEXT tile is prefetched under the current tile's work: its row
+//     pointers into a second private LDS buffer, its first 256 source ids into registers that are
+//     written over the (then dead) id buffer at the tile switch; ids 256..WCAP of a dense tile are
+//     fetched at the switch;
 //   * gathers are batched and branch-free: lane group g8 (8 lanes x float4) serves rows it*8+g8,
 //     it = 0..3, and one step fetches two sources x both 128-B halves for all four rows = 16 loads
 //     in flight together; absent sources read a row of zeros instead of being predicated away (a
 //     load under a divergent branch is fenced by its own s_waitcnt and serialises the round trips);
-//   * the first gather step of K block b+1 is issued BEFORE the MFMAs of block b, and block 0 of the
-//     next tile before the epilogue stores of the current one, so feature-row latency hides under
-//     the matrix work of the same wave;
-//   * rows with more than 4 sources in a slot (hub rows, canonical rows of dense neighborhoods)
-//     are finished cooperatively by the whole wave (8 lane groups stride over one row's sources);
+//   * the first gather step of the next LIVE K block is issued BEFORE the MFMAs of block b, and the
+//     first live block of the next tile before the epilogue stores of the current one, so
+//     feature-row latency hides under the matrix work of the same wave; a relation slot without a
+//     source in the wave's 32 rows is dead: no gather, no split, no MFMAs (exact zeros);
+//   * rows with more than 2 sources in a slot take up to EXTRA_STEPS more batched steps; beyond that
+//     (hub rows, canonical rows of dense neighborhoods, ids past WCAP) they are finished
+//     cooperatively by the whole wave (8 lane groups stride over one row's sources);
 //   * table slots run as one extra pseudo K block: their pre-transformed source rows are gathered
 //     the same way, staged in the A image and ADDED to the accumulators in the C/D layout;
 //   * HBM traffic per row and layer: one 256-B read of x, one 256-B write, ~20 B of indices
