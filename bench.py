@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- graphs/sec of the DeSCo hot path (29-query neighborhood + gossip inference).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full pass of the hot path (neighborhood counting -> apply_neighborhood_count ->
 gossip propagation -> per-graph aggregation, main.py:296-302, 417-423 of the reference) over the
 rank's resident shard: a COX2-shaped synthetic dataset (467 graphs, BASELINE.json configs[1])
 replicated ``--replicas`` times so that one pass saturates the GPU.  Inputs (CSR blocks, weights)
-are resident in HBM before the timed region.  Data parallel over graphs, no data-path collective
-(weak scaling: every rank owns the same number of graphs).
+are resident in HBM before the timed region.  Data parallel over graphs, no data-path collective.
+``--scaling weak`` (default): every rank owns the same number of graphs; ``--scaling strong``: ONE
+dataset (workload x replicas) is cut into cost-balanced graph ranges (distributed.shard_graphs)
+and rank 0 assembles the per-graph counts of all ranks (InferencePipeline.gather).
+
+Without a torchrun environment, ``--gpus N`` (N > 1) starts N worker processes itself BEFORE
+anything touches the GPU (desco_amd.distributed.launch: fresh children, never an exec), each
+joins the RCCL group and asserts world_size == N.
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
-  "roofline":     dominant kernel, achieved vs peak from HIP events recorded live in the timed region
-  "cpu_baseline": the CPU oracle (reference-form torch port) timed on a bounded sample (N=1 only)
+  "roofline":     dominant kernel, achieved vs peak from HIP events recorded live in the timed
+                  region; "gather" = the fused SHMP layer kernel (the north_star's gather) priced
+                  against HBM, with its PMC traffic
+  "cpu_baseline": the CPU oracle (reference-form torch port) on PRE-BUILT batches, timed with
+                  1 thread and with all physical cores on a bounded sample (N=1 only)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,15 +37,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s, ~6.3 achievable)
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (same guide)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (same guide)
 # fp32-accurate kernels on the bf16 pipe ("bf16x6"): every algorithmic fp32 multiply-add is six bf16
 # MFMA products, so the speed of light of the ALGORITHM is the bf16 peak / 6 in fp32-equivalent flops
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+GATHER_KERNEL = "shmp_layer_f32_kernel<3,2,x6>"     # count-row launches of the fused SHMP layer
 
 
 def mfma_peak(kernel: str):
@@ -50,6 +58,7 @@ def mfma_peak(kernel: str):
 def build_models(device, seed=0):
     """Random-init weights of the reference architecture (no checkpoint is reachable offline):
     default nn.Linear init, matrices widened so that 8 relu layers keep O(1), finite activations."""
+    import torch
     from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
     na = argparse.Namespace(layer_num=8, conv_type="SAGE", use_hetero=True, dropout=0.0, depth=4,
                             lr=1e-4, weight_decay=0.0, use_tconv=True, hidden_dim=64, input_dim=1,
@@ -70,34 +79,67 @@ def build_models(device, seed=0):
     return nm.to(device), gm.to(device)
 
 
-def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=15.0):
-    """The CPU oracle in the reference's form on a bounded sample of the same workload."""
+def host_cpu_info():
+    """(model string, physical cores, logical cores) from lscpu (fallback: os.cpu_count)."""
+    logical = os.cpu_count() or 1
+    model, phys = "unknown", logical
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for line in txt.splitlines():
+            if ":" in line:
+                k, v = line.split(":", 1)
+                kv[k.strip()] = v.strip()
+        model = kv.get("Model name", model)
+        cps, soc = int(kv.get("Core(s) per socket", "0")), int(kv.get("Socket(s)", "0"))
+        if cps > 0 and soc > 0:
+            phys = cps * soc
+    except Exception:      # lscpu missing: keep the fallback
+        pass
+    try:                   # cores this process may actually use (cgroup / affinity limits)
+        phys = max(1, min(phys, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    return model, phys, logical
+
+
+def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0):
+    """The CPU oracle in the reference's form on a bounded sample of the same workload, on
+    PRE-BUILT batches (canonical partition, triangle split and collate excluded, as on the GPU
+    side -- SURVEY 8d), timed with k = 1 thread and with k = all physical cores."""
+    import torch
     from oracle import model as OM
     sd_n = {k: v.detach().cpu().float() for k, v in nm.state_dict().items()}
     sd_g = {k: v.detach().cpu().float() for k, v in gm.state_dict().items()}
-    # torch's intra-op threading only pays on large ops; this path is thousands of tiny ones, so
-    # pick the faster of 1 thread and min(8, cores) (the reference's --num_cpu default) on a probe
-    host_cores = os.cpu_count() or 1
-    probe = graphs_host[:2]
-    best = None
-    for nt in sorted({1, min(8, host_cores)}):
-        torch.set_num_threads(nt)
-        t0 = time.perf_counter()
-        OM.reference_pipeline(sd_n, sd_g, probe, queries, emulate_quirk=False)
-        dt = (time.perf_counter() - t0) / len(probe)
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-    per_graph, cores = best
-    torch.set_num_threads(cores)
-    n = int(max(2, min(8 * len(graphs_host), target_seconds / max(per_graph, 1e-6))))
+    model, phys, logical = host_cpu_info()
+    # size the sample from a 2-graph probe with one thread
+    torch.set_num_threads(1)
+    probe = OM.prebuild_reference_inputs(graphs_host[:2], queries)
+    t0 = time.perf_counter()
+    OM.run_reference_prebuilt(sd_n, sd_g, probe, emulate_quirk=False)
+    per_graph = (time.perf_counter() - t0) / 2
+    n = int(max(2, min(4 * len(graphs_host), 0.5 * target_seconds / max(per_graph, 1e-6))))
     sample = [graphs_host[i % len(graphs_host)] for i in range(n)]     # cycles over the dataset
     t0 = time.perf_counter()
-    ref = OM.reference_pipeline(sd_n, sd_g, sample, queries, emulate_quirk=False)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} graphs cycling over the synthetic set (incl. canonical partition), "
-                      f"reference-form batches 512/256, {dt:.1f} s, torch fp32, {cores} threads "
-                      f"(best of 1 / {min(8, host_cores)} threads on a probe; host has {host_cores} logical cores)"}, ref, n
+    pre = OM.prebuild_reference_inputs(sample, queries)
+    t_prep = time.perf_counter() - t0
+    runs, ref = {}, None
+    for k in sorted({1, phys}):
+        torch.set_num_threads(k)
+        t0 = time.perf_counter()
+        ref = OM.run_reference_prebuilt(sd_n, sd_g, pre, emulate_quirk=False)
+        runs[k] = n / (time.perf_counter() - t0)
+    best_k = max(runs, key=runs.get)
+    torch.set_num_threads(max(1, min(8, phys)))
+    return {"value": runs[best_k], "unit": "graphs/s", "cores": best_k, "kind": "port",
+            "value_1_thread": runs[1], "value_all_physical_cores": runs[phys], "physical_cores": phys,
+            "logical_cores": logical, "cpu_model": model,
+            "sample": f"{n} graphs cycling over the synthetic set; reference-form model (per-edge-type "
+                      f"index_select/index_add_/Linear, 29-iteration loops, queries re-embedded per batch, "
+                      f"batches 512/256, torch fp32) on PRE-BUILT collated batches: the oracle's Python "
+                      f"canonical partition + triangle split + collate ({t_prep:.1f} s for the sample) is "
+                      f"excluded, as the partition build is excluded from the GPU's timed region; "
+                      f"value = best of k=1 ({runs[1]:.1f}) and k={phys} physical cores ({runs[phys]:.1f})"}, ref, n
 
 
 def main():
@@ -106,10 +148,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cox2", choices=["cox2", "mutag", "syn_1827", "msrc_imdb"])
-    ap.add_argument("--replicas", type=int, default=64, help="dataset replication factor per rank")
+    ap.add_argument("--replicas", type=int, default=64, help="dataset replication factor per rank "
+                    "(weak scaling) or of the one global dataset (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--no-x1", action="store_true", help="skip the small-dataset (x1) latency line")
     ap.add_argument("--graph", action="store_true",
                     help="replay the pass from a captured hipGraph (implies --no-profile)")
     ap.add_argument("--neigh-rows", type=int, default=6_000_000,
@@ -120,29 +165,24 @@ def main():
                     help="diagnostic: key GEMM launches by shape in the kernel table")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from desco_amd import distributed as D      # (imports torch; no GPU call)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves, before any GPU call in this process
+        sys.exit(D.launch([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    import torch
+    rank, world, local_rank = D.env_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher must "
+                         f"start exactly --gpus ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # DESCO_BENCH_SHARE_GPU=1 (testing only): all ranks on device 0 with the gloo backend, to
-    # exercise the multi-rank control flow on a 1-GPU box; the driver's runs use one GPU per rank
-    # and RCCL ("nccl").
-    share = os.environ.get("DESCO_BENCH_SHARE_GPU") == "1"
-    dev_index = 0 if share else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-    comm_dev = torch.device("cpu") if share else device
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # DESCO_SHARE_GPU=1 (testing only): all ranks on device 0 with the gloo backend, to exercise the
+    # multi-rank control flow on a 1-GPU box; real runs use one GPU per rank and RCCL ("nccl")
+    share = D.share_gpu()
+    device = D.local_device()
+    D.init_from_env(device)
+    assert D.world_size() == args.gpus, (D.world_size(), args.gpus)
 
     from desco_amd import ops, synthetic
     from desco_amd.data import STANDARD_QUERY_IDS
@@ -152,17 +192,18 @@ def main():
     graphs = base.replicate(args.replicas)
     nm, gm = build_models(device)
     nm.set_queries(STANDARD_QUERY_IDS)
+    strong = args.scaling == "strong"
     t0 = time.perf_counter()
     pipe = InferencePipeline(nm, gm, graphs, depth=4, device=device, max_neigh_rows=args.neigh_rows,
-                             max_gossip_rows=args.gossip_rows)
+                             max_gossip_rows=args.gossip_rows,
+                             rank=rank if strong else 0, world=world if strong else 1)
     t_build = time.perf_counter() - t0
     part = pipe.partition
 
     def sync():
         torch.cuda.synchronize(device)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(device)
+        D.barrier()
+        torch.cuda.synchronize(device)
 
     if args.graph:
         args.no_profile = True
@@ -180,34 +221,41 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ops.PROFILER.enabled = False
-    if dist is not None:
+    comm_dev = torch.device("cpu") if share else device
+    if world > 1:
         t = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        D.all_reduce_(t, "max")
         elapsed = float(t.item())
-        # the only exchange of the inference path: graph-level counts to rank 0
-        mine = out["graph_gossip_count"].to(comm_dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
+    # the only exchange of the inference path: per-graph counts to rank 0
+    if strong:
+        gathered = pipe.gather(out)
         if rank == 0:
-            assert all(torch.isfinite(gt).all() for gt in gathered)
+            assert gathered["graph_gossip_count"].shape[0] == graphs.num_graphs
+            assert torch.isfinite(gathered["graph_gossip_count"]).all()
+    elif world > 1:
+        g_all = D.gather_rows(out["graph_gossip_count"])
+        if rank == 0:
+            assert g_all.shape[0] == graphs.num_graphs * world and torch.isfinite(g_all).all()
 
-    graphs_per_step = graphs.num_graphs * world
+    graphs_per_step = graphs.num_graphs if strong else graphs.num_graphs * world
     value = graphs_per_step * args.steps / elapsed
+    cnt = torch.tensor([pipe.graphs.num_graphs, pipe.graphs.num_nodes, part.num_neigh, part.num_rows,
+                        part.num_edges], dtype=torch.int64)
     result = {
         "metric": "graphs/sec (29-query neighborhood+gossip inference)",
         "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "arithmetic": "fp32 in/out; matrix products as 6 bf16 MFMA products per multiply-add (3-way "
                       "truncation split, fp32 accumulation): fp32-accurate, see DESIGN.md section 4",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}-shaped synthetic ({base.num_graphs} graphs) x{args.replicas} "
-                        f"replicas per GPU, 29 standard queries, depth-4 canonical neighborhoods, "
-                        f"neighborhood+gossip inference, random-init weights",
-            "graphs_per_gpu": graphs.num_graphs, "nodes_per_gpu": graphs.num_nodes,
-            "neighborhoods_per_gpu": part.num_neigh, "neighborhood_rows_per_gpu": part.num_rows,
-            "neighborhood_directed_edges_per_gpu": part.num_edges,
+                        f"replicas {'in total' if strong else 'per GPU'}, 29 standard queries, depth-4 "
+                        f"canonical neighborhoods, neighborhood+gossip inference, random-init weights",
+            "graphs_per_gpu": int(cnt[0]), "nodes_per_gpu": int(cnt[1]),
+            "neighborhoods_per_gpu": int(cnt[2]), "neighborhood_rows_per_gpu": int(cnt[3]),
+            "neighborhood_directed_edges_per_gpu": int(cnt[4]),
             "parallelism": f"dp{world} (graph sharding, no data-path collective)",
             "partition_build_s": round(t_build, 3), "partition_backend": pipe.partition_backend,
             "launch_mode": "hipGraph replay" if args.graph else "eager launches",
@@ -216,17 +264,26 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from the HIP events of the timed region -----------
-        roof = None
         if not args.no_profile:
             summ = ops.PROFILER.summary()
             tot = sum(d["ms"] for d in summ.values())
             name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
             calls = d["calls"]
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+            # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS
+            # workload (tools/profile_round.sh; gfx950-corrected), keyed "<workload>_x<replicas>"
+            pmc = pmc_all.get("workloads", {}).get(f"{args.workload}_x{args.replicas}", {})
+
+            def traffic(kernel):
+                e = pmc.get("kernels", {}).get(kernel)
+                return None if not e or world != 1 else e["hbm_bytes_per_launch"]
+
             mp = mfma_peak(name)
             if mp is not None:
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": mp[0],
-                        "unit": "TFLOP/s", "frac": ach / mp[0], "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / mp[0], "traffic": traffic(name),
                         "pipe": mp[1],
                         "note": "achieved/peak in algorithmic fp32 flops; executed bf16 flops are 6x "
                                 "(frac = matrix-pipe utilisation)" if mp[0] == PEAK_X6_TFLOPS else
@@ -234,22 +291,52 @@ def main():
             else:
                 ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_path) and args.workload == "cox2" and args.replicas == 64:
-                pmc = json.load(open(pmc_path))["kernels"].get(name)
-                if pmc:     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                    roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, gfx950-corrected)"
+                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic(name)}
             roof.update({"kernel": name, "launches": calls, "avg_launch_ms": d["ms"] / calls,
                          "share_of_kernel_time": d["ms"] / tot,
-                         "algorithmic_per_launch": (d["flops"] if roof["bound"] == "mfma" else d["bytes"]) / calls})
+                         "algorithmic_per_launch": (d["flops"] if roof["bound"] == "mfma" else d["bytes"]) / calls,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes, gfx950-corrected)" if roof["traffic"] else None})
+            # the north_star's gather = the fused SHMP layer's count-row launches, priced against HBM
+            gk = summ.get(GATHER_KERNEL)
+            if gk and gk["ms"] > 0:
+                gbs = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
+                tfs = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+                tr = traffic(GATHER_KERNEL)
+                alg = gk["bytes"] / gk["calls"]
+                roof["gather"] = {
+                    "kernel": GATHER_KERNEL, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": gk["calls"],
+                    "avg_launch_ms": gk["ms"] / gk["calls"], "share_of_kernel_time": gk["ms"] / tot,
+                    "algorithmic_bytes_per_launch": alg, "traffic": tr,
+                    "traffic_over_algorithmic": None if tr is None else tr / alg,
+                    "mfma_TFLOPs": tfs, "mfma_frac_of_x6_peak": tfs / PEAK_X6_TFLOPS,
+                    "note": "x rows once + out rows once + indices per launch (DESIGN.md section 4); "
+                            "the same launches also run the layer's folded GEMM on the matrix pipe"}
             result["roofline"] = roof
             result["kernels"] = {
                 k: {"calls": v["calls"], "ms": round(v["ms"], 3),
                     "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 else None,
                     "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        # ---- small-dataset latency: the real dataset size (x1), hipGraph replay vs eager --------
+        if world == 1 and not args.no_x1 and args.replicas != 1:
+            p1 = InferencePipeline(nm, gm, base, depth=4, device=device)
+            lat = {}
+            for mode, fn in (("eager", p1.run), ("hipgraph_replay", p1.step)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    fn()
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - t0) / 50
+                lat[mode] = {"ms_per_pass": 1e3 * dt, "graphs_per_s": base.num_graphs / dt}
+            lat["graphs"] = base.num_graphs
+            lat["note"] = ("one pass over the un-replicated dataset; InferencePipeline.step() replays a "
+                           "hipGraph for shards under 400k neighborhood rows (launch-bound otherwise)")
+            result["latency_x1"] = lat
         # ---- CPU baseline (N=1 only) + parity of the sample ------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as f:
@@ -263,7 +350,8 @@ def main():
             result["cpu_baseline"] = cb
             result["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(result))
-    if dist is not None:
+    if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

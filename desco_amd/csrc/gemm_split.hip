@@ -277,12 +277,12 @@ template <int WN, int NP>
 static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
   constexpr int BN = 64 * WN;
   constexpr size_t lds_bytes = (size_t)(NP * APLANE + NP * BN * SST) * sizeof(short);
-  static bool configured = false;     // benign race: the attribute is idempotent
-  if (!configured) {
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN, NP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_f32: cannot size LDS");
-    configured = true;
+    attr_once.mark();
   }
   const int64_t gm = (g.m + SBM - 1) / SBM;
   const int ny = g.n / BN;

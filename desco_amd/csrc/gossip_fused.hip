@@ -538,13 +538,13 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                     reinterpret_cast<const short*>(w1_planes), reinterpret_cast<const short*>(wp_planes),
                     reinterpret_cast<const short*>(w3_planes), b3,
                     reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out};
-  static bool attr_set = false;     // benign race: the attribute is idempotent
-  if (!attr_set) {
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)GOSSIP_LDS_BYTES);
     if (e != hipSuccess) return fail((int)e, "desco_gossip_fused_f32: cannot size LDS");
-    attr_set = true;
+    attr_once.mark();
   }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {

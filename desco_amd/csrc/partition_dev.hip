@@ -363,13 +363,13 @@ static int part_dev_launch(bool fill, const PartDevArgs& a, int num_waves, hipSt
   if (lds > 160 * 1024)
     return fail(DESCO_EINVAL, "desco_partition_dev: largest graph does not fit the LDS workspace "
                               "(use desco_partition_build)");
-  static bool attr_set = false;     // benign race: the attribute is idempotent
-  if (!attr_set) {
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_dev_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(partition_dev_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.mark();
   }
   if (fill)
     hipLaunchKernelGGL(partition_dev_kernel<true>, dim3(blocks), dim3(256), lds, st, a);

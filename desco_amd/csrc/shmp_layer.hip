@@ -683,11 +683,11 @@ static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr size_t w_floats = X6 ? (size_t)3 * 64 * WST / 2 : (size_t)KB * 64 * 64;
   constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS);
   static_assert(shmem <= 160 * 1024, "SHMP layer: LDS budget exceeded");
-  static bool attr_set = false;     // benign race: the attribute is idempotent
-  if (!attr_set) {
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6, LD64>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.mark();
   }
   hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6, LD64>), dim3(grid), dim3(NW * 64), shmem, st, g);
 }
@@ -724,7 +724,8 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
       slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
       ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
-      (slots_table > 0 && mis16(ytab)) || x == out || x == out2)
+      (slots_table > 0 && mis16(ytab)) || x == out || x == out2 ||
+      mis16(out) || ldo % 4 || (out2 && (mis16(out2) || ldo2 % 4)))      // float4 stores
     return fail(DESCO_EINVAL,
                 x6 ? "desco_shmp_layer_bf16x6_f32: bad argument (slots_mfma <= 2, slots_table <= 2)"
                    : "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
@@ -810,7 +811,7 @@ extern "C" int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int1
   if (num_rows == 0 || num_blocks == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (!x || !w_planes || !out || num_rows < 0 || num_blocks < 0 || ldx % 4 || mis16(x) ||
-      mis16(w_planes) || x == out)
+      mis16(w_planes) || x == out || mis16(out) || ldo % 4)
     return fail(DESCO_EINVAL, "desco_linear64_bf16x6_f32: bad argument");
   const int64_t ntiles = (num_rows + NW * WR - 1) / (NW * WR);
   int dev = 0, cus = 256;
@@ -820,13 +821,13 @@ extern "C" int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int1
       cus = v;
   }
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  static bool attr_set = false;     // benign race: the attribute is idempotent
-  if (!attr_set) {
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear64_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear64_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_once.mark();
   }
   constexpr size_t wave_bytes = sizeof(float) * (size_t)NW * A_FLOATS;
   for (int j = 0; j < num_blocks;) {

@@ -1,14 +1,30 @@
 """Multi-GPU support: the path shards by independent target graphs.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
-Inference: cost-balanced contiguous graph ranges, no data-path collective, one gather of the
-[G,29] graph-level counts.  Training: flat-bucket gradient all-reduce (``allreduce_grads``).
-The reference only has Lightning DDP for neighborhood training (main.py:242-255) and runs
-inference on one device.
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU
+tests and in the shared-GPU test mode).  Nothing here is a translation of the reference's NCCL
+usage: the reference only has Lightning DDP for neighborhood training (main.py:242-255), refuses
+it for the gossip model (main.py:353-356) and runs inference on one device.
+
+  launch / init_from_env   start N ranks BEFORE any GPU call / join the process group
+  shard_graphs             inference: cost-balanced contiguous graph ranges, no data-path collective
+  allgather_rows / gather_rows   the one exchange of the inference path ([G,29] counts, 54 KB on COX2)
+  GradBuckets              training: gradients live in a few flat buckets (p.grad are views), each
+                           bucket's all-reduce is issued from an autograd hook as soon as its last
+                           gradient is accumulated, i.e. overlapped with the rest of backward
+  step_groups              equal-work packing of the reference's batch stream over the ranks with
+                           count weights, so that the N-rank gradient equals the gradient of the
+                           single-process loss over the union batch (the loss is a mean)
+
+Environment: DESCO_SHARE_GPU=1 (tests on a 1-GPU box): every rank uses cuda:0 and the "gloo"
+backend; collectives on device tensors are staged through host memory.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -16,6 +32,212 @@ import torch
 from .graphs import GraphSet
 
 
+# ------------------------------------------------------------------------------------------------
+# process management
+# ------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def share_gpu() -> bool:
+    return os.environ.get("DESCO_SHARE_GPU") == "1" or os.environ.get("DESCO_BENCH_SHARE_GPU") == "1"
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun-style environment (1 process: 0, 1, 0)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def is_initialized() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if is_initialized() else 1
+
+
+def rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if is_initialized() else 0
+
+
+def local_device(devices: Optional[Sequence[int]] = None, accelerator: str = "gpu") -> torch.device:
+    """This rank's device: devices[LOCAL_RANK] when the list covers the world, else cuda:LOCAL_RANK
+    (cuda:0 for every rank in the shared-GPU test mode; devices[0] in a single process)."""
+    if accelerator == "cpu":
+        return torch.device("cpu")
+    if share_gpu():
+        return torch.device("cuda", 0)
+    _, world, lr = env_world()
+    devs = [int(d) for d in devices] if isinstance(devices, (list, tuple)) else []
+    if world > 1:
+        return torch.device("cuda", devs[lr] if len(devs) >= world else lr)
+    return torch.device("cuda", devs[0] if devs else 0)
+
+
+def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] = None) -> bool:
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (set by ``launch``, by
+    ``python -m torch.distributed.run`` or by the driver).  Returns True when world_size > 1.
+    Call it before the first collective; the GPU is bound with torch.cuda.set_device first."""
+    import torch.distributed as dist
+    r, w, _ = env_world()
+    if device is not None and device.type == "cuda":
+        torch.cuda.set_device(device)
+    if w <= 1:
+        return False
+    if dist.is_initialized():
+        if dist.get_world_size() != w:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, environment says {w}")
+        return True
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: start the ranks with "
+                           "desco_amd.distributed.launch, main.py --gpu 0 1 .., or torch.distributed.run")
+    if backend is None:
+        cpu = device is None or device.type != "cuda"
+        backend = "gloo" if (cpu or share_gpu()) else "nccl"
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=r, world_size=w, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=r, world_size=w)
+    if dist.get_world_size() != w:      # pragma: no cover
+        raise RuntimeError("process group size mismatch")
+    return True
+
+
+def launch(argv: Sequence[str], nprocs: int, env: Optional[dict] = None,
+           devices: Optional[Sequence[int]] = None, timeout: Optional[float] = None) -> int:
+    """Start ``nprocs`` copies of ``python argv...`` with the torchrun environment (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) and wait for them -- what Lightning's "ddp"
+    strategy does for main.py:242-255.  The caller must not have touched the GPU: children are
+    fresh processes (never an exec of a process that initialised HIP).  Returns the worst exit
+    code; on a failure the remaining ranks are terminated."""
+    port = free_port()
+    procs = []
+    for r in range(nprocs):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nprocs),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                  "HSA_ENABLE_IPC_MODE_LEGACY": e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        if devices is not None:
+            e["DESCO_DEVICES"] = ",".join(str(int(d)) for d in devices)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait(timeout=timeout)
+            rc = rc or p.returncode
+            if p.returncode != 0:
+                break
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:       # pragma: no cover
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# collectives (device tensors are staged through the host under gloo)
+# ------------------------------------------------------------------------------------------------
+def _staged(t: torch.Tensor) -> bool:
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op: str = "sum", async_op: bool = False):
+    """In-place all-reduce; returns a handle with .wait() when async_op (None if already done)."""
+    import torch.distributed as dist
+    if not is_initialized() or dist.get_world_size() == 1:
+        return None
+    rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+    if _staged(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=rop)
+        t.copy_(h)
+        return None
+    if async_op:
+        return dist.all_reduce(t, op=rop, async_op=True)
+    dist.all_reduce(t, op=rop)
+    return None
+
+
+def barrier():
+    import torch.distributed as dist
+    if is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_object(obj, src: int = 0):
+    import torch.distributed as dist
+    if not is_initialized() or dist.get_world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def _row_sizes(local: torch.Tensor) -> List[int]:
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    staged = _staged(local)
+    n = torch.tensor([local.shape[0]], device="cpu" if staged else local.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    return [int(s.item()) for s in sizes]
+
+
+def allgather_rows(local: torch.Tensor) -> torch.Tensor:
+    """Concatenate per-rank row blocks (different row counts allowed) in rank order, on EVERY rank."""
+    import torch.distributed as dist
+    if not is_initialized() or dist.get_world_size() == 1:
+        return local
+    sizes = _row_sizes(local)
+    staged = _staged(local)
+    src = local.detach().cpu() if staged else local.detach()
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(src.shape[1:]), device=src.device, dtype=src.dtype)
+    pad[:src.shape[0]] = src
+    bufs = [torch.empty_like(pad) for _ in sizes]
+    dist.all_gather(bufs, pad)
+    out = torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+    return out.to(local.device) if staged else out
+
+
+def gather_rows(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
+    """Concatenate per-rank row blocks (different row counts allowed) on ``dst`` in rank order."""
+    import torch.distributed as dist
+    if not is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, r = dist.get_world_size(), dist.get_rank()
+    sizes = _row_sizes(local)
+    staged = _staged(local)
+    src = local.detach().cpu() if staged else local.detach()
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(src.shape[1:]), device=src.device, dtype=src.dtype)
+    pad[:src.shape[0]] = src
+    bufs = [torch.empty_like(pad) for _ in range(world)] if r == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if r != dst:
+        return None
+    out = torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+    return out.to(local.device) if staged else out
+
+
+# ------------------------------------------------------------------------------------------------
+# inference: graph sharding
+# ------------------------------------------------------------------------------------------------
 def graph_costs(graphs: GraphSet, num_queries: int = 29) -> np.ndarray:
     """Cheap per-graph cost proxy c(g) ~ neighborhood work + gossip work:
     sum over nodes of (1 + deg)^2 bounded, plus Q*(n + e)."""
@@ -47,40 +269,157 @@ def shard_graphs(graphs: GraphSet, rank: int, world_size: int, num_queries: int 
     return graphs.subset(lo, hi), (lo, hi)
 
 
-def gather_rows(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
-    """Concatenate per-rank row blocks (different row counts allowed) on ``dst`` in rank order."""
+# ------------------------------------------------------------------------------------------------
+# training: batch packing and gradient buckets
+# ------------------------------------------------------------------------------------------------
+def step_groups(batch_sizes: Sequence[int], world: int) -> List[List[Optional[int]]]:
+    """Pack the reference's batch stream (shuffle=False, main.py:195) into optimisation steps of
+    ``world`` consecutive batches: group k = batches [k*world, (k+1)*world), rank r takes the r-th.
+    A short last group is padded with None: that rank runs no forward but still joins the step's
+    collectives with zero gradients, so every rank executes the same number of steps (Lightning's
+    DistributedSampler pads by repeating samples instead, which double-counts them)."""
+    n = len(batch_sizes)
+    groups = []
+    for k in range(0, n, world):
+        g: List[Optional[int]] = list(range(k, min(k + world, n)))
+        g += [None] * (world - len(g))
+        groups.append(g)
+    return groups
+
+
+def mean_loss_weight(batch_sizes: Sequence[int], group: Sequence[Optional[int]], r: int) -> float:
+    """Weight of rank r's (mean) loss in a step so that the SUM all-reduce of the weighted
+    gradients is the gradient of the mean loss over the union of the group's batches:
+    B_r / sum_r' B_r' (equal batches: 1 / world, DDP's mean)."""
+    tot = sum(batch_sizes[i] for i in group if i is not None)
+    i = group[r]
+    return 0.0 if i is None or tot == 0 else batch_sizes[i] / tot
+
+
+class GradBuckets:
+    """Gradients of a model in ``num_buckets`` flat fp32 buffers; ``p.grad`` are views.
+
+    The whole neighborhood model is 5.24 MB (gossip 0.58 MB): over xGMI a ring all-reduce of that
+    size is latency-bound, so a few large buckets beat per-tensor collectives.  Buckets are filled
+    in REVERSE registration order (the order backward produces gradients: head first, layer 0
+    last); a post-accumulate hook counts a bucket's gradients and issues its asynchronous
+    all-reduce the moment it is complete -- backward of the earlier layers overlaps it.
+    ``finish()`` issues the buckets whose parameters received no gradient (the never-used
+    query-side ``anchor_mlp``, SURVEY A10: DDP's find_unused_parameters semantics, they reduce
+    zeros) and waits.  Collective order is identical on every rank because the autograd graph is.
+    """
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], num_buckets: int = 4):
+        self.params = [p for p in params if p.requires_grad]
+        rev = list(reversed(self.params))
+        total = sum(p.numel() for p in rev)
+        target = max(1, -(-total // max(1, num_buckets)))
+        self.buckets: List[torch.Tensor] = []
+        self._members: List[List[torch.nn.Parameter]] = []
+        cur: List[torch.nn.Parameter] = []
+        cur_n = 0
+        for p in rev:
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= target:
+                self._members.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self._members.append(cur)
+        self._bucket_of = {}
+        for b, members in enumerate(self._members):
+            n = sum(p.numel() for p in members)
+            # 16-byte aligned slices keep every view usable by vectorised kernels
+            offs, off = [], 0
+            for p in members:
+                offs.append(off)
+                off += (p.numel() + 3) // 4 * 4
+            flat = torch.zeros(off, device=members[0].device, dtype=members[0].dtype)
+            self.buckets.append(flat)
+            for p, o in zip(members, offs):
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                self._bucket_of[id(p)] = b
+        self._pending = [0] * len(self.buckets)
+        self._next = 0
+        self._handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.active = False
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # -- per step ---------------------------------------------------------------------------------
+    def zero(self):
+        """Replaces optimizer.zero_grad(): the views stay attached to the buckets."""
+        for flat in self.buckets:
+            flat.zero_()
+        self._pending = [len(m) for m in self._members]
+        self._next = 0                      # buckets are issued strictly in index order on every
+        self._handles = []                  # rank (collectives are matched by order)
+        self.active = True
+
+    def _issue_ready(self, force: bool = False):
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            h = all_reduce_(self.buckets[self._next], "sum", async_op=True)
+            if h is not None:
+                self._handles.append(h)
+            self._next += 1
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        self._pending[self._bucket_of[id(p)]] -= 1
+        self._issue_ready()
+
+    def finish(self, scale: Optional[float] = None):
+        """Issue what is left, wait for every bucket, optionally scale (mean = 1 / world)."""
+        self._issue_ready(force=True)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self.active = False
+        if scale is not None and scale != 1.0:
+            for flat in self.buckets:
+                flat.mul_(scale)
+
+
+def broadcast_params(module: torch.nn.Module, src: int = 0) -> None:
+    """Every rank starts from rank ``src``'s parameters and buffers (what DDP does at construction)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
-    pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+    if world_size() == 1:
+        return
+    ts = [t for t in list(module.parameters()) + list(module.buffers())]
+    if not ts:
+        return
+    flat = torch.cat([t.detach().reshape(-1).float() for t in ts])
+    if _staged(flat):
+        h = flat.cpu()
+        dist.broadcast(h, src=src)
+        flat = h.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+            off += n
 
 
 def allreduce_grads(params: Sequence[torch.nn.Parameter], mode: str = "mean") -> None:
-    """Single flat-bucket gradient all-reduce (the whole model is 5.24 MB fp32: one collective is
-    latency-optimal over xGMI).  Parameters without a gradient (the never-used query-side
-    ``anchor_mlp``) contribute zeros -- DDP's find_unused_parameters semantics.
-    mode="mean" for the neighborhood loss (a mean), "sum" for the gossip loss (a sum)."""
-    import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    """One-shot (blocking) gradient all-reduce for callers without ``GradBuckets``: a single flat
+    buffer.  mode="mean" for the neighborhood loss (a mean), "sum" for the gossip loss (a sum).
+    Parameters without a gradient contribute zeros."""
+    if world_size() == 1:
         return
     params = [p for p in params if p.requires_grad]
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                       for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    all_reduce_(flat, "sum")
     if mode == "mean":
-        flat /= dist.get_world_size()
+        flat /= world_size()
     off = 0
     for p in params:
         n = p.numel()

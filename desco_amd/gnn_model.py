@@ -476,6 +476,10 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     dev = batch.vrowptr.device
     N, S = batch.num_rows, batch.slots
     ti = batch.train_index()
+    import torch.nn.functional as F
+    # --neigh_dropout > 0 (default 0.0, config.py:251): F.dropout after every layer's relu and the
+    # nn.Dropout of post_mp.1, as the reference applies them in training mode
+    drop = gnn.training and float(core.dropout or 0.0) > 0.0
     if isinstance(batch, NeighborhoodBatch):
         Nc = batch.num_count
         groups = [("count", 0, Nc, 4), ("canonical", Nc, N, 2)]
@@ -496,7 +500,10 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
             e = pk["layers"][l][t]
             parts.append(AG.Linear.apply(agg[r0:r1, :su * H], X[-1][r0:r1], e["wt"], e["b"],
                                          ops.ACT_RELU, 0.0))
-        X.append(torch.cat(parts, 0))
+        xl = torch.cat(parts, 0)
+        if drop:                                                           # gnn_model.py:274
+            xl = F.dropout(xl, p=core.dropout, training=True)
+        X.append(xl)
     if isinstance(batch, NeighborhoodBatch):
         canon = torch.cat([xl[Nc:] for xl in X], dim=1)
         aw, ab = pk["anchor"]
@@ -508,7 +515,11 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
         pooled = torch.cat([AG.SegmentSum.apply(xl, seg_ptr, ti["seg_id"], ti["ident_ptr"], None)
                             for xl in X], dim=1)
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
-    h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_LEAKY, 0.1)
+    if drop:                                                               # post_mp.1 (gnn_model.py:46)
+        h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_NONE, 0.0)
+        h = F.leaky_relu(F.dropout(h, p=gnn.post_mp[1].p, training=True), 0.1)
+    else:
+        h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_LEAKY, 0.1)
     h = AG.Linear.apply(h, None, w3, b3, ops.ACT_RELU, 0.0)
     h = AG.Linear.apply(h, None, w5, b5, ops.ACT_RELU, 0.0)
     return AG.Linear.apply(h, None, w7, b7, ops.ACT_NONE, 0.0)

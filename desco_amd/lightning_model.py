@@ -84,6 +84,17 @@ class _LightningLike(nn.Module):
     def on_load_checkpoint(self, checkpoint):
         return None
 
+    def invalidate_caches(self):
+        """Drop every cache derived from the parameters (folded / split weights, head operands,
+        query embeddings).  They are keyed on (data_ptr, tensor._version); an update that does not
+        bump ``_version`` -- a hipGraph replay of the optimizer step (Trainer(graph_capture=True)),
+        a raw ``hipMemcpy`` into a parameter -- needs this call."""
+        for m in self.modules():
+            if isinstance(m, BaseGNN):
+                m._pack_cache = None
+        self._head_cache = None
+        self._qemb_cache = None
+
 
 class NeighborhoodCountingModel(_LightningLike):
     def __init__(self, input_dim, hidden_dim, args, **kwargs):

@@ -67,13 +67,24 @@ class _Timed:
 
 
 def _stream() -> int:
+    """The current stream of the CURRENT device.  The C ABI launches on the current HIP device, and
+    ``_dev`` only admits operands that live there, so this is the operands' own stream."""
     return torch.cuda.current_stream().cuda_stream
+
+
+_current_device = torch.cuda.current_device
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"desco_amd.ops: `{name}` must be a tensor on the MI355X (cuda) device; "
                            "there is no CPU fallback (use oracle/ for CPU checks)")
+    if t.device.index != _current_device():
+        # launching on device A's stream with device-B pointers would fault (or silently use peer
+        # access with no stream ordering); every operand of a launch has to be on the current device
+        raise RuntimeError(f"desco_amd.ops: `{name}` lives on {t.device} but the current device is "
+                           f"cuda:{_current_device()}; call torch.cuda.set_device({t.device.index}) "
+                           "(Trainer / InferencePipeline do) -- operands on mixed devices are rejected")
     if t.dtype != dtype:
         raise TypeError(f"desco_amd.ops: `{name}` must be {dtype}, got {t.dtype}")
     return t.data_ptr()

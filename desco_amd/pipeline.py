@@ -37,12 +37,36 @@ class InferencePipeline:
                  device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 6_000_000,
                  max_gossip_rows: int = 4_000_000, num_threads: int = 0,
                  partition: Optional[NeighborhoodPartition] = None,
-                 partition_backend: str = "device"):
+                 partition_backend: str = "device", rank: Optional[int] = None,
+                 world: Optional[int] = None, graph_replay_rows: int = 400_000):
+        """``rank`` / ``world`` (default: the initialised torch.distributed group): this process
+        keeps the ``rank``-th of ``world`` contiguous, cost-balanced graph ranges
+        (distributed.shard_graphs) with all their neighborhoods -- no data-path collective; the
+        results of all ranks are assembled in dataset order by ``gather()``.
+        ``graph_replay_rows``: ``step()`` replays the pass from a hipGraph when the shard has fewer
+        neighborhood rows than this (a 467-graph COX2 pass is ~70 launches of a few microseconds:
+        launch-bound when issued eagerly)."""
+        from . import distributed as D
         self.nm, self.gm = neigh_model, gossip_model
+        self.rank = D.rank() if rank is None else int(rank)
+        self.world = D.world_size() if world is None else int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"rank {self.rank} outside world of {self.world}")
+        self.num_graphs_total = graphs.num_graphs
+        self.graph_range = (0, graphs.num_graphs)
+        if self.world > 1:
+            if partition is not None:
+                raise ValueError("pass the partition of the local shard, or let the pipeline build it")
+            Q = len(getattr(neigh_model, "queries_flat", [])) or 29
+            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q)
         self.graphs = graphs
         from .batch import _norm_device
         self.device = _norm_device(device)
         device = self.device
+        if device.type == "cuda":
+            torch.cuda.set_device(device)      # the C ABI launches on the current device / stream
+        self._graph = None
+        self._graph_replay_rows = graph_replay_rows
         # canonical partition: built on the GPU (csrc/partition_dev.hip) unless the PyG quirk
         # emulation is requested or a graph exceeds the device builder's per-wave LDS workspace
         # (then the host C++ builder, same output)
@@ -108,7 +132,29 @@ class InferencePipeline:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_out = self.run(gossip)
+        self._graph_gossip = gossip
         return self
+
+    def step(self, gossip: bool = True) -> Dict[str, torch.Tensor]:
+        """One pass, launch mode chosen by shard size: small shards replay a hipGraph captured on
+        the first call (the returned tensors are then the graph's static outputs, overwritten by
+        the next ``step()``), large ones launch eagerly."""
+        if self.partition.num_rows >= self._graph_replay_rows or self.partition.num_neigh == 0:
+            return self.run(gossip)
+        if self._graph is None or self._graph_gossip != gossip:
+            self.capture(gossip)
+        return self.run_graph()
+
+    def gather(self, out: Dict[str, torch.Tensor], dst: int = 0, node_level: bool = False):
+        """The one exchange of the inference path: the per-graph counts of every rank on
+        ``dst`` in dataset order (``[G,29]``, 54 KB for COX2; with ``node_level`` also the per-node
+        and per-neighborhood predictions for the CSV dumps).  Returns None on the other ranks."""
+        from . import distributed as D
+        keys = [k for k in ("graph_neigh_count", "graph_gossip_count") if k in out]
+        if node_level:
+            keys += [k for k in ("neigh_count", "node_count", "x") if k in out]
+        res = {k: D.gather_rows(out[k], dst) for k in keys}
+        return res if self.rank == dst or self.world == 1 else None
 
     def run_graph(self) -> Dict[str, torch.Tensor]:
         """Replay the captured pass; the returned tensors are the graph's static outputs."""

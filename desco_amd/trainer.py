@@ -1,7 +1,8 @@
 """Minimal stand-in for the slice of ``pytorch_lightning.Trainer`` that main.py uses
 (main.py:205-213, 242-273, 296-301, 338-347, 370-379): fit / test / predict, ReduceLROnPlateau on
-the monitored validation loss, best/last checkpointing, optional data-parallel training
-(one process per GPU, flat-bucket gradient all-reduce over RCCL -- desco_amd.distributed)."""
+the monitored validation loss, best/last checkpointing, and data-parallel training / prediction
+with one process per GPU (``strategy="ddp"``: gradient buckets all-reduced over RCCL while backward
+is still running -- desco_amd.distributed)."""
 from __future__ import annotations
 
 import os
@@ -26,7 +27,7 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, accelerator: str = "gpu", devices=None,
                  default_root_dir: str = ".", callbacks=None, strategy: Optional[str] = None,
                  grad_reduce: str = "mean", precision: str = "fp32", graph_capture: bool = False,
-                 **unused):
+                 num_buckets: int = 4, **unused):
         # precision: "fp32" | "bf16" (Lightning's "32" / "bf16-mixed" spellings accepted): matrix
         # products of the training step in fp32 or bf16 MFMA (desco_amd.autograd.set_precision)
         self.precision = precision
@@ -39,34 +40,43 @@ class Trainer:
         self.callbacks = callbacks or []
         self.strategy = strategy
         self.grad_reduce = grad_reduce      # "mean" (neighborhood loss) or "sum" (gossip loss)
-        dev = devices[0] if isinstance(devices, (list, tuple)) and devices else 0
-        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", dev if dev != "auto" else 0)))
+        self.num_buckets = num_buckets
+        self.device = D.local_device(devices, accelerator)
+        if self.device.type == "cuda":
+            # the C ABI launches on the CURRENT device / stream: bind this process to its GPU
+            torch.cuda.set_device(self.device)
+        ndev = len(devices) if isinstance(devices, (list, tuple)) else 1
+        if strategy == "ddp" or ndev > 1:
+            _, w, _ = D.env_world()
+            if w == 1 and ndev > 1 and not D.is_initialized():
+                raise RuntimeError(
+                    f"Trainer(devices={list(devices)}): {ndev} devices need {ndev} processes (one per GPU) "
+                    "but WORLD_SIZE is 1 -- start them with `main.py --gpu 0 1 ..` (which spawns the "
+                    "ranks), desco_amd.distributed.launch, or `python -m torch.distributed.run`")
+            D.init_from_env(self.device)
         self.history: List[dict] = []
 
     # ---- helpers ----------------------------------------------------------------------------
     def _rank0(self):
-        import torch.distributed as dist
-        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        return D.rank() == 0
 
     def _shard(self, batches):
-        """Round-robin batches over ranks (what Lightning's DistributedSampler does per item)."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return batches
-        r, w = dist.get_rank(), dist.get_world_size()
-        return [b for i, b in enumerate(batches) if i % w == r]
+        """Round-robin batches over ranks (validation / test: one all-reduce of (sum, count) at the
+        end, so unequal per-rank batch counts are harmless)."""
+        r, w = D.rank(), D.world_size()
+        return batches if w == 1 else [b for i, b in enumerate(batches) if i % w == r]
 
     def _mean_loss(self, model, loader, step_name) -> float:
-        import torch.distributed as dist
         tot, cnt = 0.0, 0
         with torch.no_grad():
             for i, batch in enumerate(self._shard(list(loader))):
                 loss = getattr(model, step_name)(batch.to(self.device), i)
                 tot += float(loss) * batch.num_graphs
                 cnt += batch.num_graphs
-        if dist.is_available() and dist.is_initialized():          # sync_dist=True
-            t = torch.tensor([tot, cnt], device=self.device, dtype=torch.float64)
-            dist.all_reduce(t)
+        if D.world_size() > 1:                                       # sync_dist=True
+            t = torch.tensor([tot, cnt], dtype=torch.float64,
+                             device=self.device if self.device.type == "cuda" else "cpu")
+            D.all_reduce_(t, "sum")
             tot, cnt = float(t[0]), float(t[1])
         return tot / max(cnt, 1)
 
@@ -89,22 +99,40 @@ class Trainer:
                     graphs[i] = g
                 graphs[i].replay()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        if capture:
+            # a replay updates the parameters without bumping tensor._version, which is what the
+            # inference-side caches (folded weights, head operands, query embeddings) are keyed on
+            model.invalidate_caches()
 
     # ---- API ----------------------------------------------------------------------------------
     def fit(self, model, datamodule):
         from . import autograd as AG
         AG.set_precision(self.precision)
         model.to(self.device)
+        world, rank = D.world_size(), D.rank()
+        multi = world > 1
+        if multi:
+            D.broadcast_params(model)          # every replica starts from rank 0's weights
         cfg = model.configure_optimizers()
         opt, sched = cfg["optimizer"], cfg["lr_scheduler"]
         ckpt = next((c for c in self.callbacks if isinstance(c, ModelCheckpoint)), None)
         os.makedirs(self.root, exist_ok=True)
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        use_graphs = self.graph_capture and not multi and float(getattr(model, "dropout", 0.0) or 0.0) == 0.0
+        use_graphs = (self.graph_capture and not multi and self.device.type == "cuda"
+                      and float(getattr(model, "dropout", 0.0) or 0.0) == 0.0)
         # shuffle=False (main.py:195): the batch stream is the same every epoch, so the device-resident
-        # batches (and their backward indices) are built once
-        train_batches = [b.to(self.device) for b in self._shard(list(datamodule.train_dataloader()))]
+        # batches (and their backward indices) are built once.  Data parallel: optimisation step k
+        # consumes the `world` consecutive batches [k*world, (k+1)*world), one per rank, weighted by
+        # their neighborhood counts for the mean loss (distributed.step_groups)
+        host_batches = list(datamodule.train_dataloader())
+        sizes = [b.num_graphs for b in host_batches]
+        groups = D.step_groups(sizes, world)
+        steps = []
+        for g in groups:
+            i = g[rank]
+            w = 1.0 if self.grad_reduce == "sum" else D.mean_loss_weight(sizes, g, rank)
+            steps.append((i, None if i is None else host_batches[i].to(self.device), w))
+        del host_batches
+        buckets = D.GradBuckets(list(model.parameters()), self.num_buckets) if multi else None
         graphs = {}
         # capture happens on a side stream, and autograd's AccumulateGrad nodes must have been created
         # on that same stream: with graph_capture the whole training loop runs on it
@@ -116,13 +144,20 @@ class Trainer:
         for epoch in range(self.max_epochs):
             model.train()
             if use_graphs:
-                self._graph_epoch(model, opt, train_batches, graphs, side, capture=epoch >= 1)
+                self._graph_epoch(model, opt, [b for _, b, _ in steps], graphs, side, capture=epoch >= 1)
+            elif multi:
+                for i, batch, w in steps:
+                    buckets.zero()
+                    if batch is not None:
+                        loss = model.training_step(batch, i)
+                        (loss if w == 1.0 else loss * w).backward()   # bucket all-reduces start here
+                    buckets.finish()
+                    opt.step()
             else:
-                for i, batch in enumerate(train_batches):
+                for i, batch, _ in steps:
                     opt.zero_grad(set_to_none=True)
                     loss = model.training_step(batch, i)
                     loss.backward()
-                    D.allreduce_grads(list(model.parameters()), mode=self.grad_reduce)
                     opt.step()
             model.eval()
             val = self._mean_loss(model, datamodule.val_dataloader(), "validation_step")
@@ -137,13 +172,23 @@ class Trainer:
             else:
                 sched.step(val)
             self.history.append({"epoch": epoch, cfg["monitor"]: val, "lr": float(opt.param_groups[0]["lr"])})
-            if ckpt is not None and self._rank0():
-                if ckpt.save_last:
-                    model.save_checkpoint(os.path.join(self.root, "last.ckpt"))
-                if ckpt.best_score is None or val < ckpt.best_score:
-                    ckpt.best_score = val
-                    ckpt.best_model_path = os.path.join(self.root, f"epoch={epoch}-best.ckpt")
-                    model.save_checkpoint(ckpt.best_model_path)
+            if ckpt is not None:
+                if self._rank0():
+                    if ckpt.save_last:
+                        model.save_checkpoint(os.path.join(self.root, "last.ckpt"))
+                    if ckpt.best_score is None or val < ckpt.best_score:
+                        ckpt.best_score = val
+                        ckpt.best_model_path = os.path.join(self.root, f"epoch={epoch}-best.ckpt")
+                        model.save_checkpoint(ckpt.best_model_path)
+                if multi:     # every rank reloads the best checkpoint afterwards (main.py:262-264)
+                    ckpt.best_score, ckpt.best_model_path = D.broadcast_object(
+                        (ckpt.best_score, ckpt.best_model_path))
+        if buckets is not None:
+            buckets.close()
+            for p in model.parameters():      # detach the views from the (now unused) buckets
+                p.grad = None
+        if multi:
+            D.barrier()                        # the checkpoint files are complete on every rank
         return self
 
     def test(self, model, datamodule):
@@ -152,6 +197,24 @@ class Trainer:
         return [{"test_loss": loss}]
 
     def predict(self, model, dataloader) -> List[torch.Tensor]:
+        """Per-batch predictions.  Data parallel: every rank predicts a contiguous range of the
+        batches and the row blocks are all-gathered in order, so each rank returns the full result
+        (as ONE tensor in the list; the caller concatenates, main.py:279-301)."""
         model.to(self.device).eval()
+        world, rank = D.world_size(), D.rank()
         with torch.no_grad():
-            return [model.predict_step(b.to(self.device), i) for i, b in enumerate(dataloader)]
+            if world == 1:
+                return [model.predict_step(b.to(self.device), i) for i, b in enumerate(dataloader)]
+            batches = list(dataloader)
+            n = len(batches)
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            outs = [model.predict_step(batches[i].to(self.device), i) for i in range(lo, hi)]
+            local = torch.cat(outs) if outs else None
+            # fewer batches than ranks: a rank without a batch contributes an empty block of the
+            # common width, which it learns from the others
+            width = torch.tensor([local.shape[1] if local is not None else 0], dtype=torch.int64)
+            width = width.to(self.device) if self.device.type == "cuda" else width
+            D.all_reduce_(width, "max")
+            if local is None:
+                local = torch.zeros((0, int(width.item())), device=self.device)
+            return [D.allgather_rows(local)]

@@ -44,8 +44,13 @@ class NeighborhoodDataset:
         pdir = os.path.join(root, "processed") if root else None
         names = self.processed_file_names
         paths = [os.path.join(pdir, n) for n in names] if pdir else None
+        cached = None
         if paths and all(os.path.exists(p) for p in paths):
-            z = np.load(paths[0])
+            cached = np.load(paths[0])
+            if int(cached["quirk_batch"]) != int(quirk_batch):
+                cached = None          # a cache built for another PyG-quirk emulation setting: rebuild
+        if cached is not None:
+            z = cached
             self.partition = NeighborhoodPartition(
                 np.load(paths[1]), np.load(paths[2]), z["count_ptr"], z["count_orig"],
                 z["vrowptr"], z["vcol"], depth_neigh, int(z["quirk_batch"]))

@@ -51,13 +51,35 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
     assert args_neighborhood.use_hetero if args_neighborhood.use_tconv else True
     depth, ncpu = args_neighborhood.depth, args_opt.num_cpu
 
-    train_w = valid_w = None
-    if train_neighborhood or train_gossip:
-        train_w = build_workload(args_opt.train_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
-        valid_w = build_workload(args_opt.valid_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
-    test_w = build_workload(args_opt.test_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
-
     devices = args_opt.gpu if isinstance(args_opt.gpu, list) else [args_opt.gpu]
+    # len(devices) > 1: one process per GPU (started by __main__ below or by torch.distributed.run);
+    # every rank runs this function, training and prediction are data parallel over RCCL
+    # (Trainer(strategy="ddp")), and rank 0 alone writes the output files.  The reference
+    # parallelises only neighborhood training (main.py:242-255) and refuses it for the gossip model
+    # (main.py:353-356); both stages and both predict passes are sharded here.
+    from desco_amd import distributed as D
+    _, env_world, _ = D.env_world()
+    if len(devices) > 1 and env_world != len(devices):
+        raise RuntimeError(f"--gpu {devices}: {len(devices)} ranks expected, WORLD_SIZE={env_world}; run "
+                           "main.py directly (it starts the ranks) or under torch.distributed.run")
+    strategy = "ddp" if len(devices) > 1 else None
+    if strategy:
+        D.init_from_env(D.local_device(devices))
+
+    def build_all():
+        tw = vw = None
+        if train_neighborhood or train_gossip:
+            tw = build_workload(args_opt.train_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
+            vw = build_workload(args_opt.valid_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
+        return tw, vw, build_workload(args_opt.test_dataset, query_ids, nx_queries, depth, transform, ncpu,
+                                      data_root)
+
+    # rank 0 computes the ground truth / partitions and writes the on-disk caches; the others read them
+    if D.rank() == 0:
+        train_w, valid_w, test_w = build_all()
+    D.barrier()
+    if D.rank() != 0:
+        train_w, valid_w, test_w = build_all()
 
     # ---------------- neighborhood counting ----------------
     neigh_loader = LightningDataLoader(
@@ -69,7 +91,7 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
                                  save_last=True)
     neigh_trainer = Trainer(max_epochs=args_neighborhood.epoch_num, accelerator="gpu", devices=devices,
                             default_root_dir=args_neighborhood.model_path, callbacks=[neigh_ckpt],
-                            strategy="ddp" if len(devices) > 1 else None, grad_reduce="mean",
+                            strategy=strategy, grad_reduce="mean",
                             precision=getattr(args_opt, "precision", "fp32"),
                             graph_capture=getattr(args_opt, "graph_capture", False))
     if train_neighborhood and neighborhood_checkpoint is None:
@@ -119,9 +141,11 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
             gossip_model = GossipCountingModel.load_from_checkpoint(gossip_checkpoint)
         gossip_ckpt = ModelCheckpoint(monitor="gossip_counting_val_loss", mode="min", save_top_k=1,
                                       save_last=True)
-        gossip_trainer = Trainer(max_epochs=args_gossip.epoch_num, accelerator="gpu", devices=devices[:1],
+        # the gossip loss is a SUM over nodes and queries (lightning_model.py:607): sum-reduce
+        gossip_trainer = Trainer(max_epochs=args_gossip.epoch_num, accelerator="gpu", devices=devices,
                                  default_root_dir=args_gossip.model_path, callbacks=[gossip_ckpt],
-                                 grad_reduce="sum", precision=getattr(args_opt, "precision", "fp32"))
+                                 strategy=strategy, grad_reduce="sum",
+                                 precision=getattr(args_opt, "precision", "fp32"))
         gossip_model.to(gossip_trainer.device)
         gossip_model.set_query_emb(neigh_model.get_query_emb())
         if train_gossip:
@@ -134,6 +158,12 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
             print("gossip test:", gossip_trainer.test(gossip_model, datamodule=gossip_loader))
 
     # ---------------- outputs (main.py:381-515) ----------------
+    gossip_count_test = None
+    if not skip_gossip:
+        gossip_count_test = torch.cat(gossip_trainer.predict(gossip_model, gossip_loader.test_dataloader()), dim=0)
+    if D.rank() != 0:          # every rank holds the full predictions; rank 0 writes the files
+        D.barrier()
+        return None
     os.makedirs(output_dir, exist_ok=True)
     ds = args_opt.test_dataset
     with open(os.path.join(output_dir, f"config_{ds}.txt"), "w") as f:
@@ -142,9 +172,8 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
     graphlet_neigh = test_w.neighborhood_dataset.aggregate_neighborhood_count(neighborhood_count_test)
     pd.DataFrame(torch.round(F.relu(graphlet_neigh)).cpu().numpy()).to_csv(
         os.path.join(output_dir, f"neighborhood_graphlet_{ds}.csv"))
-    graphlet_gossip = gossip_count_test = None
+    graphlet_gossip = None
     if not skip_gossip:
-        gossip_count_test = torch.cat(gossip_trainer.predict(gossip_model, gossip_loader.test_dataloader()), dim=0)
         graphlet_gossip = test_w.gossip_dataset.aggregate_neighborhood_count(gossip_count_test)
         pd.DataFrame(torch.round(F.relu(graphlet_gossip)).cpu().numpy()).to_csv(
             os.path.join(output_dir, f"gossip_graphlet_{ds}.csv"))
@@ -177,6 +206,7 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
             print(f"{k}: {v}")
             f.write(f"{k}: {v}\n")
     print("done")
+    D.barrier()
     return report
 
 
@@ -191,6 +221,13 @@ if __name__ == "__main__":
     parser.add_argument("--graph_capture", action="store_true",
                         help="replay each neighborhood training batch's step from a hipGraph after epoch 0")
     args = parser.parse_args()
+    gpus = args.gpu if isinstance(args.gpu, list) else [args.gpu]
+    if len(gpus) > 1 and "WORLD_SIZE" not in os.environ:
+        # --gpu 0 1 ..: start one process per GPU (what Lightning's "ddp" strategy does for
+        # main.py:242-255), before this process touches the GPU; LOCAL_RANK r uses gpus[r]
+        import sys
+        from desco_amd import distributed as D
+        sys.exit(D.launch([os.path.abspath(__file__)] + sys.argv[1:], len(gpus), devices=gpus))
     print(args)
     args_neighborhood, args_gossip, args_opt = split_namespaces(args)
     args_opt.precision = args.precision          # this build's flags (not in the reference's groups)

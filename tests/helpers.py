@@ -23,8 +23,10 @@ def gossip_args(**over):
     return argparse.Namespace(**a)
 
 
-def make_models(seed=0, scale_bias=True):
-    """Seeded NeighborhoodCountingModel + GossipCountingModel (reference key names)."""
+def make_models(seed=0, scale_bias=True, gains=(1.3, 1.4)):
+    """Seeded NeighborhoodCountingModel + GossipCountingModel (reference key names).
+    ``gains``: widening of the (neighborhood, gossip) weight matrices (dense Syn-shaped batches sum
+    over many more neighbours per row and want a smaller one to stay O(1))."""
     from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
     torch.manual_seed(seed)
     nm = NeighborhoodCountingModel(1, 64, neigh_args()).to_hetero_old(True, True)
@@ -34,7 +36,7 @@ def make_models(seed=0, scale_bias=True):
         # weights so that parity tests see structure-dependent, O(1) values
         g = torch.Generator().manual_seed(seed + 1)
         with torch.no_grad():
-            for m, gain in ((nm, 1.3), (gm, 1.4)):
+            for m, gain in ((nm, gains[0]), (gm, gains[1])):
                 for name, p in m.named_parameters():
                     if p.dim() == 2:
                         p.mul_(gain)

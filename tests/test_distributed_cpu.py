@@ -1,6 +1,10 @@
-"""World-size-2 gloo tests of the N>1 path: graph sharding + ordered gather reproduce the
-single-process result; flat-bucket gradient all-reduce averages like DDP."""
+"""World-size-2 gloo tests of the N>1 path (CPU): graph sharding + ordered gather reproduce the
+single-process result; the gradient buckets (async all-reduce issued from autograd hooks) and the
+count-weighted step packing give the single-process gradient of the union batch; ``Trainer.fit`` /
+``Trainer.predict`` in "ddp" mode with an ODD number of batches end in the same state as the
+equivalent single-process run."""
 import os
+import queue as _queue
 import socket
 
 import numpy as np
@@ -30,41 +34,164 @@ def _fake_stage(gs: GraphSet) -> torch.Tensor:
     return torch.tensor(out).reshape(-1, 3)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+# ---- a tiny Lightning-shaped model + datamodule on CPU tensors ------------------------------------
+class _Batch:
+    def __init__(self, x, y):
+        self.x, self.y, self.num_graphs = x, y, x.shape[0]
+
+    def to(self, device):
+        return self
+
+
+class _Loader:
+    def __init__(self, batches):
+        self.b = batches
+
+    def __iter__(self):
+        return iter(self.b)
+
+    def __len__(self):
+        return len(self.b)
+
+
+class _Data:
+    def __init__(self, sizes, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.batches = [_Batch(torch.randn(n, 4, generator=g), torch.randn(n, 3, generator=g)) for n in sizes]
+
+    def train_dataloader(self):
+        return _Loader(self.batches)
+
+    val_dataloader = test_dataloader = train_dataloader
+
+
+class _Model(torch.nn.Module):
+    """mean loss (like the neighborhood model) or sum loss (like the gossip model)."""
+
+    def __init__(self, reduce="mean"):
+        super().__init__()
+        torch.manual_seed(1)
+        self.net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+        self.unused = torch.nn.Linear(2, 2)      # never reached by backward (query-side anchor_mlp)
+        self.reduce = reduce
+        self.saved = []
+
+    def _loss(self, b):
+        d = (self.net(b.x) - b.y) ** 2
+        return d.mean() if self.reduce == "mean" else d.sum()
+
+    def training_step(self, b, i):
+        return self._loss(b)
+
+    def validation_step(self, b, i):
+        return self._loss(b)
+
+    test_step = validation_step
+
+    def predict_step(self, b, i):
+        return self.net(b.x)
+
+    def configure_optimizers(self):
+        opt = torch.optim.SGD(self.parameters(), lr=0.05)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=20)
+        return {"optimizer": opt, "lr_scheduler": sched, "monitor": "val"}
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+
+SIZES = [6, 6, 3]        # odd number of batches, ragged last one
+
+
+def _single_process_reference(reduce, epochs):
+    """What the 2-rank run must equal: one process stepping on the UNION of each group of 2 batches
+    (mean loss over the union / sum loss over the union)."""
+    m = _Model(reduce)
+    data = _Data(SIZES)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    for _ in range(epochs):
+        for k in range(0, len(SIZES), 2):
+            bs = data.batches[k:k + 2]
+            u = _Batch(torch.cat([b.x for b in bs]), torch.cat([b.y for b in bs]))
+            opt.zero_grad()
+            m._loss(u).backward()
+            opt.step()
+    return m
+
+
+def _worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from desco_amd.trainer import ModelCheckpoint, Trainer
+    D.init_from_env(torch.device("cpu"))
     try:
+        res = {}
         gs = GraphSet.from_edge_lists(golden_graphs())
         shard, (lo, hi) = D.shard_graphs(gs, rank, world)
-        full = D.gather_rows(_fake_stage(shard), dst=0)
-        # gradient all-reduce
+        res["full"] = D.gather_rows(_fake_stage(shard), dst=0)
+        res["full_all"] = D.allgather_rows(_fake_stage(shard))
+        res["range"] = (lo, hi)
+        # one-shot gradient all-reduce
         torch.manual_seed(0)
         lin = torch.nn.Linear(4, 3)
         unused = torch.nn.Linear(2, 2)
         x = torch.full((5, 4), float(rank + 1))
         lin(x).sum().backward()
         D.allreduce_grads(list(lin.parameters()) + list(unused.parameters()), mode="mean")
-        if rank == 0:
-            q.put((full, lin.weight.grad.clone(), unused.weight.grad.clone(), (lo, hi)))
+        res["wgrad"], res["ugrad"] = lin.weight.grad.clone(), unused.weight.grad.clone()
+        # bucketed, hook-driven all-reduce: one weighted step on batches (0, 1) and one on (2, None)
+        m = _Model("mean")
+        data = _Data(SIZES)
+        bk = D.GradBuckets(list(m.parameters()), num_buckets=3)
+        grads = []
+        for group in D.step_groups(SIZES, world):
+            bk.zero()
+            i = group[rank]
+            if i is not None:
+                (m._loss(data.batches[i]) * D.mean_loss_weight(SIZES, group, rank)).backward()
+            bk.finish()
+            grads.append([p.grad.clone() for p in m.parameters()])
+        bk.close()
+        res["bucket_grads"] = grads
+        # Trainer.fit / predict in ddp mode
+        for reduce in ("mean", "sum"):
+            m = _Model(reduce)
+            if rank == 1:       # replicas must be re-synchronised from rank 0
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.add_(1.0)
+            ck = ModelCheckpoint(monitor="val")
+            tr = Trainer(max_epochs=2, accelerator="cpu", devices=[0, 1], strategy="ddp",
+                         default_root_dir=os.path.join(tmp, reduce), callbacks=[ck], grad_reduce=reduce)
+            tr.fit(m, _Data(SIZES))
+            res[f"fit_{reduce}"] = [p.detach().clone() for p in m.parameters()]
+            res[f"ckpt_{reduce}"] = (ck.best_model_path, os.path.exists(ck.best_model_path))
+            res[f"hist_{reduce}"] = tr.history
+            res[f"pred_{reduce}"] = torch.cat(tr.predict(m, _Data(SIZES).train_dataloader()))
+            res[f"test_{reduce}"] = tr.test(m, _Data(SIZES))[0]["test_loss"]
+        torch.save(res, os.path.join(tmp, f"res_{rank}.pt"))     # (tensors through a queue need the
+        q.put(rank)                                               #  sender alive while they are read)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _run_world(world):
+def _run_world(world, tmp):
     """Spawn the ranks; a lost rendezvous (the probed port taken in between, a slow spawn) is retried
     on a fresh port -- the assertions on the results are made once, by the caller."""
-    import queue as _queue
     last = None
     for _attempt in range(3):
         port = _free_port()
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, tmp)) for r in range(world)]
         for p in procs:
             p.start()
+        res = {}
         try:
-            res = q.get(timeout=180)
+            for _ in range(world):
+                r = q.get(timeout=240)
+                res[r] = torch.load(os.path.join(tmp, f"res_{r}.pt"), weights_only=False)
         except _queue.Empty:
             res = None
         for p in procs:
@@ -78,14 +205,80 @@ def _run_world(world):
     raise AssertionError(f"gloo world of {world} did not complete (exit codes {last})")
 
 
-def test_sharded_inference_gather_and_grad_allreduce():
-    full, wgrad, ugrad, (lo, hi) = _run_world(2)
+@pytest.fixture(scope="module")
+def world2(tmp_path_factory):
+    return _run_world(2, str(tmp_path_factory.mktemp("ddp")))
+
+
+def test_sharded_inference_gather_and_grad_allreduce(world2):
+    r0 = world2[0]
     gs = GraphSet.from_edge_lists(golden_graphs())
-    assert torch.equal(full, _fake_stage(gs))                      # 1-vs-N rank equality
+    assert torch.equal(r0["full"], _fake_stage(gs))                      # 1-vs-N rank equality
+    assert world2[1]["full"] is None
+    assert torch.equal(world2[1]["full_all"], _fake_stage(gs))           # all-gather: on every rank
+    lo, hi = r0["range"]
     assert lo == 0 and 0 < hi < gs.num_graphs
     # mean of per-rank grads: rank r contributes 5*(r+1) per weight entry
-    assert torch.allclose(wgrad, torch.full((3, 4), 5 * (1 + 2) / 2))
-    assert torch.equal(ugrad, torch.zeros(2, 2))                   # unused params -> zeros
+    assert torch.allclose(r0["wgrad"], torch.full((3, 4), 5 * (1 + 2) / 2))
+    assert torch.equal(r0["ugrad"], torch.zeros(2, 2))                   # unused params -> zeros
+
+
+def test_bucketed_weighted_gradients_equal_union_batch_gradient(world2):
+    """sum-all-reduce of count-weighted per-rank mean-loss gradients == gradient of the mean loss over
+    the union of the group's batches, incl. the short last group (rank 1 has no batch there) and a
+    parameter that never receives a gradient."""
+    data = _Data(SIZES)
+    for step, k in enumerate(range(0, len(SIZES), 2)):
+        m = _Model("mean")
+        bs = data.batches[k:k + 2]
+        u = _Batch(torch.cat([b.x for b in bs]), torch.cat([b.y for b in bs]))
+        m._loss(u).backward()
+        want = [p.grad if p.grad is not None else torch.zeros_like(p) for p in m.parameters()]
+        for r in (0, 1):
+            got = world2[r]["bucket_grads"][step]
+            for g, w in zip(got, want):
+                torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_trainer_ddp_fit_matches_single_process_union_steps(world2, reduce):
+    ref = _single_process_reference(reduce, epochs=2)
+    for r in (0, 1):
+        for g, w in zip(world2[r][f"fit_{reduce}"], ref.parameters()):
+            torch.testing.assert_close(g, w.detach(), rtol=1e-5, atol=1e-6)
+    # the best checkpoint path is known on every rank and the file exists (rank 0 wrote it)
+    p0, ok0 = world2[0][f"ckpt_{reduce}"]
+    p1, ok1 = world2[1][f"ckpt_{reduce}"]
+    assert p0 == p1 and p0 and ok0 and ok1
+    assert world2[0][f"hist_{reduce}"] == world2[1][f"hist_{reduce}"]     # synchronised val loss
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_trainer_ddp_predict_and_test_are_sharded_and_complete(world2, reduce):
+    ref = _single_process_reference(reduce, epochs=2)
+    data = _Data(SIZES)
+    want = torch.cat([ref.predict_step(b, 0) for b in data.batches]).detach()
+    for r in (0, 1):
+        torch.testing.assert_close(world2[r][f"pred_{reduce}"], want, rtol=1e-5, atol=1e-6)
+    tot = sum(float(ref._loss(b)) * b.num_graphs for b in data.batches) / sum(SIZES)
+    assert abs(world2[0][f"test_{reduce}"] - tot) < 1e-4 * max(1.0, abs(tot))
+    assert world2[0][f"test_{reduce}"] == world2[1][f"test_{reduce}"]
+
+
+def test_trainer_refuses_many_devices_without_ranks():
+    from desco_amd.trainer import Trainer
+    with pytest.raises(RuntimeError, match="processes"):
+        Trainer(accelerator="cpu", devices=[0, 1], strategy="ddp")
+
+
+def test_step_groups_and_weights():
+    g = D.step_groups([512, 512, 512, 100, 7], 2)
+    assert g == [[0, 1], [2, 3], [4, None]]
+    assert D.mean_loss_weight([512, 512, 512, 100, 7], g[0], 0) == 0.5
+    assert abs(D.mean_loss_weight([512, 512, 512, 100, 7], g[1], 1) - 100 / 612) < 1e-12
+    assert D.mean_loss_weight([512, 512, 512, 100, 7], g[2], 0) == 1.0
+    assert D.mean_loss_weight([512, 512, 512, 100, 7], g[2], 1) == 0.0
+    assert D.step_groups([5, 5], 1) == [[0], [1]]
 
 
 def test_contiguous_shards_balance_and_cover():

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json.
 
-usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>"
+usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>" [<workload key, e.g. cox2_x64>] [<round tag>]
+The output file holds one entry per workload key ("<workload>_x<replicas>", what bench.py looks up);
+an existing file is updated in place.
 Per kernel and launch: raw counters (KB) and HBM bytes corrected as MI355X_MICROARCH.md (HBM
 section) prescribes for gfx950: FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced
 reads -> x2; WRITE_SIZE is exact for 16-B-per-lane stores.  Other access widths are uncalibrated,
@@ -31,19 +33,26 @@ def load(path, cname):
 
 def main():
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    out = {"command": sys.argv[4] if len(sys.argv) > 4 else "", "unit_note": "FETCH_SIZE/WRITE_SIZE in KB per launch; "
-           "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction for 16 B/lane reads)",
-           "kernels": {}}
+    key = sys.argv[5] if len(sys.argv) > 5 else "cox2_x64"
+    entry = {"command": sys.argv[4] if len(sys.argv) > 4 else "", "round": sys.argv[6] if len(sys.argv) > 6 else "",
+             "kernels": {}}
     for k in sorted(f, key=lambda k: -f[k][1]):
         if "_kernel" not in k:
             continue
         fk = f[k][1] / f[k][0]
         wk = w[k][1] / w[k][0] if k in w and w[k][0] else 0.0
-        out["kernels"][k] = {"launches": f[k][0], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-                             "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
-                             "hbm_bytes_per_launch_uncorrected": (fk + wk) * 1024}
+        entry["kernels"][k] = {"launches": f[k][0], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+                               "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+                               "hbm_bytes_per_launch_uncorrected": (fk + wk) * 1024}
+    try:
+        out = json.load(open(sys.argv[3]))
+    except (OSError, ValueError):
+        out = {}
+    out.setdefault("unit_note", "FETCH_SIZE/WRITE_SIZE in KB per launch; hbm_bytes = (2*FETCH_SIZE + "
+                   "WRITE_SIZE)*1024 (gfx950 correction for 16 B/lane reads)")
+    out.setdefault("workloads", {})[key] = entry
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    print(json.dumps(out["kernels"], indent=1)[:1500])
+    print(json.dumps(entry["kernels"], indent=1)[:1500])
 
 
 if __name__ == "__main__":
