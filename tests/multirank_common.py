@@ -15,7 +15,9 @@ def mixed_graphs():
     return g + m + [s[i] for i in (20, 30, 40, 44, 48)]
 
 
-def models(device, gains=(1.0, 1.4), seed=0):
+def models(device, gains=(0.8, 1.2), seed=0):
+    # (narrower weights than the molecule-sized tests: the dense graphs sum over more neighbours per
+    #  row, and 2**logit must stay finite for the count comparison)
     nm, gm = make_models(seed=seed, gains=gains)
     qids, queries = standard_queries()
     nm, gm = nm.to(device), gm.to(device)

@@ -54,6 +54,7 @@ def test_two_rank_pipeline_equals_one_rank(tmp_path):
     for k in ("graph_neigh_count", "graph_gossip_count", "neigh_count", "node_count", "x"):
         got, ref = r0[k], one[k].cpu()
         assert got.shape == ref.shape, k
+        assert torch.isfinite(ref).all() and torch.isfinite(got).all(), k
         exact = torch.equal(got, ref)
         # a row's in-tile summation order depends on where its tile falls in the launch, so shards
         # agree to fp32 rounding (amplified by 2**logit), as slices of one launch do
