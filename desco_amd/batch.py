@@ -135,7 +135,9 @@ class QueryBatch(_TrainIndexMixin):
     slots = 2
 
     def __init__(self, queries: Sequence[Tuple[int, Sequence[Tuple[int, int]]]], device,
-                 input_dim: int = 1):
+                 input_dim: int = 1, node_feature: Optional[torch.Tensor] = None):
+        """``node_feature`` [sum of query sizes, input_dim]: the labelled queries of --use_node_feature
+        (one-hot rows, main.py:51-62); None = zeros (the unlabelled standard queries)."""
         self.queries = [(int(n), [tuple(e) for e in es]) for n, es in queries]
         self.device = _norm_device(device)
         device = self.device
@@ -159,6 +161,11 @@ class QueryBatch(_TrainIndexMixin):
         self.vcol = _i32(np.array([c for _, c in ents], dtype=np.int64), device)
         self.graph_ptr = _i32(gp, device)
         self.node_feature = None
+        if node_feature is not None:
+            nf = torch.as_tensor(node_feature, dtype=torch.float32)
+            if nf.shape != (N, input_dim):
+                raise ValueError(f"query node_feature must be [{N}, {input_dim}], got {tuple(nf.shape)}")
+            self.node_feature = nf.to(device).contiguous()
 
     def _seg_ptr_host(self):
         return self.graph_ptr_host

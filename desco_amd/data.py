@@ -43,6 +43,20 @@ def graph_atlas_plus(atlas_id: int) -> nx.Graph:
         "pass them via queries=[...]")
 
 
+def add_node_feat_to_networkx(graph: nx.Graph, node_feats, node_feat_key: str = "feat"):
+    """All ``len(node_feats) ** n`` labelled copies of ``graph`` (utils.py:258-272): copy i carries
+    the i-th element of ``itertools.product(node_feats, repeat=n)``, node k gets its k-th entry."""
+    import itertools
+    n = len(graph.nodes)
+    out = []
+    for feats in itertools.product(node_feats, repeat=n):
+        g = graph.copy()
+        for k, f in enumerate(feats):
+            g.nodes[k][node_feat_key] = f
+        out.append(g)
+    return out
+
+
 def k_neigh(G: nx.Graph, start_node, k):
     """BFS ball of radius k (data.py:329-338)."""
     neighs, fronts = {start_node}, {start_node}
@@ -95,15 +109,21 @@ def _read_tu_raw(raw_dir: str, name: str) -> GraphSet:
     if not (np.diff(gi) >= 0).all():
         raise ValueError("graph_indicator must be sorted")
     graph_ptr = np.concatenate([[0], np.cumsum(np.bincount(gi))])
-    return GraphSet._from_global_pairs(graph_ptr, a[:, 0], a[:, 1])
+    gs = GraphSet._from_global_pairs(graph_ptr, a[:, 0], a[:, 1])
+    lab = os.path.join(raw_dir, name + "_node_labels.txt")
+    if os.path.exists(lab):      # PyG's TUDataset: x = one-hot node labels
+        l = np.loadtxt(lab, dtype=np.int64).reshape(-1)
+        l = l - l.min()
+        gs = GraphSet(gs.graph_ptr, gs.rowptr, gs.col, np.eye(int(l.max()) + 1, dtype=np.float32)[l])
+    return gs
 
 
 def relabel(graphs: GraphSet, mode: str) -> GraphSet:
     """Per-graph node re-indexing (transforms.py:415-442 Relabel): "decreasing_degree",
     "increasing_degree" (stable w.r.t. the original order) or "random" (seed 0)."""
     rng = np.random.default_rng(0)
-    out = []
-    for (n, edges) in graphs.edge_lists():
+    out, feats = [], []
+    for gi, (n, edges) in enumerate(graphs.edge_lists()):
         deg = np.zeros(n, dtype=np.int64)
         for a, b in edges:
             deg[a] += 1
@@ -115,7 +135,10 @@ def relabel(graphs: GraphSet, mode: str) -> GraphSet:
         new = np.empty(n, dtype=np.int64)
         new[order] = np.arange(n)
         out.append((n, [(int(new[a]), int(new[b])) for a, b in edges]))
-    return GraphSet.from_edge_lists(out)
+        if graphs.node_feat is not None:
+            f = graphs.node_feat[graphs.graph_ptr[gi]:graphs.graph_ptr[gi + 1]]
+            feats.append(f[order])                       # new id k holds old node order[k]
+    return GraphSet.from_edge_lists(out, node_feat=feats if graphs.node_feat is not None else None)
 
 
 def read_syn_edgelist(edgelist_path: str, indicator_path: str) -> GraphSet:
@@ -214,4 +237,7 @@ def load_data(dataset_name: str, root_folder="data", n_neighborhoods=-1, transfo
     sel = {"train": idx[:train_len], "val": idx[train_len:train_len + val_len],
            "test": idx[train_len + val_len:]}[split]
     lists = graphs.edge_lists()
-    return GraphSet.from_edge_lists([lists[i] for i in sel])
+    feats = None
+    if graphs.node_feat is not None:
+        feats = [graphs.node_feat[graphs.graph_ptr[i]:graphs.graph_ptr[i + 1]] for i in sel]
+    return GraphSet.from_edge_lists([lists[i] for i in sel], node_feat=feats)

@@ -599,14 +599,22 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
     if Q != query_emb.shape[0]:
         raise ValueError("batch.x has a different number of query columns than query_emb rows")
     if FUSED_GOSSIP:
-        scal4 = ops.gossip_scalars(x, batch.rowptr, batch.col, q["g0"], q["g1"])
         (w3, b3), (w5, b5) = pk["post"]
-        v = {"g1": q["g1"], "p": q["p"], "z": q["z"], "zp": q["zp"], "r": q["r"], "t": q["t"],
-             "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"],
-             # the fused kernel takes n-major ([out, in]) weight blocks
-             "w1s": pk["fused_w1s"], "wps": pk["fused_wps"], "w3s": pk["fused_w3s"], "b3": b3,
-             "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
-        return ops.gossip_fused(scal4, batch.rowptr, batch.col, N, Q, v)
+        outs = []
+        # the scalars pre-pass maps one lane to one query: more than 64 queries (the labelled queries
+        # of --use_node_feature) go in column groups
+        for q0 in range(0, Q, 64):
+            q1 = min(q0 + 64, Q)
+            sl = (lambda t: t) if (q0 == 0 and q1 == Q) else (lambda t: t[q0:q1].contiguous())
+            xs = x if (q0 == 0 and q1 == Q) else x[:, q0:q1].contiguous()
+            scal4 = ops.gossip_scalars(xs, batch.rowptr, batch.col, sl(q["g0"]), sl(q["g1"]))
+            v = {"g1": sl(q["g1"]), "p": sl(q["p"]), "z": sl(q["z"]), "zp": sl(q["zp"]), "r": q["r"],
+                 "t": q["t"], "u": pk["ws1"][0], "tp": pk["wsp"][1], "d1": pk["d1"],
+                 # the fused kernel takes n-major ([out, in]) weight blocks
+                 "w1s": pk["fused_w1s"], "wps": pk["fused_wps"], "w3s": pk["fused_w3s"], "b3": b3,
+                 "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
+            outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0
     hh = ops.gossip_gather(h1, batch.rowptr, batch.col, N, Q, q["g1"])           # layer 1 aggregate

@@ -96,3 +96,37 @@ def canonical_counts(graphs: GraphSet, queries: Sequence, num_threads: int = 0,
                                         q_edges.ctypes.data if len(q_edges) else None, len(flat),
                                         num_threads, out.ctypes.data), "desco_canonical_counts")
     return torch.from_numpy(out).double()
+
+
+def canonical_counts_labelled(graphs: GraphSet, queries: Sequence, node_feat_key: str = "feat") -> torch.Tensor:
+    """Canonical counts of LABELLED queries (--use_node_feature): the reference's own procedure,
+    networkx VF2 with ``node_match`` on the feature (workload.py:327-348) divided by the labelled
+    symmetry factor (data.py:61-68).  The native enumerators count unlabelled patterns; labelled
+    ground truth is an offline, one-time step and stays on the host like the reference's."""
+    import networkx as nx
+    if graphs.node_feat is None:
+        raise ValueError("labelled ground truth needs GraphSet.node_feat")
+    match = lambda a, b: a[node_feat_key] == b[node_feat_key]     # noqa: E731
+    targets = []
+    for g, (n, edges) in enumerate(graphs.edge_lists()):
+        t = nx.Graph()
+        base = int(graphs.graph_ptr[g])
+        for v in range(n):
+            t.add_node(v, **{node_feat_key: [float(x) for x in graphs.node_feat[base + v]]})
+        t.add_edges_from(edges)
+        targets.append(t)
+    out = torch.zeros((graphs.num_nodes, len(queries)), dtype=torch.double)
+    for qi, q in enumerate(queries):
+        qq = nx.Graph()
+        for v in q.nodes:
+            qq.add_node(v, **{node_feat_key: [float(x) for x in np.asarray(q.nodes[v][node_feat_key]).reshape(-1)]})
+        qq.add_edges_from(q.edges())
+        sym = sum(1 for _ in nx.algorithms.isomorphism.GraphMatcher(qq, qq, node_match=match)
+                  .subgraph_isomorphisms_iter())
+        for g, t in enumerate(targets):
+            base = int(graphs.graph_ptr[g])
+            gm = nx.algorithms.isomorphism.GraphMatcher(t, qq, node_match=match)
+            for vmap in gm.subgraph_isomorphisms_iter():
+                out[base + max(vmap.keys()), qi] += 1
+        out[:, qi] /= sym
+    return out

@@ -28,10 +28,18 @@ from .gnn_model import (BaseGNN, H, QUERY_EDGE_TYPES_TCONV, QUERY_EDGE_TYPES_UNI
 def gen_queries(query_ids: List[int], queries=None, transform=None, node_feat_len: int = 1,
                 hetero=True, device="cpu"):
     """Query graphs by atlas id (lightning_model.py:37-87).  Returns ([(n, edges)], [nx.Graph]);
-    the flat pairs replace the list of PyG graphs (``transform`` is applied by QueryBatch)."""
-    if node_feat_len != 1:
-        raise NotImplementedError("--use_node_feature query expansion is outside the hot path")
-    queries_nx = [graph_atlas_plus(q) for q in query_ids] if queries is None else list(queries)
+    the flat pairs replace the list of PyG graphs (``transform`` is applied by QueryBatch).
+    ``node_feat_len != 1`` (--use_node_feature): every atlas query is expanded into its
+    ``node_feat_len ** n`` labelled copies with one-hot node features (utils.py:258-272), in the
+    reference's ``itertools.product`` order; the features are on the returned graphs' ``"feat"``."""
+    from .data import add_node_feat_to_networkx
+    if queries is None:
+        queries_nx = [graph_atlas_plus(q) for q in query_ids]
+        if node_feat_len != 1:
+            eye = [t for t in np.eye(node_feat_len).tolist()]
+            queries_nx = [g for q in queries_nx for g in add_node_feat_to_networkx(q, eye, "feat")]
+    else:
+        queries_nx = list(queries)
     flat = []
     for g in queries_nx:
         nodes = list(g.nodes)
@@ -39,6 +47,20 @@ def gen_queries(query_ids: List[int], queries=None, transform=None, node_feat_le
         flat.append((len(nodes), sorted((min(idx[a], idx[b]), max(idx[a], idx[b]))
                                         for a, b in g.edges())))
     return flat, queries_nx
+
+
+def query_node_features(queries_nx, input_dim: int) -> Optional[torch.Tensor]:
+    """[sum n, input_dim] "feat" rows of the query graphs in node order, or None when no query
+    carries features (NetworkxToHetero then fills zeros, transforms.py:380-384)."""
+    if not any("feat" in g.nodes[v] for g in queries_nx for v in g.nodes):
+        return None
+    rows = []
+    for g in queries_nx:
+        for v in g.nodes:
+            f = g.nodes[v].get("feat")
+            rows.append(torch.zeros(input_dim) if f is None else
+                        torch.as_tensor(f, dtype=torch.float32).reshape(-1))
+    return torch.stack(rows)
 
 
 class _LightningLike(nn.Module):
@@ -72,7 +94,10 @@ class _LightningLike(nn.Module):
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
-        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        # Lightning-free reader with a restricted unpickler: also opens the authors' Lightning 1.6.4
+        # files (pytorch_lightning.* classes in them resolve to inert stand-ins, desco_amd/ckpt.py)
+        from .ckpt import load_checkpoint
+        ckpt = load_checkpoint(checkpoint_path, map_location=map_location or "cpu")
         hp = dict(ckpt["hyper_parameters"])
         hp.update(kwargs)
         args = hp.pop("args")
@@ -145,14 +170,16 @@ class NeighborhoodCountingModel(_LightningLike):
             warnings.warn("neighborhood diameter {:d} is too small for the queries, the minimum is "
                           "{:d}".format(self.depth, min_len_neighbor))
         self.queries_flat = flat
-        self.query_loader = QueryBatch(flat, device or self.device, self.input_dim)
+        self.query_feat = query_node_features(queries_nx, self.input_dim)
+        self.query_loader = QueryBatch(flat, device or self.device, self.input_dim, self.query_feat)
         self._qemb_cache = None
 
     def _queries(self) -> QueryBatch:
         if self.query_loader is None:
             raise RuntimeError("call set_queries() first (main.py:231-233)")
         if self.query_loader.device != self.device and self.device.type == "cuda":
-            self.query_loader = QueryBatch(self.queries_flat, self.device, self.input_dim)
+            self.query_loader = QueryBatch(self.queries_flat, self.device, self.input_dim,
+                                           getattr(self, "query_feat", None))
         return self.query_loader
 
     def get_query_emb(self) -> torch.Tensor:                                # :311-316
@@ -192,7 +219,13 @@ class NeighborhoodCountingModel(_LightningLike):
         else:
             T = ops.gemm(emb_t, hp["wt_t"])
             Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])
-        return ops.count_head(T, Qh, hp["w2"], hp["b2"], self.count_model[1].negative_slope, exp2)
+        slope = self.count_model[1].negative_slope
+        if Qh.shape[0] <= 32:
+            return ops.count_head(T, Qh, hp["w2"], hp["b2"], slope, exp2)
+        # more than 32 queries (labelled queries of --use_node_feature: 784 for input_dim 2): the head
+        # kernel keeps one accumulator per query in registers, so the query axis goes in groups of 32
+        return torch.cat([ops.count_head(T, Qh[q0:q0 + 32], hp["w2"], hp["b2"], slope, exp2)
+                          for q0 in range(0, Qh.shape[0], 32)], dim=1)
 
     def graph_to_count(self, batch) -> torch.Tensor:                         # :198-222
         with torch.no_grad():
@@ -220,8 +253,12 @@ class NeighborhoodCountingModel(_LightningLike):
         W1, b1 = self.count_model[0].weight, self.count_model[0].bias
         T = AG.Linear.apply(emb_t, None, W1[:, :H].t(), None, ops.ACT_NONE, 0.0)
         Qh = AG.Linear.apply(emb_q, None, W1[:, H:].t(), b1, ops.ACT_NONE, 0.0)
-        logits = AG.CountHead.apply(T, Qh, self.count_model[2].weight[0], self.count_model[2].bias[0],
-                                    self.count_model[1].negative_slope)
+        w2, b2, slope = self.count_model[2].weight[0], self.count_model[2].bias[0], self.count_model[1].negative_slope
+        if Qh.shape[0] <= 32:
+            logits = AG.CountHead.apply(T, Qh, w2, b2, slope)
+        else:       # query groups of 32 (see _logits)
+            logits = torch.cat([AG.CountHead.apply(T, Qh[q0:q0 + 32].contiguous(), w2, b2, slope)
+                                for q0 in range(0, Qh.shape[0], 32)], dim=1)
         truth = torch.log2(batch.y.to(logits.dtype) + 1)
         # mean over queries of per-query means == mean over all [B, Q] entries
         return self.criterion(logits, truth)

@@ -40,6 +40,9 @@ class NeighborhoodDataset:
         self.dataset = _as_graphset(dataset if dataset is not None else nx_targets)
         self.depth_neigh, self.root, self.transform = depth_neigh, root, transform
         self.quirk_batch = quirk_batch
+        self.node_feat = bool(node_feat)
+        if self.node_feat and self.dataset.node_feat is None:
+            raise ValueError("node_feat=True needs a dataset with node features (GraphSet.node_feat)")
         self.y: Optional[torch.Tensor] = None
         pdir = os.path.join(root, "processed") if root else None
         names = self.processed_file_names
@@ -77,7 +80,15 @@ class NeighborhoodDataset:
 
     def batch(self, b0: int, b1: int, device="cpu") -> NeighborhoodBatch:
         y = None if self.y is None else self.y[b0:b1]
-        return NeighborhoodBatch(self.partition.slice(b0, b1), device, y=y)
+        part = self.partition.slice(b0, b1)
+        feat = None
+        if self.node_feat:
+            # --use_node_feature: rows = the count nodes' features (count_orig = their global node
+            # ids) followed by the canonical nodes' (NetworkxToHetero "feat", transforms.py:380-384)
+            nf = self.dataset.node_feat
+            canon = self.dataset.graph_ptr[part.neigh_index[:, 0]] + part.neigh_index[:, 1]
+            feat = torch.from_numpy(np.concatenate([nf[part.count_orig], nf[canon]]))
+        return NeighborhoodBatch(part, device, node_feature=feat, y=y)
 
     def batches(self, batch_size: int, device="cpu") -> Iterator[NeighborhoodBatch]:
         for b0 in range(0, len(self), batch_size):
@@ -147,10 +158,15 @@ class Workload:
         self.dataset = _as_graphset(dataset)
         self.root = root
         self.hetero_graph = hetero_graph
-        self.use_node_feat = node_feat_len != -1
+        self.use_node_feat = node_feat_len != -1                                   # workload.py:383
         if self.use_node_feat:
-            raise NotImplementedError("--use_node_feature is outside the hot path (SURVEY 8f N4)")
-        self.node_feat_len = 1
+            nf = self.dataset.node_feat
+            if nf is None or nf.shape[1] != node_feat_len:
+                raise ValueError(f"node_feat_len={node_feat_len}: the dataset carries "
+                                 f"{'no node features' if nf is None else f'{nf.shape[1]}-wide features'}")
+            self.node_feat_len = node_feat_len
+        else:
+            self.node_feat_len = 1
         self.node_feat_key = "feat"
         self.queries, self.query_ids = [], []
         self.canonical_count_truth = torch.tensor([[]])
@@ -164,7 +180,7 @@ class Workload:
             depth_neigh=depth_neigh,
             root=os.path.join(self.root, "NeighborhoodDataset") if self.root else None,
             dataset=self.dataset, transform=neighborhood_transform, hetero_graph=self.hetero_graph,
-            quirk_batch=quirk_batch)
+            node_feat=self.use_node_feat, quirk_batch=quirk_batch)
         self.gossip_dataset = GossipDataset(
             dataset=self.dataset,
             root=os.path.join(self.root, "GossipDataset") if self.root else None,
@@ -191,10 +207,16 @@ class Workload:
 
     def compute_groundtruth(self, query_ids=None, queries=None, num_workers=-1,
                             save_to_file=True) -> torch.Tensor:                   # :551-726
-        from .groundtruth import canonical_counts
-        from .data import graph_atlas_plus
+        from .groundtruth import canonical_counts, canonical_counts_labelled
+        from .data import add_node_feat_to_networkx, graph_atlas_plus
         qs = queries if queries is not None else [graph_atlas_plus(q) for q in query_ids]
-        truth = canonical_counts(self.dataset, qs, num_threads=max(num_workers, 0))
+        if self.use_node_feat and queries is None:                                # :564-577
+            eye = [t for t in np.eye(self.node_feat_len).tolist()]
+            qs = [g for q in qs for g in add_node_feat_to_networkx(q, eye, self.node_feat_key)]
+        if self.use_node_feat:
+            truth = canonical_counts_labelled(self.dataset, qs, self.node_feat_key)
+        else:
+            truth = canonical_counts(self.dataset, qs, num_threads=max(num_workers, 0))
         self.canonical_count_truth = truth
         self.query_ids = query_ids
         if save_to_file and self.root:

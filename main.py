@@ -28,8 +28,9 @@ from desco_amd.transforms import ToTconvHetero
 from desco_amd.workload import Workload
 
 
-def build_workload(name, query_ids, nx_queries, depth, transform, num_cpu, root="data"):
-    w = Workload(load_data(name, root_folder=root), os.path.join(root, name), hetero_graph=True)
+def build_workload(name, query_ids, nx_queries, depth, transform, num_cpu, root="data", node_feat_len=-1):
+    w = Workload(load_data(name, root_folder=root), os.path.join(root, name), hetero_graph=True,
+                 node_feat_len=node_feat_len)
     if w.exist_groundtruth(query_ids=query_ids, queries=nx_queries):
         w.canonical_count_truth = w.load_groundtruth(query_ids=query_ids, queries=nx_queries)
     else:
@@ -44,9 +45,18 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
          atlas_query_ids=None, output_dir="results/raw", data_root="data"):
     if nx_queries is None and atlas_query_ids is None:
         raise ValueError("nx_queries and atlas_query_ids cannot be both None")
+    query_ids = atlas_query_ids
     if nx_queries is None:
         nx_queries = [graph_atlas_plus(i) for i in atlas_query_ids]
-    query_ids = atlas_query_ids
+        if getattr(args_neighborhood, "use_node_feature", False):           # main.py:51-64
+            from desco_amd.data import add_node_feat_to_networkx
+            eye = [t for t in np.eye(args_neighborhood.input_dim).tolist()]
+            nx_queries = [g for q in nx_queries for g in add_node_feat_to_networkx(q, eye, "feat")]
+            query_ids = None
+            print("query_ids set to None because node features are used")
+    else:
+        query_ids = None
+    node_feat_len = args_neighborhood.input_dim if getattr(args_neighborhood, "use_node_feature", False) else -1
     transform = ToTconvHetero() if args_neighborhood.use_tconv else None
     assert args_neighborhood.use_hetero if args_neighborhood.use_tconv else True
     depth, ncpu = args_neighborhood.depth, args_opt.num_cpu
@@ -69,10 +79,12 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
     def build_all():
         tw = vw = None
         if train_neighborhood or train_gossip:
-            tw = build_workload(args_opt.train_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
-            vw = build_workload(args_opt.valid_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root)
+            tw = build_workload(args_opt.train_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root,
+                                node_feat_len)
+            vw = build_workload(args_opt.valid_dataset, query_ids, nx_queries, depth, transform, ncpu, data_root,
+                                node_feat_len)
         return tw, vw, build_workload(args_opt.test_dataset, query_ids, nx_queries, depth, transform, ncpu,
-                                      data_root)
+                                      data_root, node_feat_len)
 
     # rank 0 computes the ground truth / partitions and writes the on-disk caches; the others read them
     if D.rank() == 0:

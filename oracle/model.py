@@ -101,20 +101,21 @@ def base_gnn_hetero(sd, prefix, batch: Dict, node_types, edge_types, layer_num, 
     return post_mp(sd, prefix, pooled)                                              # :108
 
 
-def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1):
-    """emb_model_query on the query batch (lightning_model.py:204-207)."""
+def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1, qfeats=None):
+    """emb_model_query on the query batch (lightning_model.py:204-207).  ``qfeats``
+    {"union_node": [sum n, input_dim]}: labelled queries (--use_node_feature); None = zeros."""
     return base_gnn_hetero(sd, "emb_model_query", qbatch, ("union_node",), P.QUERY_EDGE_TYPES,
-                           layer_num, input_dim)
+                           layer_num, input_dim, qfeats)
 
 
 def neighborhood_logits(sd, batch, qbatch, layer_num=8, input_dim=1, feats=None,
-                        emulate_quirk=True):
+                        emulate_quirk=True, qfeats=None):
     """The [B,Q] pre-exponent outputs of graph_to_count / train_forward.
 
     lightning_model.py:198-219 + embed_to_count :176-193: the queries are re-embedded on every
     call, then per query ``count_model(cat(emb_target, query_emb.expand_as(emb_target)))``.
     """
-    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim)
+    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim, qfeats)
     emb_t = base_gnn_hetero(sd, "emb_model", batch, P.NODE_TYPES, P.EDGE_TYPES, layer_num,
                             input_dim, feats, emulate_quirk)
     outs = []
