@@ -42,16 +42,22 @@ struct GemmSplitArgs {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-constexpr int SBM = 128, SBK = 32, SST = 40;   // SST: plane row stride in bf16 (80 B)
-constexpr int APLANE = SBM * SST;              // elements per A plane
+constexpr int SBK = 32, SST = 40;              // SST: plane row stride in bf16 (80 B)
 
 // NP = 3: hi/mid/lo planes and six products (fp32-accurate); NP = 1: one round-to-nearest bf16 plane
-// and one product (plain bf16 MFMA with fp32 accumulation, the bf16 training mode)
-template <int WN, int NP>
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
-  constexpr int BN = 64 * WN, BPLANE = BN * SST;
+// and one product (plain bf16 MFMA with fp32 accumulation, the bf16 training mode).
+// BM = rows per block tile (128: 4 waves, two blocks per CU).  The A chunk AFTER the next one is kept
+// in flight too: one chunk of MFMAs (2 304 cycles) does not cover an HBM round trip under load, two do
+// (144 -> 156 TF/s fp32-equivalent on the 576^2 anchor GEMM).
+template <int WN, int NP, int BM>
+__global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
+  constexpr int NT = 2 * BM;                   // threads
+  constexpr int BN = 64 * WN, BPLANE = BN * SST, APLANE = BM * SST;
+  constexpr int AR = BM / 4;                   // A staging: row step between a thread's 4 rows
+  constexpr int BR = NT / 4;                   // W staging: rows covered by one pass of the block
+  constexpr int BJ = (BN + BR - 1) / BR;       // passes over the BN weight rows
   extern __shared__ __attribute__((aligned(16))) short lds[];
-  short* Ap = lds;                  // planes hi, mid, lo of the A chunk [128][40]
+  short* Ap = lds;                  // planes hi, mid, lo of the A chunk [BM][40]
   short* Bp = lds + NP * APLANE;    // planes hi, mid, lo of the W chunk [BN][40]
 
   // block id -> (m tile, n tile): ids id, id+8, id+16, ... share an XCD (round-robin dispatch);
@@ -61,21 +67,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
   const int64_t mt = (local / ny) * 8 + (id & 7);
   if (mt >= gm) return;
   const int n0 = (int)(local % ny) * BN;
-  const int64_t m0 = mt * SBM;
+  const int64_t m0 = mt * BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = g.k1 + g.k2;
   const int nchunks = K / SBK;
 
-  // staging maps: A 128 rows x 8 float4 -> 4 per thread; W planes BN rows x 4 uint4 -> WN per plane
+  // staging maps: A BM rows x 8 float4 -> 4 per thread; W planes BN rows x 4 uint4 -> BJ per plane
   const int arow = tid >> 3, ac4 = tid & 7;
-  int64_t r0 = m0 + arow, r1 = r0 + 32, r2 = r0 + 64, r3 = r0 + 96;
   const int64_t mlast = g.m - 1;
+  int64_t r0 = m0 + arow, r1 = r0 + AR, r2 = r0 + 2 * AR, r3 = r0 + 3 * AR;
   r0 = r0 < g.m ? r0 : mlast;
   r1 = r1 < g.m ? r1 : mlast;
   r2 = r2 < g.m ? r2 : mlast;
   r3 = r3 < g.m ? r3 : mlast;
+  // (named scalars, not arrays: hipcc parks indexed register arrays in scratch)
   const float* p10 = g.a1 + r0 * g.lda1 + 4 * ac4;
   const float* p11 = g.a1 + r1 * g.lda1 + 4 * ac4;
   const float* p12 = g.a1 + r2 * g.lda1 + 4 * ac4;
@@ -87,38 +94,37 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
   const int brow = tid >> 2, bpart = tid & 3;
   const short* pw = g.w + (int64_t)(n0 + brow) * K + 8 * bpart;
   const int64_t wplane = (int64_t)g.n * K;
+  const int64_t wj = (int64_t)BR * K;
+  // weight rows brow + j*BR, j < BJ; the last pass may cover only part of the block's threads
+  const bool v0 = BR <= BN || brow < BN;
+  const bool v1 = BJ > 1 && brow + BR < BN;
+  const bool v2 = BJ > 2 && brow + 2 * BR < BN;
 
-  float4 ra0, ra1, ra2, ra3;
+  float4 ra0, ra1, ra2, ra3;                   // A chunk about to be stored
+  float4 rn0, rn1, rn2, rn3;                   // A chunk after it (two chunks of latency cover)
   uint4 rb00, rb01, rb02, rb10, rb11, rb12, rb20, rb21, rb22;   // W planes of the next chunk
-  const int64_t wj = (int64_t)64 * K;
-#define DESCO_LOAD_CHUNK(kk_)                                                                 \
+  rb00 = rb01 = rb02 = rb10 = rb11 = rb12 = rb20 = rb21 = rb22 = make_uint4(0, 0, 0, 0);
+#define DESCO_LOAD_A(d_, kk_)                                                                 \
   {                                                                                           \
     const int k_ = (kk_);                                                                     \
     const bool s1_ = k_ < g.k1;                                                               \
-    ra0 = *reinterpret_cast<const float4*>((s1_ ? p10 : p20) + k_);                           \
-    ra1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);                           \
-    ra2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);                           \
-    ra3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);                           \
-    const short* w_ = pw + k_;                                                                \
-    rb00 = *reinterpret_cast<const uint4*>(w_);                                               \
+    d_##0 = *reinterpret_cast<const float4*>((s1_ ? p10 : p20) + k_);                         \
+    d_##1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);                         \
+    d_##2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);                         \
+    d_##3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);                         \
+  }
+#define DESCO_LOAD_WJ(j_, v_)                                                                 \
+  if (BJ > (j_) && (v_)) {                                                                    \
+    rb##j_##0 = *reinterpret_cast<const uint4*>(w_ + (j_) * wj);                              \
     if constexpr (NP == 3) {                                                                  \
-      rb01 = *reinterpret_cast<const uint4*>(w_ + wplane);                                    \
-      rb02 = *reinterpret_cast<const uint4*>(w_ + 2 * wplane);                                \
+      rb##j_##1 = *reinterpret_cast<const uint4*>(w_ + (j_) * wj + wplane);                   \
+      rb##j_##2 = *reinterpret_cast<const uint4*>(w_ + (j_) * wj + 2 * wplane);               \
     }                                                                                         \
-    if constexpr (WN > 1) {                                                                   \
-      rb10 = *reinterpret_cast<const uint4*>(w_ + wj);                                        \
-      if constexpr (NP == 3) {                                                                \
-        rb11 = *reinterpret_cast<const uint4*>(w_ + wj + wplane);                             \
-        rb12 = *reinterpret_cast<const uint4*>(w_ + wj + 2 * wplane);                         \
-      }                                                                                       \
-    }                                                                                         \
-    if constexpr (WN > 2) {                                                                   \
-      rb20 = *reinterpret_cast<const uint4*>(w_ + 2 * wj);                                    \
-      if constexpr (NP == 3) {                                                                \
-        rb21 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + wplane);                         \
-        rb22 = *reinterpret_cast<const uint4*>(w_ + 2 * wj + 2 * wplane);                     \
-      }                                                                                       \
-    }                                                                                         \
+  }
+#define DESCO_LOAD_W(kk_)                                                                     \
+  {                                                                                           \
+    const short* w_ = pw + (kk_);                                                             \
+    DESCO_LOAD_WJ(0, v0) DESCO_LOAD_WJ(1, v1) DESCO_LOAD_WJ(2, v2)                            \
   }
 #define DESCO_PUT(row_, v_)                                                                   \
   {                                                                                           \
@@ -135,32 +141,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
                                                  pack2_bf16_rne(v_.z, v_.w));                 \
     }                                                                                         \
   }
+#define DESCO_STORE_WJ(j_, v_)                                                                \
+  if (BJ > (j_) && (v_)) {                                                                    \
+    *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST) = rb##j_##0;                              \
+    if constexpr (NP == 3) {                                                                  \
+      *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST + BPLANE) = rb##j_##1;                   \
+      *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST + 2 * BPLANE) = rb##j_##2;               \
+    }                                                                                         \
+  }
 #define DESCO_STORE_CHUNK()                                                                   \
   {                                                                                           \
     DESCO_PUT(arow, ra0)                                                                      \
-    DESCO_PUT(arow + 32, ra1)                                                                 \
-    DESCO_PUT(arow + 64, ra2)                                                                 \
-    DESCO_PUT(arow + 96, ra3)                                                                 \
+    DESCO_PUT(arow + AR, ra1)                                                                 \
+    DESCO_PUT(arow + 2 * AR, ra2)                                                             \
+    DESCO_PUT(arow + 3 * AR, ra3)                                                             \
     short* b_ = Bp + brow * SST + 8 * bpart;                                                  \
-    *reinterpret_cast<uint4*>(b_) = rb00;                                                     \
-    if constexpr (NP == 3) {                                                                  \
-      *reinterpret_cast<uint4*>(b_ + BPLANE) = rb01;                                          \
-      *reinterpret_cast<uint4*>(b_ + 2 * BPLANE) = rb02;                                      \
-    }                                                                                         \
-    if constexpr (WN > 1) {                                                                   \
-      *reinterpret_cast<uint4*>(b_ + 64 * SST) = rb10;                                        \
-      if constexpr (NP == 3) {                                                                \
-        *reinterpret_cast<uint4*>(b_ + 64 * SST + BPLANE) = rb11;                             \
-        *reinterpret_cast<uint4*>(b_ + 64 * SST + 2 * BPLANE) = rb12;                         \
-      }                                                                                       \
-    }                                                                                         \
-    if constexpr (WN > 2) {                                                                   \
-      *reinterpret_cast<uint4*>(b_ + 128 * SST) = rb20;                                       \
-      if constexpr (NP == 3) {                                                                \
-        *reinterpret_cast<uint4*>(b_ + 128 * SST + BPLANE) = rb21;                            \
-        *reinterpret_cast<uint4*>(b_ + 128 * SST + 2 * BPLANE) = rb22;                        \
-      }                                                                                       \
-    }                                                                                         \
+    DESCO_STORE_WJ(0, v0) DESCO_STORE_WJ(1, v1) DESCO_STORE_WJ(2, v2)                         \
   }
 
   f32x16 acc[2][WN];
@@ -171,13 +167,18 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  DESCO_LOAD_CHUNK(0)
+  DESCO_LOAD_A(ra, 0)
+  DESCO_LOAD_W(0)
+  DESCO_LOAD_A(rn, (nchunks > 1 ? 1 : 0) * SBK)
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch > 0) __syncthreads();          // previous chunk's fragments have been read
     DESCO_STORE_CHUNK()
     __syncthreads();
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
-    DESCO_LOAD_CHUNK(chn * SBK)            // in flight under the MFMAs
+    const int chnn = ch + 2 < nchunks ? ch + 2 : chn;
+    ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;
+    DESCO_LOAD_W(chn * SBK)                // in flight under the MFMAs
+    DESCO_LOAD_A(rn, chnn * SBK)           // two chunks ahead (HBM latency)
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
     const short* ap = Ap + (wr * 64 + (lane & 31)) * SST + 8 * (lane >> 5);
     const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST + 8 * (lane >> 5);
@@ -216,9 +217,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs g, int64_
       }
     }
   }
-#undef DESCO_LOAD_CHUNK
+#undef DESCO_LOAD_A
+#undef DESCO_LOAD_W
+#undef DESCO_LOAD_WJ
 #undef DESCO_PUT
 #undef DESCO_STORE_CHUNK
+#undef DESCO_STORE_WJ
 
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col = lane & 31;
@@ -273,24 +277,32 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
   planes[2 * count + i] = (short)(__float_as_uint(r2) >> 16);
 }
 
-template <int WN, int NP>
-static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
+template <int WN, int NP, int BM>
+static int launch_gemm_split_bm(const GemmSplitArgs& g, hipStream_t stream) {
   constexpr int BN = 64 * WN;
-  constexpr size_t lds_bytes = (size_t)(NP * APLANE + NP * BN * SST) * sizeof(short);
+  constexpr size_t lds_bytes = (size_t)(NP * BM * SST + NP * BN * SST) * sizeof(short);
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN, NP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN, NP, BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_f32: cannot size LDS");
     attr_once.mark();
   }
-  const int64_t gm = (g.m + SBM - 1) / SBM;
+  const int64_t gm = (g.m + BM - 1) / BM;
   const int ny = g.n / BN;
   const int64_t blocks = ((gm + 7) / 8) * 8 * ny;
   if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_bf16x6_f32: m too large");
-  hipLaunchKernelGGL((gemm_split_kernel<WN, NP>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, g,
-                     gm, ny);
+  hipLaunchKernelGGL((gemm_split_kernel<WN, NP, BM>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
+                     stream, g, gm, ny);
   return launch_status("desco_gemm_bf16x6_f32");
+}
+
+// BM = 256 (8 waves, half the weight-plane traffic per flop) measured 3 % SLOWER than BM = 128 on the
+// 576^2 anchor GEMM (152 vs 156 TF/s fp32-equivalent, same box): the weight stream from L2 is not
+// what bounds the kernel, so every shape takes the 128-row tile (two blocks per CU).
+template <int WN, int NP>
+static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
+  return launch_gemm_split_bm<WN, NP, 128>(g, stream);
 }
 
 }  // namespace desco

@@ -51,7 +51,7 @@ def test_registered_device_ops_are_the_c_abi_path():
     # <A x, g> == <x, A^T g>
     lhs = float((agg.double() * dagg.double()).sum())
     rhs = float((x.double() * dx.double()).sum())
-    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    assert abs(lhs - rhs) <= 1e-4 * float((agg.double() * dagg.double()).abs().sum()) / agg.numel() ** 0.5 + 1e-5 * abs(lhs)
     pooled = torch.ops.desco.segment_sum(x[:b.num_count], b.count_ptr, b.num_graphs, None)
     ref = torch.zeros(b.num_graphs, 64, dtype=torch.double)
     ref.index_add_(0, torch.from_numpy(np.repeat(np.arange(b.num_graphs), np.diff(part.count_ptr))),
