@@ -96,6 +96,32 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def _seg_ptr_device(self):
         return self.count_ptr
 
+    def pool_index(self):
+        """(pool_bits, pool_slot, num_slots) of the fused pooling (desco_shmp_layer_pool_bf16x6_f32):
+        per 32-row tile of the count rows, the bitmap of rows that END a neighborhood and the first
+        partial slot of the tile (a tile uses one slot per neighborhood that has a row in it)."""
+        if getattr(self, "_pool_index", None) is None:
+            cp = self.part.count_ptr.astype(np.int64)
+            nc = int(cp[-1])
+            if (np.diff(cp) <= 0).any():
+                raise ValueError("fused pooling needs at least one count row per neighborhood")
+            nt = (nc + 31) // 32
+            ends = cp[1:] - 1
+            bits = np.zeros(nt, dtype=np.uint32)
+            np.bitwise_or.at(bits, ends >> 5, (np.uint32(1) << (ends & 31).astype(np.uint32)))
+            pop = np.zeros(nt, dtype=np.int64)
+            np.add.at(pop, ends >> 5, 1)
+            last_row = np.minimum(32 * np.arange(nt, dtype=np.int64) + 31, nc - 1)
+            carry = ((bits >> (last_row & 31).astype(np.uint32)) & 1) == 0    # a segment runs on into the next tile
+            nseg = pop + carry
+            slot = np.concatenate([[0], np.cumsum(nseg)])
+            if slot[-1] >= 2 ** 31:
+                raise ValueError("too many pooling slots for int32")
+            dev = self.device
+            self._pool_index = (torch.from_numpy(bits.view(np.int32)).to(dev),
+                                torch.from_numpy(slot[:-1].astype(np.int32)).to(dev), int(slot[-1]))
+        return self._pool_index
+
     # PyG-style views -----------------------------------------------------------------------
     @property
     def node_feature_dict(self) -> Dict[str, torch.Tensor]:

@@ -33,7 +33,12 @@
 //   * table slots run as one extra pseudo K block: their pre-transformed source rows are gathered
 //     the same way, staged in the A image and ADDED to the accumulators in the C/D layout;
 //   * HBM traffic per row and layer: one 256-B read of x, one 256-B write, ~20 B of indices
-//     (neighbour re-reads hit L2 / MALL: a neighborhood's rows are contiguous).
+//     (neighbour re-reads hit L2 / MALL: a neighborhood's rows are contiguous);
+//   * optional fused pooling (global_add_pool of the produced rows): after the stores a wave swaps
+//     the two lane halves of its accumulators (v_permlane32_swap: lane = column, all 32 rows of the
+//     tile in registers in row order), runs one running sum down the rows and writes it out at every
+//     segment end -- one 256-B partial per (tile, segment), summed per segment by pool_reduce_kernel.
+//     All control flow of that pass is wave-uniform (the segment-end bitmap of the tile is a scalar).
 //
 // Two arithmetic modes share the gather:
 //   f32   v_mfma_f32_32x32x2_f32 on an fp32 A image [32][33] and fp32 weights [K][64];
@@ -81,6 +86,11 @@ struct ShmpArgs {
   int64_t ldo2;
   int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
   float slope;
+  // fused pooling (global_add_pool of the produced rows, gnn_model.py:107), optional: see
+  // desco_shmp_layer_pool_bf16x6_f32 in desco_hip.h.  out may then be null (rows not stored).
+  const uint32_t* pool_bits;   // [ceil(rows / 32)] bit r of word t: row 32 t + r is the last row of its segment
+  const int32_t* pool_slot;    // [ceil(rows / 32)] first partial slot of 32-row tile t
+  float* pool_part;            // [num slots][64] partial segment sums
 };
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -347,7 +357,8 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // KB = sm + 1 resident weight blocks (1..4), ST table slots (0..2), X6: bf16 6-product arithmetic,
 // LD64: x rows are 64 floats and ytab rows 64*ST floats apart (the product path's layouts): source-row
 // addresses then need a shift instead of a 64-bit multiply per gathered row
-template <int KB, int ST, bool X6, bool LD64>
+// POOL: fused pooling epilogue (instantiated for the count-row launches of the x6 form only)
+template <int KB, int ST, bool X6, bool LD64, bool POOL = false>
 __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WST = KB * 64 + 8;                         // weight plane row stride (shorts)
@@ -439,6 +450,15 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     }
     int qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0;   // source ids of the next tile (registers until the tile ends)
     int ebn = 0, ecntn = 0;
+    // fused pooling: this tile's segment-end bitmap and first partial slot (wave-uniform address:
+    // scalar loads, in flight under the whole tile)
+    uint32_t pool_e = 0;
+    int pool_s = 0;
+    if constexpr (POOL) {
+      const int t32 = __builtin_amdgcn_readfirstlane((int)(grow0 >> 5));
+      pool_e = g.pool_bits[t32];
+      pool_s = g.pool_slot[t32];
+    }
 
     // ---- accumulator init: bias ----------------------------------------------------------------
     f32x16 acc0, acc1;
@@ -548,19 +568,54 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
     // ---- epilogue: relu + store; C/D map col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5) ----
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (r < nr_out) {
-        const float v0 = acc0[reg], v1 = acc1[reg];
-        const float r0v = apply_act(v0, g.act, g.slope), r1v = apply_act(v1, g.act, g.slope);
-        float* o = g.out + (grow_out + r) * g.ldo + cl;
-        o[0] = r0v;
-        o[32] = r1v;
-        if (g.out2) {        // e.g. the canonical rows' column block of the anchor-MLP operand
-          float* o2 = g.out2 + (grow_out - g.row0 + r) * g.ldo2 + cl;
-          o2[0] = r0v;
-          o2[32] = r1v;
+      acc0[reg] = apply_act(acc0[reg], g.act, g.slope);
+      acc1[reg] = apply_act(acc1[reg], g.act, g.slope);
+    }
+    if (!POOL || g.out) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (r < nr_out) {
+          float* o = g.out + (grow_out + r) * g.ldo + cl;
+          o[0] = acc0[reg];
+          o[32] = acc1[reg];
+          if (g.out2) {        // e.g. the canonical rows' column block of the anchor-MLP operand
+            float* o2 = g.out2 + (grow_out - g.row0 + r) * g.ldo2 + cl;
+            o2[0] = acc0[reg];
+            o2[32] = acc1[reg];
+          }
         }
       }
+    }
+    if constexpr (POOL) {
+      // lane halves swapped: acc0[reg] = row (reg&3)+8*(reg>>2), acc1[reg] = that row + 4, column = lane
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[reg]), __float_as_uint(acc1[reg]),
+                                                          false, false);
+        acc0[reg] = __uint_as_float(t_[0]);
+        acc1[reg] = __uint_as_float(t_[1]);
+      }
+      const uint32_t E = __builtin_amdgcn_readfirstlane(pool_e);
+      int slot = __builtin_amdgcn_readfirstlane(pool_s);
+      const int nru = __builtin_amdgcn_readfirstlane(nr_out);
+      float* pp = g.pool_part + lane;
+      float run = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int reg = (r & 3) + 4 * (r >> 3);
+        if (r < nru) {                                        // (wave-uniform)
+          run += ((r >> 2) & 1) ? acc1[reg] : acc0[reg];
+          if ((E >> r) & 1u) {                                // row r ends its segment (wave-uniform)
+            pp[(int64_t)slot * 64] = run;
+            ++slot;
+            run = 0.f;
+          }
+        }
+      }
+      // the last segment of the tile continues in the next tile: its partial so far
+      if (nru > 0 && !((E >> (nru - 1)) & 1u)) pp[(int64_t)slot * 64] = run;
     }
     if (!has_next) break;
   }
@@ -677,7 +732,7 @@ __global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
 #undef DESCO_MFMA_HALF_X6
 #undef DESCO_TAB_HALF
 
-template <int KB, int ST, bool X6, bool LD64>
+template <int KB, int ST, bool X6, bool LD64, bool POOL = false>
 static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 8;
   constexpr size_t w_floats = X6 ? (size_t)3 * 64 * WST / 2 : (size_t)KB * 64 * 64;
@@ -685,16 +740,25 @@ static void shmp_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   static_assert(shmem <= 160 * 1024, "SHMP layer: LDS budget exceeded");
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6, LD64>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer_f32_kernel<KB, ST, X6, LD64, POOL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.mark();
   }
-  hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6, LD64>), dim3(grid), dim3(NW * 64), shmem, st, g);
+  hipLaunchKernelGGL((shmp_layer_f32_kernel<KB, ST, X6, LD64, POOL>), dim3(grid), dim3(NW * 64), shmem, st, g);
 }
 
 template <int KB, bool X6>
 static void shmp_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st);
+  if constexpr (KB == 3 && X6) {
+    if (g.pool_part) {       // count-row launches of the product path (validated by shmp_launch)
+      if (ld64)
+        shmp_launch_one<3, 2, true, true, true>(g, grid, st);
+      else
+        shmp_launch_one<3, 2, true, false, true>(g, grid, st);
+      return;
+    }
+  }
 #define DESCO_ONE(ST_)                                         \
   if (ld64)                                                    \
     shmp_launch_one<KB, ST_, X6, true>(g, grid, st);           \
@@ -716,16 +780,23 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const int32_t* vcol, int64_t row0, int64_t num_rows, int slots_stored,
                        int slots_mfma, int slots_table, const void* weights, const float* bias,
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
-                       float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream) {
+                       float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream,
+                       const uint32_t* pool_bits = nullptr, const int32_t* pool_slot = nullptr,
+                       float* pool_part = nullptr) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
-  if (!x || (!vrowptr && slots_stored > 0) || !weights || !out || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
+  const bool pool = pool_part != nullptr;
+  if (pool && (!pool_bits || !pool_slot || row0 % 32 || mis16(pool_part) || out2 || !x6 || slots_mfma != 2 ||
+               slots_table != 2))
+    return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % 32, no out2, "
+                              "slots_mfma == 2, slots_table == 2)");
+  if (!x || (!vrowptr && slots_stored > 0) || !weights || (!out && !pool) || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
       slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
       ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
       (slots_table > 0 && mis16(ytab)) || x == out || x == out2 ||
-      mis16(out) || ldo % 4 || (out2 && (mis16(out2) || ldo2 % 4)))      // float4 stores
+      (out && (mis16(out) || ldo % 4)) || (out2 && (mis16(out2) || ldo2 % 4)))      // float4 stores
     return fail(DESCO_EINVAL,
                 x6 ? "desco_shmp_layer_bf16x6_f32: bad argument (slots_mfma <= 2, slots_table <= 2)"
                    : "desco_shmp_layer_f32: bad argument (slots_mfma <= 3, slots_table <= 2)");
@@ -757,7 +828,10 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              out2,
              ldo2,
              act,
-             slope};
+             slope,
+             pool_bits,
+             pool_slot,
+             pool_part};
   hipStream_t st = (hipStream_t)stream;
   if (x6) {
     switch (slots_mfma) {
@@ -799,6 +873,22 @@ extern "C" int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const in
   return desco::shmp_launch("desco_shmp_layer_bf16x6_f32", true, x, ldx, vrowptr, vcol, row0,
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
                             ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream);
+}
+
+extern "C" int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                                const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                                int slots_stored, int slots_mfma, int slots_table,
+                                                const int16_t* wt_planes, const float* bias,
+                                                const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                                float* out, int64_t ldo, const uint32_t* pool_bits,
+                                                const int32_t* pool_slot, float* pool_part,
+                                                desco_stream_t stream) {
+  if (!pool_part)
+    return desco::fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: pool_part is null");
+  return desco::shmp_launch("desco_shmp_layer_pool_bf16x6_f32", true, x, ldx, vrowptr, vcol, row0,
+                            num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
+                            ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
+                            pool_bits, pool_slot, pool_part);
 }
 
 // Row-wise Linear with K = 64 inputs (see linear64_kernel): out[i, 0:64*nb] = act(x[i, 0:64] * W^T + bias),

@@ -32,6 +32,9 @@ FUSED_GOSSIP = True
 GEMM_BF16X6 = True
 # True: the fused SHMP layer's MFMA blocks also run as the bf16x6 split (csrc/shmp_layer.hip, K <= 192)
 SHMP_BF16X6 = True
+# True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
+# (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
+FUSED_POOLING = True
 
 TARGET_NODE_TYPES = ["count", "canonical"]
 # metadata of to_hetero_old(tconv_target=True), lightning_model.py:376-383
@@ -409,7 +412,16 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     # column block directly (out2), so no concatenation pass is needed
     direct_canon = FUSED_SHMP_LAYER and isinstance(batch, NeighborhoodBatch)
     canon = torch.empty((B, P), device=dev) if direct_canon else None
+    # fused pooling: the count launches leave partial neighborhood sums, reduced after the anchor MLP
+    fpool = (FUSED_POOLING and FUSED_SHMP_LAYER and SHMP_BF16X6 and GEMM_BF16X6
+             and isinstance(batch, NeighborhoodBatch) and Nc > 0)
+    pool_parts = {}
+    if fpool:
+        pbits, pslot, nslots = batch.pool_index()
     for l in range(first, core.layer_num):
+        last = l == core.layer_num - 1
+        # the last layer's count rows feed nothing but the pooling: with fused pooling they are
+        # never stored (the canonical rows still are, they sit at the end of the same tensor)
         xn = torch.empty((N, H), device=dev)
         if FUSED_SHMP_LAYER:
             for t, r0, r1, su in groups:                                   # :262-264, :273, :389-395
@@ -419,9 +431,14 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                 if "wt_tab" in e:
                     ytab = (ops.linear64(X[-1][Nc:], e["wt_tab_l64"]) if GEMM_BF16X6 else
                             ops.gemm(X[-1][Nc:], e["wt_tab"]))            # canonical rows x [W2|W3]
+                    pool = None
+                    if fpool and "wt_mfma_x6" in e:
+                        pool_parts[l + 1] = torch.empty((nslots, H), device=dev)
+                        pool = (pbits, pslot, pool_parts[l + 1])
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2,
                                    e.get("wt_mfma_x6", e["wt_mfma"]) if SHMP_BF16X6 else e["wt_mfma"],
-                                   e["b"], xn, ytab=ytab, ytab_row0=Nc)
+                                   e["b"], None if (pool is not None and last) else xn, ytab=ytab,
+                                   ytab_row0=Nc, pool=pool)
                 else:
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
                                    e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn,
@@ -462,6 +479,8 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
             if ck not in pk:
                 pk[ck] = torch.stack([x0[t0], torch.zeros(H, device=dev)]).contiguous()
             ops.degree_affine(seg_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, out_l, extra=extra)
+        elif l in pool_parts:
+            ops.pool_reduce(pool_parts[l], pbits, pslot, seg_ptr, B, extra=extra, out=out_l)
         else:
             ops.segment_sum(xl[:Nc], seg_ptr, B, extra=extra, out=out_l)
     return _post_mp(pk, pooled)                                            # :108

@@ -174,14 +174,21 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0: int,
                num_rows: int, slots_stored: int, slots_mfma: int, wt: torch.Tensor,
-               bias: torch.Tensor, out: torch.Tensor, ytab: Optional[torch.Tensor] = None,
-               ytab_row0: int = 0, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+               bias: torch.Tensor, out: Optional[torch.Tensor], ytab: Optional[torch.Tensor] = None,
+               ytab_row0: int = 0, out2: Optional[torch.Tensor] = None,
+               pool: Optional[tuple] = None) -> Optional[torch.Tensor]:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
     ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1.
     ``out2`` [num_rows, >=64] (optional): second copy of the produced rows (see desco_hip.h).
     ``wt``: fp32 [(sm+1)*64, 64] (f32 MFMA) or int16 planes [3, 64, (sm+1)*64] =
-    ``split_bf16_planes(wt.t())`` (fp32-accurate bf16x6 arithmetic, sm <= 2)."""
+    ``split_bf16_planes(wt.t())`` (fp32-accurate bf16x6 arithmetic, sm <= 2).
+    ``pool`` = (pool_bits, pool_slot, pool_part): also leave the per-(tile, segment) partial sums of
+    the produced rows in ``pool_part`` (fused global_add_pool, finished by ``pool_reduce``); ``out``
+    may then be None (rows not stored)."""
     x6 = wt.dtype == torch.int16
+    if pool is not None:
+        return _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out,
+                                ytab, ytab_row0, pool)
     if x6:
         assert wt.is_contiguous() and wt.shape == (3, 64, (slots_mfma + 1) * 64)
     else:
@@ -205,6 +212,46 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                       slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
                       _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
                       op, ldo, o2p, ldo2, _stream()), "shmp_layer")
+    return out
+
+
+def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out, ytab,
+                     ytab_row0, pool):
+    bits, slot, part = pool
+    assert wt.dtype == torch.int16 and wt.is_contiguous() and ytab is not None
+    xp, ldx = _rows(x, "x")
+    op, ldo = (None, 0) if out is None else _rows(out, "out")
+    st = ytab.shape[1] // 64
+    yp, ldy = _rows(ytab, "ytab")
+    L = _lib.lib()
+    fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
+    # x once (+ out once when stored) + indices + the partial rows (about one per 32 rows + one per segment)
+    nb = (256.0 if out is None else 512.0) * num_rows + 4.0 * (num_rows * slots_stored +
+                                                                vcol.numel() * num_rows / max(x.shape[0], 1))
+    with _Timed(f"shmp_layer_f32_kernel<{slots_mfma + 1},{st},x6>", fl, nb):
+        _lib.check(L.desco_shmp_layer_pool_bf16x6_f32(
+            xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
+            slots_stored, slots_mfma, st, _dev(wt, "wt", torch.int16), _dev(bias.contiguous(), "bias"), yp, ldy,
+            ytab_row0, op, ldo, _dev(bits, "pool_bits", torch.int32), _dev(slot, "pool_slot", torch.int32),
+            _dev(part, "pool_part"), _stream()), "shmp_layer_pool")
+    return out
+
+
+def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_ptr: torch.Tensor,
+                num_seg: int, extra: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = sum of segment b's partial rows (left by ``shmp_layer(pool=...)``) + extra[b]."""
+    if out is None:
+        out = torch.empty((num_seg, 64), device=part.device, dtype=torch.float32)
+    op, ldo = _rows(out, "out")
+    ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
+    L = _lib.lib()
+    with _Timed("pool_reduce_kernel", float(part.shape[0]) * 64,
+                256.0 * part.shape[0] + 4.0 * (2 * bits.numel() + num_seg) + 512.0 * num_seg):
+        _lib.check(L.desco_pool_reduce_f32(_dev(part, "pool_part"), _dev(bits, "pool_bits", torch.int32),
+                                           _dev(slot, "pool_slot", torch.int32),
+                                           _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, ep, lde, op, ldo,
+                                           _stream()), "pool_reduce")
     return out
 
 

@@ -199,3 +199,47 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+
+
+def test_pool_index_slots_are_consistent_between_kernel_and_reduce():
+    """The fused pooling's index (NeighborhoodBatch.pool_index): emulate the layer kernel's slot
+    walk (one slot per segment end in a tile + one for a segment that runs on) and the reduce
+    kernel's slot lookup (slot_base[t] + popcount of the ends before the segment's first row in the
+    tile) -- every (tile, segment) pair must get one private slot and the partials must add up."""
+    import torch
+    from desco_amd.batch import NeighborhoodBatch
+    rng = np.random.default_rng(3)
+    for lens in ([1], [32], [33], [5, 1, 1, 90, 2, 31, 64, 1], list(rng.integers(1, 70, size=200)),
+                 [1] * 100, [700, 3, 640]):
+        cp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+        class _P:
+            count_ptr = cp
+        nb = NeighborhoodBatch.__new__(NeighborhoodBatch)
+        nb.part, nb.device = _P, torch.device("cpu")
+        bits, slot, nslots = nb.pool_index()
+        bits = bits.numpy().view(np.uint32)
+        slot = slot.numpy()
+        nc = int(cp[-1])
+        vals = rng.standard_normal(nc)
+        part = np.full(nslots, np.nan)
+        for t in range((nc + 31) // 32):                        # the layer kernel's walk over tile t
+            s, run, nr = int(slot[t]), 0.0, min(32, nc - 32 * t)
+            for r in range(nr):
+                run += vals[32 * t + r]
+                if (bits[t] >> r) & 1:
+                    assert np.isnan(part[s])
+                    part[s] = run
+                    s, run = s + 1, 0.0
+            if not (bits[t] >> (nr - 1)) & 1:
+                assert np.isnan(part[s])
+                part[s] = run
+        assert not np.isnan(part).any()
+        for b in range(len(lens)):                              # the reduce kernel's lookup
+            r0, r1 = int(cp[b]), int(cp[b + 1])
+            tot = 0.0
+            for t in range(r0 >> 5, ((r1 - 1) >> 5) + 1):
+                first = max(r0 - 32 * t, 0)
+                k = bin(int(bits[t]) & ((1 << first) - 1)).count("1")
+                tot += part[slot[t] + k]
+            assert abs(tot - vals[r0:r1].sum()) < 1e-9

@@ -225,6 +225,70 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
 
+@pytest.mark.parametrize("num_rows,seg_kind", [(1, "one"), (31, "tiny"), (32, "tiny"), (1000, "mixed"),
+                                               (70001, "mixed"), (70000, "huge"), (4096, "single-rows")])
+def test_fused_pooling_equals_segment_sum(num_rows, seg_kind):
+    """desco_shmp_layer_pool_bf16x6_f32 + desco_pool_reduce_f32 == the layer followed by
+    desco_segment_sum_f32 (global_add_pool, gnn_model.py:107): produced rows bit-identical to the plain
+    launch, segment sums equal to fp32 rounding (a segment's partials are added tile by tile);
+    segments of one row, segments spanning 60+ tiles, ragged last tile, rows not stored."""
+    g = torch.Generator().manual_seed(num_rows + len(seg_kind))
+    S, sm, st = 4, 2, 2
+    n_tab = 50
+    x = torch.randn(num_rows + n_tab, 64, generator=g)
+    ptr, col, cnt = _random_vcsr(num_rows + n_tab, S, 3, num_rows, g)
+    # table slots (2, 3) read the table rows [num_rows, num_rows + n_tab)
+    vrow = torch.repeat_interleave(torch.arange((num_rows + n_tab) * S), cnt)
+    is_tab = (vrow % S) >= sm
+    col = torch.where(is_tab, num_rows + col % n_tab, col % num_rows).to(torch.int32)
+    if seg_kind == "one":
+        lens = [num_rows]
+    elif seg_kind == "single-rows":
+        lens = [1] * num_rows
+    else:
+        hi = {"tiny": 3, "mixed": 40, "huge": 3000}[seg_kind]
+        lens, left = [], num_rows
+        while left > 0:
+            k = int(torch.randint(1, hi + 1, (1,), generator=g))
+            k = min(k, left)
+            lens.append(k)
+            left -= k
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    B = len(lens)
+
+    class _P:           # the slice of NeighborhoodPartition that NeighborhoodBatch.pool_index reads
+        count_ptr = seg
+    from desco_amd.batch import NeighborhoodBatch
+    nb = NeighborhoodBatch.__new__(NeighborhoodBatch)
+    nb.part, nb.device = _P, torch.device(DEV, torch.cuda.current_device())
+    bits, slot, nslots = nb.pool_index()
+    assert nslots <= B + (num_rows + 31) // 32
+    wt = torch.randn(3 * 64, 64, generator=g) / 12
+    bias = torch.randn(64, generator=g)
+    planes = ops.split_bf16_planes(wt.t().contiguous().to(DEV))
+    ytab = torch.randn(n_tab, 128, generator=g).to(DEV)
+    xd, ptrd, cold, segd = x.to(DEV), ptr.to(DEV), col.to(DEV), torch.from_numpy(seg).to(DEV)
+    plain = torch.empty(num_rows, 64, device=DEV)
+    ops.shmp_layer(xd, ptrd, cold, 0, num_rows, S, sm, planes, bias.to(DEV), plain, ytab=ytab, ytab_row0=num_rows)
+    ref = ops.segment_sum(plain, segd, B)
+    extra = torch.randn(B, 64, generator=g).to(DEV)
+    for store in (True, False):
+        part = torch.full((nslots, 64), float("nan"), device=DEV)
+        out = torch.full((num_rows, 64), -7.0, device=DEV) if store else None
+        ops.shmp_layer(xd, ptrd, cold, 0, num_rows, S, sm, planes, bias.to(DEV), out, ytab=ytab,
+                       ytab_row0=num_rows, pool=(bits, slot, part))
+        assert torch.isfinite(part).all()                       # every slot written exactly once
+        if store:
+            assert torch.equal(out, plain)
+        got = ops.pool_reduce(part, bits, slot, segd, B)
+        _close(got, ref.double().cpu(), rtol=1e-5, atol=1e-4)
+        got_e = ops.pool_reduce(part, bits, slot, segd, B, extra=extra)
+        _close(got_e, (ref + extra).double().cpu(), rtol=1e-5, atol=1e-4)
+    exact = torch.zeros(B, 64, dtype=torch.double).index_add_(
+        0, torch.from_numpy(np.repeat(np.arange(B), lens)), plain.double().cpu())
+    _close(got, exact, rtol=1e-5, atol=1e-4 * max(1, max(lens)) ** 0.5)
+
+
 @pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (300, 128, 64, 128), (1000, 576, 0, 576), (4097, 64, 0, 192)])
 def test_gemm_bf16_rounds_operands_to_nearest_even(m, k1, k2, n):
     """bf16 training GEMM == exact product of the RNE-bf16-rounded operands (fp32 accumulation)."""

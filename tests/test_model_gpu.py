@@ -127,11 +127,14 @@ def test_full_size_run_is_replica_invariant(setup):
         assert torch.isfinite(x).all(), key
         ref = small[key].reshape(1, per, Q)
         assert float(ref.abs().max()) > 1e-3 and float(ref.std()) > 0.0, key    # not a trivial output
-        scale = ref.abs().clamp_min(1e-3)
-        worst = float(((x - ref).abs() / scale).max())
-        print(f"[property] {key}: worst replica deviation {worst:.2e} (relative to max(1e-3, |count|)); "
+        # counts are 2**logit - 1 with fp32 logits: their absolute precision is ~1e-7 * (1 + count), so
+        # deviations are measured in that (log-space) scale.  Replicas are not bit-identical: a
+        # neighborhood's pooled sum is added up tile by tile (fused pooling) and where the 32-row tiles
+        # cut it depends on the replica's position in the launch -- fp32 rounding, nothing more
+        worst = float(((x - ref).abs() / (1.0 + ref.abs())).max())
+        print(f"[property] {key}: worst replica deviation {worst:.2e} (relative to 1 + |count|); "
               f"max |count| {float(ref.abs().max()):.3e}")
-        assert worst < 1e-4, (key, worst)
+        assert worst < 1e-5, (key, worst)
 
 
 def test_gossip_conv_standalone_forward(setup):

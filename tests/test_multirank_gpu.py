@@ -58,9 +58,9 @@ def test_two_rank_pipeline_equals_one_rank(tmp_path):
         exact = torch.equal(got, ref)
         # a row's in-tile summation order depends on where its tile falls in the launch, so shards
         # agree to fp32 rounding (amplified by 2**logit), as slices of one launch do
-        scale = ref.abs().clamp_min(1e-3)
-        worst = float(((got - ref).abs() / scale).max())
-        print(f"[multirank] {k}: bit-identical={exact}, worst relative deviation {worst:.2e}")
+        # (counts are 2**logit - 1: deviations in the log-space scale 1 + |count|)
+        worst = float(((got - ref).abs() / (1.0 + ref.abs())).max())
+        print(f"[multirank] {k}: bit-identical={exact}, worst deviation {worst:.2e} (relative to 1 + |count|)")
         assert worst < 1e-4, (k, worst)
     assert float(one["graph_gossip_count"].abs().max()) > 1e-3
 
