@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--no-x1", action="store_true", help="skip the small-dataset (x1) latency line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of the other workload shapes (Syn_1827, MSRC+IMDB)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the pass from a captured hipGraph (implies --no-profile)")
     ap.add_argument("--neigh-rows", type=int, default=6_000_000,
@@ -237,6 +239,49 @@ def main():
         if rank == 0:
             assert g_all.shape[0] == graphs.num_graphs * world and torch.isfinite(g_all).all()
 
+    primary_summary = ops.PROFILER.summary() if not args.no_profile else {}
+    # secondary workloads (every rank runs them; rank 0 reports): weak scaling, 3 timed steps
+    secondary = {}
+    if not args.no_secondary:
+        for wname, wrep in (("syn_1827", 2), ("msrc_imdb", 8)):
+            if wname == args.workload:
+                continue
+            g2 = synthetic.WORKLOADS[wname]().replicate(wrep)
+            p2 = InferencePipeline(nm, gm, g2, depth=4, device=device, max_neigh_rows=args.neigh_rows,
+                                   max_gossip_rows=args.gossip_rows, rank=0, world=1)
+            p2.run()
+            sync()
+            ops.PROFILER.enabled = True
+            ops.PROFILER.reset()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                p2.run()
+            sync()
+            dt = time.perf_counter() - t0
+            ops.PROFILER.enabled = False
+            if world > 1:
+                t = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
+                D.all_reduce_(t, "max")
+                dt = float(t.item())
+            summ2 = ops.PROFILER.summary()
+            tot2 = sum(d["ms"] for d in summ2.values())
+            gk = summ2.get(GATHER_KERNEL)
+            dom, dd = max(summ2.items(), key=lambda kv: kv[1]["ms"])
+            entry = {"value": g2.num_graphs * world * 3 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt / 3,
+                     "graphs_per_gpu": g2.num_graphs, "neighborhood_rows_per_gpu": p2.partition.num_rows,
+                     "neighborhood_directed_edges_per_gpu": p2.partition.num_edges,
+                     "dominant_kernel": dom, "dominant_share_of_kernel_time": dd["ms"] / tot2}
+            if gk and gk["ms"] > 0:
+                gbs = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
+                tfs = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+                entry["gather"] = {"kernel": GATHER_KERNEL, "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                                   "mfma_TFLOPs": tfs, "mfma_frac_of_x6_peak": tfs / PEAK_X6_TFLOPS,
+                                   "share_of_kernel_time": gk["ms"] / tot2,
+                                   "avg_launch_ms": gk["ms"] / gk["calls"]}
+            secondary[f"{wname}_x{wrep}"] = entry
+            del p2, g2
+            torch.cuda.empty_cache()
+
     graphs_per_step = graphs.num_graphs if strong else graphs.num_graphs * world
     value = graphs_per_step * args.steps / elapsed
     cnt = torch.tensor([pipe.graphs.num_graphs, pipe.graphs.num_nodes, part.num_neigh, part.num_rows,
@@ -265,7 +310,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, from the HIP events of the timed region -----------
         if not args.no_profile:
-            summ = ops.PROFILER.summary()
+            summ = primary_summary
             tot = sum(d["ms"] for d in summ.values())
             name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
             calls = d["calls"]
@@ -319,6 +364,10 @@ def main():
                     "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3) if v["ms"] > 0 else None,
                     "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        # ---- the other BASELINE workload shapes, short runs of the same pass (Syn_1827-shaped: C3 / C4,
+        #      MSRC-21 + IMDB-BINARY-shaped: C5), each with its own gather roofline --------------------
+        if not args.no_secondary:
+            result["secondary"] = secondary
         # ---- small-dataset latency: the real dataset size (x1), hipGraph replay vs eager --------
         if world == 1 and not args.no_x1 and args.replicas != 1:
             p1 = InferencePipeline(nm, gm, base, depth=4, device=device)

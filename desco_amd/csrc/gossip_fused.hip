@@ -23,10 +23,11 @@
 //   Rows are 128 B without padding; the 16-byte chunk index is XOR-swizzled with (row>>1)&7, which
 //   makes every ds_read_b128 fragment read conflict-free.
 // The GEMMs are computed TRANSPOSED (MFMA A operand = weight rows, B operand = activation rows):
-// in the 32x32 C/D layout a lane then owns one node and 4 consecutive output features per register
-// quad, so an epilogue packs bf16 pairs in registers and writes 8 bytes per plane, reads its
+// in the C/D layout a lane then owns a node and 4 consecutive output features per accumulator tile,
+// so an epilogue packs bf16 pairs in registers and writes 8 bytes per plane, reads its
 // per-node scalars once, and the final 256-wide dot product is a per-lane running sum.
-// Wave (wm = wave&3, wn = wave>>2) owns nodes 32wm..+31 x features 32wn..+31 of every 64-wide block.
+// Wave (wm = wave&3, wn = wave>>2) owns nodes 32wm..+31 x features 32wn..+31 of every 64-wide block,
+// as 2 x 2 tiles of v_mfma_f32_16x16x32_bf16 (a lane then owns two nodes and 2 x 4 features).
 // The next item's CSR slice and scalar records are prefetched through registers in three stages
 // under the current item's GEMMs.  Algebra: DESIGN.md 4.2.
 #include "common_device.hpp"
@@ -136,61 +137,103 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
     *reinterpret_cast<uint4*>(d_ + WPLN) = q1;                                         \
     *reinterpret_cast<uint4*>(d_ + 2 * WPLN) = q2;                                     \
   }
-// the six products of one 16-deep step (smallest terms first)
-#define GF_MFMA6(wh_, wm_, wl_, xh_, xm_, xl_)                                     \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_, xh_, acc, 0, 0, 0);           \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xl_, acc, 0, 0, 0);           \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm_, xm_, acc, 0, 0, 0);           \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm_, xh_, acc, 0, 0, 0);           \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xm_, acc, 0, 0, 0);           \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_, xh_, acc, 0, 0, 0);
-// 24 MFMAs of one 64x64 weight block: D^T[n][node] += sum_k W[n][k] X[node][k]; lane (r = lane&31,
-// h = lane>>5) holds W[32wn + r][16 s + 8 h + 0..7] and X[32wm + r][16 s + 8 h + 0..7] of every plane.
-// The six fragments of step s+1 are read while the MFMAs of step s run (two register sets).
-#define GF_FRAGS(wa_, xa_, s_, wh_, wm_, wl_, xh_, xm_, xl_)                                       \
-  {                                                                                                \
-    const int c_ = (((2 * (s_) + (lane >> 5)) ^ swz) & 7) << 3;                                    \
-    wh_ = *reinterpret_cast<const bf16x8*>((wa_) + c_);                                            \
-    wm_ = *reinterpret_cast<const bf16x8*>((wa_) + WPLN + c_);                                     \
-    wl_ = *reinterpret_cast<const bf16x8*>((wa_) + 2 * WPLN + c_);                                 \
-    xh_ = *reinterpret_cast<const bf16x8*>((xa_) + c_);                                            \
-    xm_ = *reinterpret_cast<const bf16x8*>((xa_) + PLN + c_);                                      \
-    xl_ = *reinterpret_cast<const bf16x8*>((xa_) + 2 * PLN + c_);                                  \
+// MFMA shape: v_mfma_f32_16x16x32_bf16.  At equal cycles per flop the chip holds a 12-14 % higher clock
+// under it than under v_mfma_f32_32x32x16_bf16 (tools/micro/mfma_peak.hip: 2.2 vs 1.94 PFLOP/s on random
+// data), and the swizzled plane layout is conflict-free for its fragment reads as it stands.
+// A wave's 32 features x 32 nodes of a 64-wide block are 2 x 2 tiles of 16 x 16: acc_ij, i = feature
+// tile, j = node tile.  Lane (r16 = lane & 15, q4 = lane >> 4) holds, per 32-deep k step t and plane,
+// W[32 wn + 16 i + r16][32 t + 8 q4 + 0..7] and X[32 wm + 16 j + r16][32 t + 8 q4 + 0..7] (16-byte
+// fragments), and after the MFMAs D^T[feature 32 wn + 16 i + 4 q4 + e][node 32 wm + 16 j + r16].
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+#define GF_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
+// the six products (smallest terms first) of one weight tile w_ with both node tiles of x_
+#define GF_MM(c0_, c1_, w_, x_)                                       \
+  GF_M16(w_##l, x_##0h, c0_) GF_M16(w_##l, x_##1h, c1_)               \
+  GF_M16(w_##h, x_##0l, c0_) GF_M16(w_##h, x_##1l, c1_)               \
+  GF_M16(w_##m, x_##0m, c0_) GF_M16(w_##m, x_##1m, c1_)               \
+  GF_M16(w_##m, x_##0h, c0_) GF_M16(w_##m, x_##1h, c1_)               \
+  GF_M16(w_##h, x_##0m, c0_) GF_M16(w_##h, x_##1m, c1_)               \
+  GF_M16(w_##h, x_##0h, c0_) GF_M16(w_##h, x_##1h, c1_)
+// X fragments of k step t_ (both node tiles, three planes) into register set s_
+#define GF_LDX(s_, xa_, t_)                                                                   \
+  {                                                                                           \
+    const int c_ = (((4 * (t_) + q4) ^ swz) & 7) << 3;                                        \
+    s_##0h = *reinterpret_cast<const bf16x8*>((xa_) + c_);                                    \
+    s_##0m = *reinterpret_cast<const bf16x8*>((xa_) + PLN + c_);                              \
+    s_##0l = *reinterpret_cast<const bf16x8*>((xa_) + 2 * PLN + c_);                          \
+    s_##1h = *reinterpret_cast<const bf16x8*>((xa_) + 16 * 64 + c_);                          \
+    s_##1m = *reinterpret_cast<const bf16x8*>((xa_) + 16 * 64 + PLN + c_);                    \
+    s_##1l = *reinterpret_cast<const bf16x8*>((xa_) + 16 * 64 + 2 * PLN + c_);                \
   }
+// W fragments of feature tile i_, k step t_ into register set s_
+#define GF_LDW(s_, wa_, i_, t_)                                                               \
+  {                                                                                           \
+    const int c_ = (((4 * (t_) + q4) ^ swz) & 7) << 3;                                        \
+    s_##h = *reinterpret_cast<const bf16x8*>((wa_) + (i_) * 16 * 64 + c_);                    \
+    s_##m = *reinterpret_cast<const bf16x8*>((wa_) + (i_) * 16 * 64 + WPLN + c_);             \
+    s_##l = *reinterpret_cast<const bf16x8*>((wa_) + (i_) * 16 * 64 + 2 * WPLN + c_);         \
+  }
+// 48 MFMAs of one 64x64 weight block: D^T[n][node] += sum_k W[n][k] X[node][k].  The fragments of
+// the next (feature tile, k step) are read while the MFMAs of the current one run.
 #define GF_MFMA_BLOCK(wb_, img_)                                                                   \
   {                                                                                                \
     const short* wa_ = (wb_) + wrow * 64;                                                          \
     const short* xa_ = (img_) + xrow * 64;                                                         \
-    bf16x8 awh_, awm_, awl_, axh_, axm_, axl_, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_;                 \
-    GF_FRAGS(wa_, xa_, 0, awh_, awm_, awl_, axh_, axm_, axl_)                                      \
-    GF_FRAGS(wa_, xa_, 1, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                      \
-    GF_MFMA6(awh_, awm_, awl_, axh_, axm_, axl_)                                                   \
-    GF_FRAGS(wa_, xa_, 2, awh_, awm_, awl_, axh_, axm_, axl_)                                      \
-    GF_MFMA6(bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                                   \
-    GF_FRAGS(wa_, xa_, 3, bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                      \
-    GF_MFMA6(awh_, awm_, awl_, axh_, axm_, axl_)                                                   \
-    GF_MFMA6(bwh_, bwm_, bwl_, bxh_, bxm_, bxl_)                                                   \
+    bf16x8 fxa0h, fxa0m, fxa0l, fxa1h, fxa1m, fxa1l, fxb0h, fxb0m, fxb0l, fxb1h, fxb1m, fxb1l;     \
+    bf16x8 fwah, fwam, fwal, fwbh, fwbm, fwbl;                                                     \
+    GF_LDX(fxa, xa_, 0)                                                                            \
+    GF_LDW(fwa, wa_, 0, 0)                                                                         \
+    GF_LDW(fwb, wa_, 1, 0)                                                                         \
+    GF_MM(acc00, acc01, fwa, fxa)                                                                  \
+    GF_LDW(fwa, wa_, 0, 1)                                                                         \
+    GF_LDX(fxb, xa_, 1)                                                                            \
+    GF_MM(acc10, acc11, fwb, fxa)                                                                  \
+    GF_LDW(fwb, wa_, 1, 1)                                                                         \
+    GF_MM(acc00, acc01, fwa, fxb)                                                                  \
+    GF_MM(acc10, acc11, fwb, fxb)                                                                  \
   }
-// accumulators seeded with post_mp.5's bias of column group cg_
-#define GF_ACC_B5(cg_)                                                                      \
-  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                        \
-    const float4 bc = *reinterpret_cast<const float4*>(cst + 256 + 64 * (cg_) + fq_e + 8 * rg); \
-    acc[4 * rg] = bc.x;                                                                     \
-    acc[4 * rg + 1] = bc.y;                                                                 \
-    acc[4 * rg + 2] = bc.z;                                                                 \
-    acc[4 * rg + 3] = bc.w;                                                                 \
+// the four accumulators seeded with a per-feature vector v_ (+ a per-node scalar times a vector)
+#define GF_SEED1(v_)                                                                       \
+  {                                                                                        \
+    const float4 a_ = *reinterpret_cast<const float4*>((v_) + fq_e);                       \
+    const float4 b_ = *reinterpret_cast<const float4*>((v_) + fq_e + 16);                  \
+    acc00 = f32x4{a_.x, a_.y, a_.z, a_.w};                                                 \
+    acc01 = acc00;                                                                         \
+    acc10 = f32x4{b_.x, b_.y, b_.z, b_.w};                                                 \
+    acc11 = acc10;                                                                         \
   }
-// write 4 consecutive features (fb_ .. fb_+3) of node xrow as bf16 planes into image img_
-#define GF_PUT4(img_, fb_, v0_, v1_, v2_, v3_)                                           \
+#define GF_SEED2(s0_, s1_, u_, v_)                                                         \
+  {                                                                                        \
+    const float4 ua_ = *reinterpret_cast<const float4*>((u_) + fq_e);                      \
+    const float4 ub_ = *reinterpret_cast<const float4*>((u_) + fq_e + 16);                 \
+    const float4 va_ = *reinterpret_cast<const float4*>((v_) + fq_e);                      \
+    const float4 vb_ = *reinterpret_cast<const float4*>((v_) + fq_e + 16);                 \
+    acc00 = f32x4{(s0_) * ua_.x + va_.x, (s0_) * ua_.y + va_.y, (s0_) * ua_.z + va_.z, (s0_) * ua_.w + va_.w}; \
+    acc01 = f32x4{(s1_) * ua_.x + va_.x, (s1_) * ua_.y + va_.y, (s1_) * ua_.z + va_.z, (s1_) * ua_.w + va_.w}; \
+    acc10 = f32x4{(s0_) * ub_.x + vb_.x, (s0_) * ub_.y + vb_.y, (s0_) * ub_.z + vb_.z, (s0_) * ub_.w + vb_.w}; \
+    acc11 = f32x4{(s1_) * ub_.x + vb_.x, (s1_) * ub_.y + vb_.y, (s1_) * ub_.z + vb_.z, (s1_) * ub_.w + vb_.w}; \
+  }
+// write 4 consecutive features (fb_ .. fb_+3) of node node_ as bf16 planes into image img_
+#define GF_PUT4(img_, node_, fb_, v0_, v1_, v2_, v3_)                                    \
   {                                                                                      \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                               \
     split2_bf16x3(v0_, v1_, h0_, m0_, l0_);                                                  \
     split2_bf16x3(v2_, v3_, h1_, m1_, l1_);                                                  \
-    short* d_ = (img_) + gf_pidx(xrow_e, (fb_));                                           \
+    short* d_ = (img_) + gf_pidx((node_), (fb_));                                          \
     *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                \
     *reinterpret_cast<uint2*>(d_ + PLN) = make_uint2(m0_, m1_);                          \
     *reinterpret_cast<uint2*>(d_ + 2 * PLN) = make_uint2(l0_, l1_);                      \
   }
+// epilogue of a 64-wide block: activation + bf16 planes of the four accumulator tiles into img_
+#define GF_EPI(img_, ACT_)                                                               \
+  {                                                                                      \
+    GF_PUT4(img_, xrow_e, fq_e, ACT_(acc00[0]), ACT_(acc00[1]), ACT_(acc00[2]), ACT_(acc00[3]))            \
+    GF_PUT4(img_, xrow_e + 16, fq_e, ACT_(acc01[0]), ACT_(acc01[1]), ACT_(acc01[2]), ACT_(acc01[3]))       \
+    GF_PUT4(img_, xrow_e, fq_e + 16, ACT_(acc10[0]), ACT_(acc10[1]), ACT_(acc10[2]), ACT_(acc10[3]))       \
+    GF_PUT4(img_, xrow_e + 16, fq_e + 16, ACT_(acc11[0]), ACT_(acc11[1]), ACT_(acc11[2]), ACT_(acc11[3]))  \
+  }
+#define GF_RELU(v_) ((v_) > 0.f ? (v_) : 0.f)
+#define GF_LEAKY01(v_) ((v_) > 0.f ? (v_) : 0.1f * (v_))
 
 __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
@@ -207,10 +250,11 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
-  const int xrow = 32 * wm + (lane & 31);   // this lane's node (B operand, epilogues)
-  const int wrow = 32 * wn + (lane & 31);   // this lane's weight row (A operand)
-  const int swz = (lane >> 1) & 7;          // chunk swizzle of both rows: (row >> 1) & 7 with row = 32 j + (lane & 31)
-  const int fq = 32 * wn + 4 * (lane >> 5);      // first output feature of register quad 0 (+8 per quad)
+  const int q4 = lane >> 4;                 // k chunk within a 32-deep step / feature quad of a 16x16 tile
+  const int xrow = 32 * wm + (lane & 15);   // this lane's node of node tile 0 (+16: tile 1) (B operand, epilogues)
+  const int wrow = 32 * wn + (lane & 15);   // this lane's weight row of feature tile 0 (+16: tile 1) (A operand)
+  const int swz = (lane >> 1) & 7;          // chunk swizzle of all four rows: (row >> 1) & 7 with row = 16 j + (lane & 15)
+  const int fq = 32 * wn + 4 * q4;          // first output feature of feature tile 0 (+16: tile 1)
   const int Q = g.Q;
   const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
   int64_t item = blockIdx.x;
@@ -354,21 +398,13 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     }
     __syncthreads();
 
-    f32x16 acc;
-    const float4 sx = srow[xrow];          // (a0, b0, a1, x) of this lane's node
+    f32x4 acc00, acc01, acc10, acc11;      // [feature tile][node tile]
+    const float4 sx0 = srow[xrow], sx1 = srow[xrow + 16];   // (a0, b0, a1, x) of this lane's two nodes
     int xrow_e = xrow, fq_e = fq;          // epilogue addressing, not hoisted out of the item loop
     asm volatile("" : "+v"(xrow_e), "+v"(fq_e));
     // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) -> I1 -----------------------------------
     // (the affine terms seed the accumulators, so an epilogue is activation + split only)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 uc = *reinterpret_cast<const float4*>(cst + fq_e + 8 * rg);
-      const float4 dc = *reinterpret_cast<const float4*>(cst + 64 + fq_e + 8 * rg);
-      acc[4 * rg] = sx.z * uc.x + dc.x;
-      acc[4 * rg + 1] = sx.z * uc.y + dc.y;
-      acc[4 * rg + 2] = sx.z * uc.z + dc.z;
-      acc[4 * rg + 3] = sx.z * uc.w + dc.w;
-    }
+    GF_SEED2(sx0.z, sx1.z, cst, cst + 64)
     GF_MFMA_BLOCK(WB0, I1)
     GF_WSTORE(WB1)                         // block 1 (staging is dead)
     GF_WLOAD(g.wps, 64, 128, 0, 0)
@@ -377,27 +413,10 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     GF_MFMA_BLOCK(WB1, I0)
     GF_WSTORE(WB0)                         // block 2
     GF_WLOAD(g.wps, 64, 128, 0, 64)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int fb = fq_e + 8 * rg;
-      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
-      v0 = v0 > 0.f ? v0 : 0.f;
-      v1 = v1 > 0.f ? v1 : 0.f;
-      v2 = v2 > 0.f ? v2 : 0.f;
-      v3 = v3 > 0.f ? v3 : 0.f;
-      GF_PUT4(I1, fb, v0, v1, v2, v3)
-    }
+    GF_EPI(I1, GF_RELU)
     __syncthreads();
     // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) -> I0 ---------------------------
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 tc4 = *reinterpret_cast<const float4*>(cst + 128 + fq_e + 8 * rg);
-      const float4 zc4 = *reinterpret_cast<const float4*>(cst + 768 + fq_e + 8 * rg);
-      acc[4 * rg] = sx.w * tc4.x + zc4.x;
-      acc[4 * rg + 1] = sx.w * tc4.y + zc4.y;
-      acc[4 * rg + 2] = sx.w * tc4.z + zc4.z;
-      acc[4 * rg + 3] = sx.w * tc4.w + zc4.w;
-    }
+    GF_SEED2(sx0.w, sx1.w, cst + 128, cst + 768)
     GF_MFMA_BLOCK(WB0, I0)
     GF_WSTORE(WB1)                         // block 3
     GF_WLOAD(g.w3s, 64, 64, 0, 0)
@@ -406,76 +425,59 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     GF_MFMA_BLOCK(WB1, I1)
     GF_WSTORE(WB0)                         // block 4
     GF_WLOAD(g.w5s, 256, 64, 0, 0)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int fb = fq_e + 8 * rg;
-      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
-      v0 = v0 > 0.f ? v0 : 0.1f * v0;
-      v1 = v1 > 0.f ? v1 : 0.1f * v1;
-      v2 = v2 > 0.f ? v2 : 0.1f * v2;
-      v3 = v3 > 0.f ? v3 : 0.1f * v3;
-      GF_PUT4(I0, fb, v0, v1, v2, v3)
-    }
+    GF_EPI(I0, GF_LEAKY01)
     __syncthreads();
     // ---- block 4: y2 = relu(y1 W3 + b3) -> I1 ------------------------------------------------------
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 bc = *reinterpret_cast<const float4*>(cst + 192 + fq_e + 8 * rg);
-      acc[4 * rg] = bc.x;
-      acc[4 * rg + 1] = bc.y;
-      acc[4 * rg + 2] = bc.z;
-      acc[4 * rg + 3] = bc.w;
-    }
+    GF_SEED1(cst + 192)
     GF_MFMA_BLOCK(WB0, I0)
     GF_WSTORE(WB1)                         // block 5 (W5 column group 0)
     GF_WLOAD(g.w5s, 256, 64, 64, 0)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int fb = fq_e + 8 * rg;
-      float v0 = acc[4 * rg], v1 = acc[4 * rg + 1], v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];
-      v0 = v0 > 0.f ? v0 : 0.f;
-      v1 = v1 > 0.f ? v1 : 0.f;
-      v2 = v2 > 0.f ? v2 : 0.f;
-      v3 = v3 > 0.f ? v3 : 0.f;
-      GF_PUT4(I1, fb, v0, v1, v2, v3)
-    }
+    GF_EPI(I1, GF_RELU)
     __syncthreads();
     // ---- blocks 5..8: head partial  sum_c relu(y2 W5 + b5)[c] * w7[c], 4 column groups of 64 -------
-    float part = 0.f;
+    float part0 = 0.f, part1 = 0.f;        // this lane's two nodes
 #define GF_HEAD(cg_)                                                                        \
-  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                        \
-    const int fb = 64 * (cg_) + fq_e + 8 * rg;                                                \
-    const float4 wv = *reinterpret_cast<const float4*>(cst + 512 + fb);                     \
-    const float v0 = acc[4 * rg], v1 = acc[4 * rg + 1];                                     \
-    const float v2 = acc[4 * rg + 2], v3 = acc[4 * rg + 3];                                 \
-    part += (v0 > 0.f ? v0 : 0.f) * wv.x + (v1 > 0.f ? v1 : 0.f) * wv.y +                   \
-            (v2 > 0.f ? v2 : 0.f) * wv.z + (v3 > 0.f ? v3 : 0.f) * wv.w;                    \
+  {                                                                                         \
+    const float4 wa_ = *reinterpret_cast<const float4*>(cst + 512 + 64 * (cg_) + fq_e);      \
+    const float4 wb_ = *reinterpret_cast<const float4*>(cst + 512 + 64 * (cg_) + fq_e + 16); \
+    part0 += GF_RELU(acc00[0]) * wa_.x + GF_RELU(acc00[1]) * wa_.y + GF_RELU(acc00[2]) * wa_.z + \
+             GF_RELU(acc00[3]) * wa_.w + GF_RELU(acc10[0]) * wb_.x + GF_RELU(acc10[1]) * wb_.y + \
+             GF_RELU(acc10[2]) * wb_.z + GF_RELU(acc10[3]) * wb_.w;                           \
+    part1 += GF_RELU(acc01[0]) * wa_.x + GF_RELU(acc01[1]) * wa_.y + GF_RELU(acc01[2]) * wa_.z + \
+             GF_RELU(acc01[3]) * wa_.w + GF_RELU(acc11[0]) * wb_.x + GF_RELU(acc11[1]) * wb_.y + \
+             GF_RELU(acc11[2]) * wb_.z + GF_RELU(acc11[3]) * wb_.w;                           \
   }
-    GF_ACC_B5(0)
+    GF_SEED1(cst + 256)
     GF_MFMA_BLOCK(WB1, I1)
     GF_WSTORE(WB0)                         // block 6
     GF_WLOAD(g.w5s, 256, 64, 128, 0)
     GF_HEAD(0)
     __syncthreads();
-    GF_ACC_B5(1)
+    GF_SEED1(cst + 256 + 64)
     GF_MFMA_BLOCK(WB0, I1)
     GF_WSTORE(WB1)                         // block 7
     GF_WLOAD(g.w5s, 256, 64, 192, 0)
     GF_HEAD(1)
     __syncthreads();
-    GF_ACC_B5(2)
+    GF_SEED1(cst + 256 + 128)
     GF_MFMA_BLOCK(WB1, I1)
     GF_WSTORE(WB0)                         // block 8
     GF_WLOAD(g.w1s, 64, 128, 0, 0)         // block 0 of the next item
     GF_HEAD(2)
     __syncthreads();
-    GF_ACC_B5(3)
+    GF_SEED1(cst + 256 + 192)
     GF_MFMA_BLOCK(WB0, I1)
     GF_HEAD(3)
 #undef GF_HEAD
-    // fold the two lane halves (features 4h..4h+3 of every quad), then the two feature groups wn
-    part += __shfl_xor(part, 32, 64);
-    if (lane < 32) red[wn * GT + xrow] = part;
+    // fold the four lane quarters (features 4 q4 .. 4 q4 + 3 of every tile), then the two feature groups wn
+    part0 += __shfl_xor(part0, 16, 64);
+    part1 += __shfl_xor(part1, 16, 64);
+    part0 += __shfl_xor(part0, 32, 64);
+    part1 += __shfl_xor(part1, 32, 64);
+    if (lane < 16) {
+      red[wn * GT + xrow] = part0;
+      red[wn * GT + xrow + 16] = part1;
+    }
     __syncthreads();
     if (tid < nrows) g.out[(n0 + tid) * Q + q] = red[tid] + red[GT + tid] + g.b7 + srow[tid].w;
     if (!has_next) break;
@@ -489,11 +491,17 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 
 #undef GF_WLOAD
 #undef GF_WSTORE
-#undef GF_MFMA6
+#undef GF_M16
+#undef GF_MM
+#undef GF_LDX
+#undef GF_LDW
 #undef GF_MFMA_BLOCK
-#undef GF_FRAGS
-#undef GF_ACC_B5
+#undef GF_SEED1
+#undef GF_SEED2
 #undef GF_PUT4
+#undef GF_EPI
+#undef GF_RELU
+#undef GF_LEAKY01
 
 }  // namespace desco
 

@@ -609,7 +609,7 @@ def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: f
     dt = torch.empty((B, hid), device=t.device, dtype=torch.float32)
     dqh = torch.empty((Q, hid), device=t.device, dtype=torch.float32)
     dw2 = torch.empty((hid,), device=t.device, dtype=torch.float32)
-    ws = torch.empty((256 * (Q + 1) * hid,), device=t.device, dtype=torch.float32)
+    ws = torch.empty((1024 * (Q + 1) * hid,), device=t.device, dtype=torch.float32)
     tp, ldt = _rows(t, "t")
     qp, ldq = _rows(qh, "qh")
     L = _lib.lib()
