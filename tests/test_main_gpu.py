@@ -63,3 +63,32 @@ def test_driver_trains_and_writes_reference_artifacts(tmp_path):
                        gossip_checkpoint=str(tmp_path / "ckpt_g" / "last.ckpt"),
                        atlas_query_ids=STANDARD_QUERY_IDS, output_dir=str(tmp_path / "out2"), data_root=root)
     assert len(rep2["graphlet_mae_neighborhood"]) == 3
+
+
+def test_driver_with_two_gpus_starts_its_own_ranks(tmp_path):
+    """``main.py --gpu 0 1`` (reference: main.py:242-255 hands the devices to a "ddp" Trainer): the
+    driver starts one process per GPU itself, trains both stages data parallel, shards the predict
+    passes, and rank 0 writes the reference's artefacts.  (DESCO_SHARE_GPU=1: both ranks on the one
+    GPU of the test box, gloo.)"""
+    import subprocess
+    import sys
+    from helpers import golden_graphs
+    root = str(tmp_path / "data")
+    _write_tu(root, "TOY", golden_graphs(max_n=30))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DESCO_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(repo, "main.py"), "--gpu", "0", "1", "--data_root", root,
+           "--train_dataset", "TOY_train", "--valid_dataset", "TOY_val", "--test_dataset", "TOY_test",
+           "--neigh_epoch_num", "2", "--gossip_epoch_num", "1", "--gossip_dropout", "0.0",
+           "--neigh_batch_size", "32", "--gossip_batch_size", "2",
+           "--neigh_model_path", str(tmp_path / "ckpt_n"), "--gossip_model_path", str(tmp_path / "ckpt_g"),
+           "--train_neigh", "--train_gossip", "--test_gossip", "--output_dir", str(tmp_path / "out")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = tmp_path / "out"
+    for f in ["neighborhood_graphlet_TOY_test.csv", "gossip_graphlet_TOY_test.csv", "gossip_node_TOY_test_results.csv",
+              "analyze_results_TOY_test.txt", "graphlet_truth_TOY_test.csv"]:
+        assert (out / f).exists(), f
+    assert (tmp_path / "ckpt_n" / "last.ckpt").exists() and (tmp_path / "ckpt_g" / "last.ckpt").exists()
+    assert p.stdout.count("done") == 1            # only rank 0 reports
