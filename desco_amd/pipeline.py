@@ -67,6 +67,14 @@ class InferencePipeline:
             torch.cuda.set_device(device)      # the C ABI launches on the current device / stream
         self._graph = None
         self._graph_replay_rows = graph_replay_rows
+        self._empty = graphs.num_graphs == 0       # more ranks than graphs: this shard has nothing to do
+        if self._empty:
+            self.partition_backend = "none"
+            self.partition = NeighborhoodPartition(
+                np.zeros((0, 2), np.int64), np.zeros(0, bool), np.zeros(1, np.int32), np.zeros(0, np.int32),
+                np.zeros(1, np.int32), np.zeros(0, np.int32), depth, 0)
+            self.neigh_batches, self.gossip_batches, self.num_queries = [], [], None
+            return
         # canonical partition: built on the GPU (csrc/partition_dev.hip) unless the PyG quirk
         # emulation is requested or a graph exceeds the device builder's per-wave LDS workspace
         # (then the host C++ builder, same output)
@@ -139,7 +147,7 @@ class InferencePipeline:
         """One pass, launch mode chosen by shard size: small shards replay a hipGraph captured on
         the first call (the returned tensors are then the graph's static outputs, overwritten by
         the next ``step()``), large ones launch eagerly."""
-        if self.partition.num_rows >= self._graph_replay_rows or self.partition.num_neigh == 0:
+        if self._empty or self.partition.num_rows >= self._graph_replay_rows or self.partition.num_neigh == 0:
             return self.run(gossip)
         if self._graph is None or self._graph_gossip != gossip:
             self.capture(gossip)
@@ -164,6 +172,13 @@ class InferencePipeline:
     @torch.no_grad()
     def run(self, gossip: bool = True) -> Dict[str, torch.Tensor]:
         nm, gm = self.nm, self.gm
+        if self._empty:
+            Q = len(nm.queries_flat)
+            z = torch.zeros((0, Q), device=self.device)
+            out = {"neigh_count": z, "graph_neigh_count": z.clone()}
+            if gossip:
+                out.update({"x": z.clone(), "node_count": z.clone(), "graph_gossip_count": z.clone()})
+            return out
         counts = [nm.graph_to_count(b) for b in self.neigh_batches]            # main.py:296-301
         if not counts:      # no node has a non-empty canonical neighborhood
             counts = [torch.zeros((0, len(nm.queries_flat)), device=self.device)]

@@ -35,6 +35,16 @@ def main():
             res.update({k: v.cpu() for k, v in full.items()})
         else:
             assert full is None
+    elif mode == "tiny":
+        # fewer graphs than ranks: one rank's shard is empty and must still take part in the gather
+        from desco_amd.pipeline import InferencePipeline
+        nm, gm, qids, queries = C.models(dev)
+        gs = GraphSet.from_edge_lists(C.mixed_graphs()[:1])
+        pipe = InferencePipeline(nm, gm, gs, depth=4, device=dev)
+        full = pipe.gather(pipe.run(), node_level=True)
+        res = {"range": pipe.graph_range}
+        if rank == 0:
+            res.update({k: v.cpu() for k, v in full.items()})
     elif mode == "grads":
         from desco_amd.batch import GossipBatch, NeighborhoodBatch
         from desco_amd.partition import build_partition

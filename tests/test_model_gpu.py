@@ -137,6 +137,44 @@ def test_full_size_run_is_replica_invariant(setup):
         assert worst < 1e-5, (key, worst)
 
 
+@pytest.mark.parametrize("workload", ["syn_1827", "msrc_imdb"])
+def test_full_size_dense_workloads_are_shard_invariant(workload):
+    """BASELINE configs 3-5 at their full dataset size (Syn_1827-shaped: 1 827 graphs, 246 k nodes,
+    19 M neighborhood rows, 78 M directed neighborhood edges, neighborhoods of up to ~790 nodes;
+    MSRC-21 + IMDB-BINARY-shaped: 1 563 graphs): size-independent properties of the whole two-stage
+    pass -- everything finite, and the dataset processed as ONE shard equals the dataset processed
+    as two halves (different launches, tiles, row-budget blocks and pooling partials) per graph and
+    per node, compared in log space (the outputs are exponentials of fp32 logits)."""
+    from desco_amd import synthetic
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm = make_models(seed=0, gains=(0.8, 1.2))      # dense shapes: 2**logit must stay finite
+    qids, queries = standard_queries()
+    nm, gm = nm.to(DEV), gm.to(DEV)
+    nm.set_queries(qids)
+    full = synthetic.WORKLOADS[workload]()
+    G = full.num_graphs
+    whole = InferencePipeline(nm, gm, full, depth=4, device=DEV, rank=0, world=1).run()
+    part = whole["neigh_count"].shape[0]
+    print(f"[shape] {workload}: {G} graphs, {full.num_nodes} nodes, {part} neighborhoods")
+    halves = [InferencePipeline(nm, gm, full.subset(a, b), depth=4, device=DEV, rank=0, world=1,
+                                max_neigh_rows=3_000_000).run()
+              for a, b in ((0, G // 2), (G // 2, G))]
+    for key in ("graph_neigh_count", "graph_gossip_count", "node_count", "neigh_count"):
+        ref = whole[key]
+        got = torch.cat([h[key] for h in halves])
+        assert got.shape == ref.shape, key
+        assert torch.isfinite(ref).all() and torch.isfinite(got).all(), key
+        assert float(ref.abs().max()) > 1e-3 and float(ref.std()) > 0.0, key
+        # counts are 2**logit - 1 with logits up to ~31 here: compared where they are computed, in log
+        # space, with the tolerance every logit comparison of this suite uses (rtol = atol = 1e-4)
+        lg = lambda c: torch.sign(c) * torch.log2(1.0 + c.abs().double())          # noqa: E731
+        dev = (lg(got) - lg(ref)).abs()
+        worst = float((dev / (1.0 + lg(ref).abs())).max())
+        print(f"[property] {workload} {key}: whole vs two halves, worst log2-space deviation "
+              f"{float(dev.max()):.2e} (relative {worst:.2e}); max |count| {float(ref.abs().max()):.3e}")
+        assert worst < 1e-4, (key, worst)
+
+
 def test_gossip_conv_standalone_forward(setup):
     """GossipConv.forward as a stand-alone layer call (reference gnn_model.py:303-350) vs the
     formula in fp64."""

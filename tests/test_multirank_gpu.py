@@ -65,6 +65,17 @@ def test_two_rank_pipeline_equals_one_rank(tmp_path):
     assert float(one["graph_gossip_count"].abs().max()) > 1e-3
 
 
+def test_more_ranks_than_graphs(tmp_path):
+    from desco_amd.pipeline import InferencePipeline
+    r0, r1 = _run2("tiny", tmp_path)
+    assert sorted([r0["range"], r1["range"]]) in ([(0, 0), (0, 1)], [(0, 1), (1, 1)])
+    nm, gm, qids, queries = C.models(DEV)
+    gs = GraphSet.from_edge_lists(C.mixed_graphs()[:1])
+    one = InferencePipeline(nm, gm, gs, depth=4, device=DEV, rank=0, world=1).run()
+    for k in ("graph_gossip_count", "node_count", "neigh_count"):
+        torch.testing.assert_close(r0[k], one[k].cpu(), rtol=1e-5, atol=1e-5)
+
+
 def test_two_rank_gradients_equal_one_rank_union_batch(tmp_path):
     from desco_amd.batch import GossipBatch, NeighborhoodBatch
     from desco_amd.partition import build_partition
