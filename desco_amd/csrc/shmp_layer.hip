@@ -401,25 +401,21 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer_f32_kernel(ShmpArgs g) {
   (void)yb;
 
   // ---- this wave's first tile ---------------------------------------------------------------
-  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch) and its 4 MB L2.
-  // XCD x sweeps the x-th contiguous eighth of the tiles, its blocks side by side, so the 32 CUs of an
-  // XCD work on ~32 neighbouring tiles (2 MB of x) at any time and a neighborhood's rows -- the sources
-  // of all its tiles -- are fetched into ONE L2, once.  With the plain order (tile = block id, stride =
-  // grid) every XCD touched every neighborhood of the 256-tile window: on Syn_1827 shapes the gathers
-  // missed L2 (6.6 GB of fabric traffic per launch against 3.1 GB of x + out).  Speed only: any
+  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch) and its 4 MB L2,
+  // so a neighborhood's rows -- the sources of all its tiles -- should be gathered by ONE XCD.  Measured
+  // (profiles/r2_f_ab_xcd_order.log): +0.5 % on Syn_1827 / MSRC+IMDB shapes, 0 on COX2 shapes (the
+  // gathers are not what bounds the kernel); contiguous eighths per XCD were 8 % SLOWER on Syn shapes
+  // (the dataset is ordered by graph size: the XCD with the dense end finishes last).  Speed only: any
   // block -> XCD placement gives the same result.
-  int64_t tile, tend;
-  int tstride;
-  if ((gridDim.x & 7) == 0 && ntiles >= (int64_t)gridDim.x) {
-    const int64_t t8 = (ntiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7;
-    tile = xcd * t8 + (blockIdx.x >> 3);
-    tend = (xcd + 1) * t8 < ntiles ? (xcd + 1) * t8 : ntiles;
-    tstride = gridDim.x >> 3;
+  int64_t tile, tend = ntiles;
+  int tstride = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    // chunks of (grid / 8) consecutive tiles go round robin over the XCDs: XCD x works on the 32
+    // neighbouring tiles of chunk 8 j + x in sweep j (locality), heavy and light regions of the dataset
+    // are spread over all XCDs (balance)
+    tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   } else {
     tile = blockIdx.x;
-    tend = ntiles;
-    tstride = gridDim.x;
   }
   int64_t w0 = tile * (NW * WR) + wave * WR;               // first row of this wave (relative)
   if (tile >= tend || w0 >= g.num_rows) return;            // no barrier below: idle waves may leave
