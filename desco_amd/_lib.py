@@ -62,6 +62,8 @@ SIGNATURES = {
     "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp]),
     "desco_gemm_tn_workspace": (ctypes.c_size_t, [i64, i32, i32, POINTER(c_int)]),
     "desco_gemm_tn_f32": (c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, vp]),
+    "desco_linear_bwd_w_workspace": (ctypes.c_size_t, [i64, i32, i32]),
+    "desco_linear_bwd_w_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i32, vp, i64, vp, vp, vp]),
     "desco_colsum_f32": (c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),
     "desco_count_head_bwd_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, i64, i64, i32, vp, i64,

@@ -77,13 +77,20 @@ class Linear(torch.autograd.Function):
                 da1 = da[:, :k1]
             if need_a2:
                 da2 = da[:, k1:]
-        if ctx.needs_input_grad[2]:
-            dwt = torch.empty_like(wt)
-            ops.gemm_tn(a1, dz, out=dwt[:k1])
-            if ctx.has_a2:
-                ops.gemm_tn(a2, dz, out=dwt[k1:])
-        if ctx.has_bias and ctx.needs_input_grad[3]:
-            dbias = ops.colsum(dz)
+        want_b = ctx.has_bias and ctx.needs_input_grad[3]
+        fused_ok = (k1 % 64 == 0 and dz.shape[1] % 64 == 0 and (not ctx.has_a2 or a2.shape[1] % 64 == 0)
+                    and a1.shape[0] > 0)
+        if ctx.needs_input_grad[2] and fused_ok:
+            # weight and bias gradient in one pass over the rows (two launches instead of six)
+            dwt, dbias = ops.linear_bwd_w(a1, a2 if ctx.has_a2 else None, dz, want_b)
+        else:
+            if ctx.needs_input_grad[2]:
+                dwt = torch.empty_like(wt)
+                ops.gemm_tn(a1, dz, out=dwt[:k1])
+                if ctx.has_a2:
+                    ops.gemm_tn(a2, dz, out=dwt[k1:])
+            if want_b:
+                dbias = ops.colsum(dz)
         return da1, da2, dwt, dbias, None, None
 
 

@@ -66,6 +66,96 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(const float* __res
   }
 }
 
+// Weight AND bias gradient of one Linear in one pass over the M slabs (desco_linear_bwd_w_f32):
+//   partial[s][k0:k0+64][n0:n0+64] = sum over slab s of [A1 | A2][m,k]^T dZ[m,n]     (k tiles 0 .. K/64-1)
+//   partial[s][K][n0:n0+64]        = sum over slab s of dZ[m,n]                      (k tile K/64: the bias row)
+// A1 [M,k1] and A2 [M,k2] are the two operands of the forward GEMM (aggregate | x); the bias row rides
+// in the same workspace, so ONE reduce finishes dWt and db -- six launches of the step become two.
+__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
+    const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
+    const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
+    float* __restrict__ partial) {
+  __shared__ float lds[2 * TMC * 64];
+  float* As = lds;              // [32 m][64 k]
+  float* Bs = lds + TMC * 64;   // [32 m][64 n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
+  const int64_t m_beg = (int64_t)blockIdx.z * slab;
+  const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
+  const int64_t rows = (int64_t)K + 1;                      // partial rows per slab (K weight rows + bias)
+  if (k0 >= K) {
+    // bias row: column sums of the dZ tile over the slab (16 row groups x float4, fixed fold order)
+    const int rsub = tid >> 4, c4 = 4 * (tid & 15);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t m = m_beg + rsub; m < m_end; m += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(b + m * ldb + n0 + c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* red = lds;                                       // [16][64]
+    *reinterpret_cast<float4*>(red + rsub * 64 + c4) = s;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+      partial[((int64_t)blockIdx.z * rows + K) * N + n0 + tid] = t;
+    }
+    return;
+  }
+  const float* a = k0 < k1 ? a1 + k0 : a2 + (k0 - k1);
+  const int64_t lda = k0 < k1 ? lda1 : lda2;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int srow = tid >> 4, sc4 = tid & 15;
+  for (int64_t m0 = m_beg; m0 < m_end; m0 += TMC) {
+    float4 va0, va1, vb0, vb1;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ra = m0 + srow, rb = m0 + srow + 16;
+    va0 = ra < m_end ? *reinterpret_cast<const float4*>(a + ra * lda + 4 * sc4) : zero;
+    va1 = rb < m_end ? *reinterpret_cast<const float4*>(a + rb * lda + 4 * sc4) : zero;
+    vb0 = ra < m_end ? *reinterpret_cast<const float4*>(b + ra * ldb + n0 + 4 * sc4) : zero;
+    vb1 = rb < m_end ? *reinterpret_cast<const float4*>(b + rb * ldb + n0 + 4 * sc4) : zero;
+    __syncthreads();   // previous chunk consumed
+    *reinterpret_cast<float4*>(As + srow * 64 + 4 * sc4) = va0;
+    *reinterpret_cast<float4*>(As + (srow + 16) * 64 + 4 * sc4) = va1;
+    *reinterpret_cast<float4*>(Bs + srow * 64 + 4 * sc4) = vb0;
+    *reinterpret_cast<float4*>(Bs + (srow + 16) * 64 + 4 * sc4) = vb1;
+    __syncthreads();
+    const float* as = As + (lane >> 5) * 64 + wr * 32 + (lane & 31);
+    const float* bs = Bs + (lane >> 5) * 64 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int mm = 0; mm < TMC / 2; ++mm)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * mm * 64], bs[2 * mm * 64], acc, 0, 0, 0);
+  }
+  float* out = partial + ((int64_t)blockIdx.z * rows + k0) * N + n0;
+  const int col = wc * 32 + (lane & 31);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    out[(int64_t)row * N + col] = acc[reg];
+  }
+}
+
+// dwt[k][n] = sum_s partial[s][k][n] (k < K), dbias[n] = sum_s partial[s][K][n]   (fixed order)
+__global__ __launch_bounds__(256) void linear_bwd_w_reduce_kernel(const float* __restrict__ partial, int K,
+                                                                  int N, int splits,
+                                                                  float* __restrict__ dwt, int64_t lddw,
+                                                                  float* __restrict__ dbias) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t count = (int64_t)(K + 1) * N;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * count + i];
+  const int64_t row = i / N, col = i % N;
+  if (row < K)
+    dwt[row * lddw + col] = s;
+  else if (dbias)
+    dbias[col] = s;
+}
+
 // out[i] (+)= sum_s partial[s][i]   (fixed order)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
                                                               int64_t count, int splits,
@@ -249,6 +339,42 @@ extern "C" int desco_gemm_tn_f32(const float* a, int64_t lda, const float* b, in
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                      workspace, count, splits, out, ldo, n, accumulate);
   return launch_status("desco_gemm_tn_f32");
+}
+
+// M slabs of desco_linear_bwd_w_f32 (the workspace holds splits * (k1 + k2 + 1) * n floats)
+static int linear_bwd_w_splits(int64_t m, int k, int n) {
+  const int64_t tiles = (int64_t)(k / TK + 1) * (n / TN);
+  int64_t splits = (1024 + tiles - 1) / tiles;
+  const int64_t max_splits = (m + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return (int)splits;
+}
+
+extern "C" size_t desco_linear_bwd_w_workspace(int64_t m, int k, int n) {
+  return sizeof(float) * (size_t)linear_bwd_w_splits(m, k, n) * (size_t)(k + 1) * (size_t)n;
+}
+
+extern "C" int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, const float* a2,
+                                      int64_t lda2, int k2, const float* dz, int64_t lddz, int64_t m,
+                                      int n, float* dwt, int64_t lddw, float* dbias, float* workspace,
+                                      desco_stream_t stream) {
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  const int k = k1 + k2;
+  if (!a1 || !dz || !dwt || !workspace || m < 0 || k1 <= 0 || k1 % TK || k2 < 0 || k2 % TK || n <= 0 ||
+      n % TN || (k2 > 0 && (!a2 || lda2 % 4 || mis16(a2))) || lda1 % 4 || lddz % 4 || mis16(a1) || mis16(dz))
+    return fail(DESCO_EINVAL, "desco_linear_bwd_w_f32: bad argument (k%64, n%64, 16-byte alignment)");
+  const int splits = linear_bwd_w_splits(m, k, n);
+  int64_t slab = (m + splits - 1) / splits;
+  slab = (slab + TMC - 1) / TMC * TMC;
+  if (slab < TMC) slab = TMC;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(k / TK + 1, n / TN, splits), dim3(256), 0, st, a1,
+                     lda1, k1, a2, lda2, dz, lddz, m, k, n, slab, workspace);
+  const int64_t count = (int64_t)(k + 1) * n;
+  hipLaunchKernelGGL(linear_bwd_w_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                     workspace, k, n, splits, dwt, lddw, dbias);
+  return launch_status("desco_linear_bwd_w_f32");
 }
 
 extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out,

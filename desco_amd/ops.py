@@ -572,6 +572,26 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def linear_bwd_w(a1: torch.Tensor, a2: Optional[torch.Tensor], dz: torch.Tensor, want_bias: bool):
+    """(dwt [(k1+k2), n], dbias [n] or None) of c = act([a1 | a2] @ wt + bias) given dz: weight and
+    bias gradient in two launches (desco_linear_bwd_w_f32)."""
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = dz.shape[1]
+    dwt = torch.empty((k1 + k2, n), device=dz.device, dtype=torch.float32)
+    dbias = torch.empty((n,), device=dz.device, dtype=torch.float32) if want_bias else None
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    zp, ldz = _rows(dz, "dz")
+    L = _lib.lib()
+    nbytes = L.desco_linear_bwd_w_workspace(m, k1 + k2, n)
+    ws = torch.empty((max(nbytes // 4, 1),), device=dz.device, dtype=torch.float32)
+    with _Timed("linear_bwd_w_kernel", 2.0 * m * (k1 + k2) * n, 4.0 * (m * (k1 + k2) + 2 * m * n)):
+        _lib.check(L.desco_linear_bwd_w_f32(a1p, lda1, k1, a2p, lda2, k2, zp, ldz, m, n, _dev(dwt, "dwt"), n,
+                                            _opt(dbias, "dbias"), _dev(ws, "ws"), _stream()), "linear_bwd_w")
+    return dwt, dbias
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
     """out[n] (+)= sum_m x[m, n]  (bias gradient)."""
     m, n = x.shape

@@ -355,6 +355,16 @@ int desco_gemm_tn_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
                       int n, float* out, int64_t ldo, int accumulate, float* workspace,
                       desco_stream_t stream);
 
+/* weight AND bias gradient of one Linear c = act([a1 | a2] wt + bias) in two launches (partials over M
+ * slabs + one fixed-order reduce): dwt[k1+k2, n] = [a1 | a2]^T dz, dbias[n] = sum_m dz[m, n] (dbias may be
+ * NULL; a2 may be NULL with k2 = 0).  k1 % 64 == k2 % 64 == n % 64 == 0.  Replaces two desco_gemm_tn_f32
+ * and one desco_colsum_f32 call (six launches) of the training step.  workspace:
+ * desco_linear_bwd_w_workspace(m, k1 + k2, n) bytes. */
+size_t desco_linear_bwd_w_workspace(int64_t m, int k, int n);
+int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+                           const float* dz, int64_t lddz, int64_t m, int n, float* dwt, int64_t lddw,
+                           float* dbias, float* workspace, desco_stream_t stream);
+
 /* bias gradient: out[n] (+)= sum_m x[m, n];  workspace: 512 * n floats */
 int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out, int accumulate,
                      float* workspace, desco_stream_t stream);

@@ -225,6 +225,29 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
 
+@pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (300, 256, 64, 64), (5000, 128, 64, 64), (70001, 576, 0, 576),
+                                       (4097, 64, 0, 256)])
+def test_linear_bwd_w_fused_weight_and_bias_gradient(m, k1, k2, n):
+    """desco_linear_bwd_w_f32: dWt = [A1 | A2]^T dZ and db = colsum(dZ) in one pass (strided operands as
+    the training path passes them: A1 is a column block of the wider aggregate tensor)."""
+    g = torch.Generator().manual_seed(m + k1 + n)
+    wide = torch.randn(m, k1 + 64, generator=g)
+    a1 = wide[:, :k1]
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    dz = torch.randn(m, n, generator=g)
+    A = a1 if a2 is None else torch.cat([a1, a2], 1)
+    ref_w = A.double().T @ dz.double()
+    ref_b = dz.double().sum(0)
+    dwt, db = ops.linear_bwd_w(wide.to(DEV)[:, :k1], None if a2 is None else a2.to(DEV), dz.to(DEV), True)
+    _close(dwt, ref_w, rtol=1e-4, atol=1e-3 * max(1.0, m ** 0.5 / 10))
+    _close(db, ref_b, rtol=1e-4, atol=1e-3 * max(1.0, m ** 0.5 / 10))
+    dwt2, none = ops.linear_bwd_w(wide.to(DEV)[:, :k1], None if a2 is None else a2.to(DEV), dz.to(DEV), False)
+    assert none is None and torch.equal(dwt2, dwt)          # deterministic, bias row optional
+    # same numbers as the separate entry points
+    sep = ops.gemm_tn(wide.to(DEV)[:, :k1], dz.to(DEV))
+    _close(dwt[:k1], sep.double().cpu(), rtol=1e-5, atol=1e-4 * max(1.0, m ** 0.5 / 10))
+
+
 @pytest.mark.parametrize("num_rows,seg_kind", [(1, "one"), (31, "tiny"), (32, "tiny"), (1000, "mixed"),
                                                (70001, "mixed"), (70000, "huge"), (4096, "single-rows")])
 def test_fused_pooling_equals_segment_sum(num_rows, seg_kind):
