@@ -27,7 +27,7 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, accelerator: str = "gpu", devices=None,
                  default_root_dir: str = ".", callbacks=None, strategy: Optional[str] = None,
                  grad_reduce: str = "mean", precision: str = "fp32", graph_capture: bool = False,
-                 num_buckets: int = 4, **unused):
+                 num_buckets: int = 4, verbose: bool = False, **unused):
         # precision: "fp32" | "bf16" (Lightning's "32" / "bf16-mixed" spellings accepted): matrix
         # products of the training step in fp32 or bf16 MFMA (desco_amd.autograd.set_precision)
         self.precision = precision
@@ -41,6 +41,7 @@ class Trainer:
         self.strategy = strategy
         self.grad_reduce = grad_reduce      # "mean" (neighborhood loss) or "sum" (gossip loss)
         self.num_buckets = num_buckets
+        self.verbose = verbose              # print the monitored validation loss per epoch (rank 0)
         self.device = D.local_device(devices, accelerator)
         if self.device.type == "cuda":
             # the C ABI launches on the CURRENT device / stream: bind this process to its GPU
@@ -172,6 +173,9 @@ class Trainer:
             else:
                 sched.step(val)
             self.history.append({"epoch": epoch, cfg["monitor"]: val, "lr": float(opt.param_groups[0]["lr"])})
+            if self._rank0() and self.verbose:
+                print(f"epoch {epoch}: {cfg['monitor']} = {val:.6g}  lr = {float(opt.param_groups[0]['lr']):.3g}",
+                      flush=True)
             if ckpt is not None:
                 if self._rank0():
                     if ckpt.save_last:

@@ -103,7 +103,7 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
                                  save_last=True)
     neigh_trainer = Trainer(max_epochs=args_neighborhood.epoch_num, accelerator="gpu", devices=devices,
                             default_root_dir=args_neighborhood.model_path, callbacks=[neigh_ckpt],
-                            strategy=strategy, grad_reduce="mean",
+                            strategy=strategy, grad_reduce="mean", verbose=True,
                             precision=getattr(args_opt, "precision", "fp32"),
                             graph_capture=getattr(args_opt, "graph_capture", False))
     if train_neighborhood and neighborhood_checkpoint is None:
@@ -156,7 +156,7 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
         # the gossip loss is a SUM over nodes and queries (lightning_model.py:607): sum-reduce
         gossip_trainer = Trainer(max_epochs=args_gossip.epoch_num, accelerator="gpu", devices=devices,
                                  default_root_dir=args_gossip.model_path, callbacks=[gossip_ckpt],
-                                 strategy=strategy, grad_reduce="sum",
+                                 strategy=strategy, grad_reduce="sum", verbose=True,
                                  precision=getattr(args_opt, "precision", "fp32"))
         gossip_model.to(gossip_trainer.device)
         gossip_model.set_query_emb(neigh_model.get_query_emb())

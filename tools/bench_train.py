@@ -29,6 +29,8 @@ def main():
                     help="capture each batch's step (forward, backward, Adam) in a hipGraph and time replays "
                          "(what Trainer(graph_capture=True) does)")
     ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event breakdown of the timed steps")
+    ap.add_argument("--json", default=None, help="also write the neighborhood-step result (with the dominant "
+                    "kernel's roofline when --profile) to this file")
     args = ap.parse_args()
     from desco_amd import autograd as AG
     AG.set_precision(args.precision)
@@ -96,6 +98,37 @@ def main():
         print(f"profiled kernel time {tot / (len(batches) - 2):.1f} ms/step:")
         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]:
             print(f"   {k:32s} {v['calls'] // (len(batches) - 2):4d} launches/step {v['ms'] / (len(batches) - 2):7.2f} ms/step")
+    if args.json:
+        import json
+        res = {"metric": "neighborhoods/s (neighborhood-model training step: forward, backward, Adam)",
+               "value": n / dt, "unit": "neighborhoods/s", "ms_per_step": 1e3 * dt / (len(batches) - 2),
+               "rows_per_s": rows / dt, "steps": len(batches) - 2, "dtype": "f32" if args.precision == "fp32" else "bf16 products, fp32 accumulate",
+               "data": "synthetic",
+               "config": {"workload": f"{args.workload}-shaped synthetic, first {gs.num_graphs} graphs, batch {args.batch} "
+                                      f"neighborhoods, 29 queries, surrogate labels, Adam (torch)",
+                          "launch_mode": "hipGraph replay per batch" if args.graph else "eager launches",
+                          "rows_per_step": rows / (len(batches) - 2)}}
+        if args.profile:
+            tot = sum(v["ms"] for v in summ.values())
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            peak = {"gemm_f32_kernel": bench.PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": bench.PEAK_F32_MFMA_TFLOPS,
+                    "gemm_tn_partial_kernel": bench.PEAK_F32_MFMA_TFLOPS,
+                    "gemm_bf16_kernel": bench.PEAK_BF16_MFMA_TFLOPS}.get(name)
+            if peak:
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": ach / peak, "launches": d["calls"], "share_of_kernel_time": d["ms"] / tot,
+                                   "traffic": None}
+            else:
+                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                res["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": bench.PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": ach / bench.PEAK_HBM_GBS, "launches": d["calls"],
+                                   "share_of_kernel_time": d["ms"] / tot, "traffic": None}
+            res["kernels"] = {k: {"launches_per_step": v["calls"] // (len(batches) - 2),
+                                  "ms_per_step": round(v["ms"] / (len(batches) - 2), 3)}
+                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        with open(args.json, "w") as f:
+            json.dump(res, f, indent=1)
     mode = ", hipGraph replay" if args.graph else ""
     print(f"neighborhood training ({args.workload}-shaped, batch {args.batch}, {args.precision}{mode}): {len(batches) - 2} steps, "
           f"{n / dt:.0f} neighborhoods/s, {rows / dt / 1e6:.2f} M rows/s, {1e3 * dt / (len(batches) - 2):.1f} ms/step")
