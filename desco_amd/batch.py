@@ -96,31 +96,39 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def _seg_ptr_device(self):
         return self.count_ptr
 
-    def pool_index(self):
+    def pool_index(self, tile_rows: Optional[int] = None):
         """(pool_bits, pool_slot, num_slots) of the fused pooling (desco_shmp_layer_pool_bf16x6_f32):
-        per 32-row tile of the count rows, the bitmap of rows that END a neighborhood and the first
-        partial slot of the tile (a tile uses one slot per neighborhood that has a row in it)."""
-        if getattr(self, "_pool_index", None) is None:
+        per wave tile (``tile_rows`` = 16 or 32 count rows; default: what the library's layer kernel
+        uses), the bitmap of rows that END a neighborhood and the first partial slot of the tile (a
+        tile uses one slot per neighborhood that has a row in it)."""
+        if tile_rows is None:
+            from . import ops
+            tile_rows = ops.pool_tile_rows()
+        if tile_rows not in (16, 32):
+            raise ValueError("tile_rows must be 16 or 32")
+        cache = self.__dict__.setdefault("_pool_index", {})
+        if tile_rows not in cache:
+            TR, sh = tile_rows, 4 if tile_rows == 16 else 5
             cp = self.part.count_ptr.astype(np.int64)
             nc = int(cp[-1])
             if (np.diff(cp) <= 0).any():
                 raise ValueError("fused pooling needs at least one count row per neighborhood")
-            nt = (nc + 31) // 32
+            nt = (nc + TR - 1) // TR
             ends = cp[1:] - 1
             bits = np.zeros(nt, dtype=np.uint32)
-            np.bitwise_or.at(bits, ends >> 5, (np.uint32(1) << (ends & 31).astype(np.uint32)))
+            np.bitwise_or.at(bits, ends >> sh, (np.uint32(1) << (ends & (TR - 1)).astype(np.uint32)))
             pop = np.zeros(nt, dtype=np.int64)
-            np.add.at(pop, ends >> 5, 1)
-            last_row = np.minimum(32 * np.arange(nt, dtype=np.int64) + 31, nc - 1)
-            carry = ((bits >> (last_row & 31).astype(np.uint32)) & 1) == 0    # a segment runs on into the next tile
+            np.add.at(pop, ends >> sh, 1)
+            last_row = np.minimum(TR * np.arange(nt, dtype=np.int64) + TR - 1, nc - 1)
+            carry = ((bits >> (last_row & (TR - 1)).astype(np.uint32)) & 1) == 0    # a segment runs on into the next tile
             nseg = pop + carry
             slot = np.concatenate([[0], np.cumsum(nseg)])
             if slot[-1] >= 2 ** 31:
                 raise ValueError("too many pooling slots for int32")
             dev = self.device
-            self._pool_index = (torch.from_numpy(bits.view(np.int32)).to(dev),
+            cache[tile_rows] = (torch.from_numpy(bits.view(np.int32)).to(dev),
                                 torch.from_numpy(slot[:-1].astype(np.int32)).to(dev), int(slot[-1]))
-        return self._pool_index
+        return cache[tile_rows]
 
     # PyG-style views -----------------------------------------------------------------------
     @property

@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
 }
 
 // Second half of the fused pooling (desco_shmp_layer_pool_bf16x6_f32): the layer kernel left one
-// partial row per (32-row tile, segment) -- tile t's partials at slots slot_base[t] + k, k = the
+// partial row per (wave tile, segment) -- tile t's partials at slots slot_base[t] + k, k = the
 // number of segment ends in the tile before the segment's first row there.  A 16-lane group
 // (float4 per lane) owns one segment and adds its partials in tile order (a COX2-sized segment spans
-// 1-2 tiles, a 600-row Syn segment 19-20): fixed order, no atomics.
+// 1-3 tiles, a 600-row Syn segment 38-39): fixed order, no atomics.
 __global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part,
                                                           const uint32_t* __restrict__ bits,
                                                           const int32_t* __restrict__ slot_base,
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restric
                                                           int64_t num_seg,
                                                           const float* __restrict__ extra,
                                                           int64_t ld_extra, float* __restrict__ out,
-                                                          int64_t ldo) {
+                                                          int64_t ldo, int tsh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * 4 + (lane >> 4);
   if (b >= num_seg) return;
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restric
   const float* pc = part + 4 * (lane & 15);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r1 > r0) {
-    const int t0 = r0 >> 5, t1 = (r1 - 1) >> 5;
+    const int t0 = r0 >> tsh, t1 = (r1 - 1) >> tsh;                 // tiles of 1 << tsh rows
     for (int t = t0; t <= t1; ++t) {
-      const int first = r0 > (t << 5) ? r0 - (t << 5) : 0;          // the segment's first row inside tile t
+      const int first = r0 > (t << tsh) ? r0 - (t << tsh) : 0;      // the segment's first row inside tile t
       const int k = __popc(bits[t] & ((1u << first) - 1u));
       const float4 v = *reinterpret_cast<const float4*>(pc + (int64_t)(slot_base[t] + k) * 64);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -542,16 +542,18 @@ extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,
 extern "C" int desco_pool_reduce_f32(const float* part, const uint32_t* pool_bits,
                                      const int32_t* pool_slot, const int32_t* seg_ptr, int64_t num_seg,
                                      const float* extra, int64_t ld_extra, float* out, int64_t ldo,
-                                     desco_stream_t stream) {
+                                     int tile_rows, desco_stream_t stream) {
   if (num_seg == 0) return 0;
   auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (tile_rows != 16 && tile_rows != 32)
+    return fail(DESCO_EINVAL, "desco_pool_reduce_f32: tile_rows must be desco_shmp_pool_tile_rows()");
   if (!part || !pool_bits || !pool_slot || !seg_ptr || !out || num_seg < 0 || ldo % 4 || !al16(part) ||
       !al16(out) || (extra && (ld_extra % 4 || !al16(extra))))
     return fail(DESCO_EINVAL, "desco_pool_reduce_f32: bad argument");
   const int64_t blocks = (num_seg + 15) / 16;
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_pool_reduce_f32: too many segments");
   hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, part,
-                     pool_bits, pool_slot, seg_ptr, num_seg, extra, ld_extra, out, ldo);
+                     pool_bits, pool_slot, seg_ptr, num_seg, extra, ld_extra, out, ldo, tile_rows == 16 ? 4 : 5);
   return launch_status("desco_pool_reduce_f32");
 }
 

@@ -1,0 +1,37 @@
+// Arguments of the fused SHMP layer kernels (shmp_layer.hip: 32-row wave tiles; shmp_layer16.hip: 16-row
+// wave tiles, 16 waves per CU).
+#pragma once
+#include <stdint.h>
+
+namespace desco {
+
+struct ShmpArgs {
+  const float* x;
+  int64_t ldx;
+  const int32_t* vrowptr;
+  const int32_t* vcol;
+  int64_t row0, num_rows;
+  int S, sm, st;
+  const float* wt;          // f32 mode: [(sm+1)*64][64]
+  const short* wplanes;     // x6 mode: [3][64 n][(sm+1)*64 k] bf16 planes (hi, mid, lo)
+  const float* bias;
+  const float* ytab;
+  int64_t ldy, ytab_row0;
+  float* out;
+  int64_t ldo;
+  float* out2;              // optional second copy of the output rows (row i - row0 of a [num_rows, *] view)
+  int64_t ldo2;
+  int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
+  float slope;
+  // fused pooling (global_add_pool of the produced rows, gnn_model.py:107), optional: see
+  // desco_shmp_layer_pool_bf16x6_f32 in desco_hip.h.  out may then be null (rows not stored).
+  const uint32_t* pool_bits;   // [ceil(rows / TR)] bit r of word t: row TR t + r is the last row of its segment
+  const int32_t* pool_slot;    // [ceil(rows / TR)] first partial slot of TR-row tile t
+  float* pool_part;            // [num slots][64] partial segment sums
+  int pool_rows;               // TR = 32 (shmp_layer.hip) or 16 (shmp_layer16.hip)
+};
+
+// 16-row-tile form (shmp_layer16.hip); returns false when the shape is not one it is built for
+bool shmp16_launch(const ShmpArgs& g, int cus, void* stream);
+
+}  // namespace desco

@@ -48,6 +48,7 @@
 //         32-deep half block instead of 32 MFMAs of 64 cycles (sm <= 2: the planes of four weight
 //         blocks do not fit beside eight waves).
 #include "common_device.hpp"
+#include "shmp_args.hpp"
 
 namespace desco {
 
@@ -66,32 +67,8 @@ constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + WCAP;      // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
 
 // absent sources of a batched gather step read this row instead of being predicated away
-__device__ __attribute__((aligned(16))) float shmp_zero_row[64];
+__device__ __attribute__((aligned(16))) float shmp_zero_row[64] = {};
 
-struct ShmpArgs {
-  const float* x;
-  int64_t ldx;
-  const int32_t* vrowptr;
-  const int32_t* vcol;
-  int64_t row0, num_rows;
-  int S, sm, st;
-  const float* wt;          // f32 mode: [(sm+1)*64][64]
-  const short* wplanes;     // x6 mode: [3][64 n][(sm+1)*64 k] bf16 planes (hi, mid, lo)
-  const float* bias;
-  const float* ytab;
-  int64_t ldy, ytab_row0;
-  float* out;
-  int64_t ldo;
-  float* out2;              // optional second copy of the output rows (row i - row0 of a [num_rows, *] view)
-  int64_t ldo2;
-  int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
-  float slope;
-  // fused pooling (global_add_pool of the produced rows, gnn_model.py:107), optional: see
-  // desco_shmp_layer_pool_bf16x6_f32 in desco_hip.h.  out may then be null (rows not stored).
-  const uint32_t* pool_bits;   // [ceil(rows / 32)] bit r of word t: row 32 t + r is the last row of its segment
-  const int32_t* pool_slot;    // [ceil(rows / 32)] first partial slot of 32-row tile t
-  float* pool_part;            // [num slots][64] partial segment sums
-};
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
@@ -791,6 +768,16 @@ static void shmp_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
 #undef DESCO_ONE
 }
 
+// Tile form of the x6 launches: 16-row wave tiles (shmp_layer16.hip) unless DESCO_SHMP_ROWS=32 asks for
+// the 32-row kernel of this file (A/B runs; read once per process).
+static int shmp_tile_rows() {
+  static const int rows = [] {
+    const char* e = getenv("DESCO_SHMP_ROWS");
+    return e && atoi(e) == 32 ? 32 : 16;
+  }();
+  return rows;
+}
+
 static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, const int32_t* vrowptr,
                        const int32_t* vcol, int64_t row0, int64_t num_rows, int slots_stored,
                        int slots_mfma, int slots_table, const void* weights, const float* bias,
@@ -802,9 +789,10 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
   const bool pool = pool_part != nullptr;
-  if (pool && (!pool_bits || !pool_slot || row0 % 32 || mis16(pool_part) || out2 || !x6 || slots_mfma != 2 ||
+  const int tile_rows = x6 ? shmp_tile_rows() : 32;
+  if (pool && (!pool_bits || !pool_slot || row0 % tile_rows || mis16(pool_part) || out2 || !x6 || slots_mfma != 2 ||
                slots_table != 2))
-    return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % 32, no out2, "
+    return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % tile rows, no out2, "
                               "slots_mfma == 2, slots_table == 2)");
   if (!x || (!vrowptr && slots_stored > 0) || !weights || (!out && !pool) || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
@@ -846,8 +834,13 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              slope,
              pool_bits,
              pool_slot,
-             pool_part};
+             pool_part,
+             tile_rows};
   hipStream_t st = (hipStream_t)stream;
+  if (x6 && tile_rows == 16) {
+    if (!shmp16_launch(g, cus, stream)) return fail(DESCO_EINVAL, "desco_shmp_layer_bf16x6_f32: shape not built");
+    return launch_status(who);
+  }
   if (x6) {
     switch (slots_mfma) {
       case 0: shmp_launch_st<1, true>(g, grid, st); break;
@@ -905,6 +898,8 @@ extern "C" int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, con
                             ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
                             pool_bits, pool_slot, pool_part);
 }
+
+extern "C" int desco_shmp_pool_tile_rows(void) { return desco::shmp_tile_rows(); }
 
 // Row-wise Linear with K = 64 inputs (see linear64_kernel): out[i, 0:64*nb] = act(x[i, 0:64] * W^T + bias),
 // w_planes = nb blocks [3][64 n][64 k].  Two column blocks per pass over x where possible.

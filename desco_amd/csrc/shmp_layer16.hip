@@ -1,0 +1,668 @@
+// Fused SHMP layer, 16-row wave tiles: the same layer as shmp_layer.hip (gnn_model.py:47-70 of the
+// reference: per relation SAGEConv(aggr=add) neighbor sums, root/self Linear, HeteroConv sum, relu) in
+// its bf16 6-product form, built for occupancy instead of tile size.
+//
+// Why a second tiling.  The 32-row kernel runs 8 waves per CU (2 per SIMD): its per-wave LDS (A image,
+// row pointers, 512 staged source ids) fills the 160 KB beside the weight planes.  Its time follows
+// T(w) = a + b / w in the waves per CU (8 -> 4 waves costs 1.44-1.53x): the
+// gather latency is hidden by other waves, not by the two-source steps of one wave.  A wave tile of
+// 16 rows (v_mfma_f32_16x16x32_bf16: four 16-column tiles of the 64 outputs) needs a quarter of the
+// accumulators (16 instead of 64 registers... in AGPRs there, VGPRs here), half the A image and half
+// the staged ids, so NW16 = 16 waves (4 per SIMD, 128 registers each) fit beside three weight blocks.
+//
+// Everything else is the 32-row kernel's design (see its header): persistent blocks, wave-autonomous
+// tiles in XCD-aware order, CSR row pointers double-buffered in LDS, the first two sources of every
+// row in flight under the previous block's MFMAs, cooperative path for heavy rows, table pseudo block
+// added in the C/D layout, optional fused pooling.  Differences:
+//   * lane group g8 gathers rows g8 and 8 + g8 (it = 0, 1) instead of four rows;
+//   * the A planes are [3][16][32] bf16 without padding (XOR-swizzled 16-byte chunks);
+//   * the epilogue transposes the four C/D tiles across the lane quarters (v_permlane32_swap +
+//     v_permlane16_swap) so that lane = column: stores are full 256-byte rows, the pooling pass a
+//     running sum in row order with wave-uniform control flow (16-row tiles: pool index of 16 rows).
+#include "common_device.hpp"
+#include "shmp_args.hpp"
+
+namespace desco {
+namespace {
+
+constexpr int WR = 16;        // rows per wave
+constexpr int AH = 33;        // half-K fp32 table image row stride (floats): conflict-free ds_read_b32
+constexpr int APS = 32;       // half-K bf16 plane row stride (shorts, 64 B), chunks XOR-swizzled
+constexpr int MAXS = 4;       // relation slots stored per row
+constexpr int RPN = WR * MAXS + 2;
+constexpr int EXTRA_STEPS = 9; // batched 2-source steps after the prefetched one (<= 20 sources per row)
+constexpr int WCAP = 256;     // source ids staged per wave (longer slices fall back to global)
+constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(16*33, 3*16*32/2) floats
+constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + WCAP;      // floats per wave
+static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
+
+// absent sources of a batched gather step read this row instead of being predicated away
+__device__ __attribute__((aligned(16))) float shmp16_zero_row[64] = {};
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+__device__ __forceinline__ void f4add(float4& a, const float4 b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+
+// ---- gather machinery (macros: every temporary is a named register) ----------------
+// They use the enclosing scope's rp, ec, ebase, grow0, nr, xb, yb, zrow, g, S, g8, l8 and the
+// registers lo*/hi* (sums), u*/w* (loads in flight), c*/n* (cursors).
+#define DESCO_CUR(it_, slot_)                              \
+  {                                                        \
+    const int v_ = ((it_) * 8 + g8) * S + (slot_);         \
+    c##it_ = rp[v_] - ebase;                               \
+    n##it_ = rp[v_ + 1] - ebase;                           \
+  }
+#define DESCO_CURS(slot_) DESCO_CUR(0, slot_) DESCO_CUR(1, slot_)
+// two sources of row it_ (staged ids only: e < WCAP), unconditional loads
+#define DESCO_ISSUE2(it_, base_, ld_)                                                 \
+  {                                                                                   \
+    const int m_ = n##it_ < WCAP ? n##it_ : WCAP;                                     \
+    const bool k0_ = c##it_ < m_, k1_ = c##it_ + 1 < m_;                              \
+    const int i0_ = ec[k0_ ? c##it_ : 0], i1_ = ec[k1_ ? c##it_ + 1 : 0];             \
+    const float* p0_ = k0_ ? (base_) + (int64_t)i0_ * (ld_) : zrow;                   \
+    const float* p1_ = k1_ ? (base_) + (int64_t)i1_ * (ld_) : zrow;                   \
+    u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                \
+    u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                           \
+    w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                \
+    w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                           \
+    c##it_ += (k0_ ? 1 : 0) + (k1_ ? 1 : 0);                                          \
+  }
+#define DESCO_CONSUME2(it_)                                                           \
+  {                                                                                   \
+    f4add(lo##it_, u##it_##0);                                                        \
+    f4add(hi##it_, u##it_##1);                                                        \
+    f4add(lo##it_, w##it_##0);                                                        \
+    f4add(hi##it_, w##it_##1);                                                        \
+  }
+#define DESCO_ZERO_SUMS()                                   \
+  {                                                         \
+    lo0 = make_float4(0.f, 0.f, 0.f, 0.f);                  \
+    lo1 = lo0;                                              \
+    hi0 = lo0; hi1 = lo0;                                   \
+  }
+#define DESCO_ANY_STAGED()                                                                    \
+  __any((c0 < (n0 < WCAP ? n0 : WCAP)) | (c1 < (n1 < WCAP ? n1 : WCAP)))
+// the row itself: rows beyond nr re-read the wave's last valid row (never stored)
+#define DESCO_ISSUE_SELF(it_)                                                                  \
+  {                                                                                            \
+    const int r_ = (it_) * 8 + g8;                                                             \
+    const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDX;                          \
+    u##it_##0 = *reinterpret_cast<const float4*>(p_);                                          \
+    u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                                     \
+  }
+// table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
+#define DESCO_TAB_CUR(it_)                                                                  \
+  const int v_ = ((it_) * 8 + g8) * S + g.sm;                                               \
+  const int ca_ = rp[v_] - ebase, na_ = rp[v_ + 1] - ebase;                                 \
+  const int nb_ = ST > 1 ? rp[v_ + 2] - ebase : na_;                                        \
+  const bool k0_ = ca_ < (na_ < WCAP ? na_ : WCAP);                                         \
+  const bool k1_ = ST > 1 && na_ < (nb_ < WCAP ? nb_ : WCAP);
+#define DESCO_ISSUE_TAB(it_)                                                                \
+  {                                                                                         \
+    DESCO_TAB_CUR(it_)                                                                      \
+    const int i0_ = ec[k0_ ? ca_ : 0], i1_ = ec[k1_ ? na_ : 0];                             \
+    const float* p0_ = k0_ ? yb + (int64_t)i0_ * LDY : zrow;                              \
+    u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                      \
+    u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                                 \
+    if (ST > 1) {                                                                           \
+      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * LDY : zrow;                       \
+      w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                    \
+      w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
+    }                                                                                       \
+  }
+// consume the step; leave the cursor of table slot 0 in (c, n) and of slot 1 in (d, m)
+#define DESCO_CONSUME_TAB(it_)                                                              \
+  {                                                                                         \
+    DESCO_TAB_CUR(it_)                                                                      \
+    f4add(lo##it_, u##it_##0);                                                              \
+    f4add(hi##it_, u##it_##1);                                                              \
+    if (ST > 1) {                                                                           \
+      f4add(lo##it_, w##it_##0);                                                            \
+      f4add(hi##it_, w##it_##1);                                                            \
+    }                                                                                       \
+    c##it_ = ca_ + (k0_ ? 1 : 0);                                                           \
+    n##it_ = na_;                                                                           \
+    d##it_ = na_ + (k1_ ? 1 : 0);                                                           \
+    m##it_ = nb_;                                                                           \
+  }
+// heavy rows (hub / canonical rows of dense neighborhoods, or ids beyond the staged WCAP): the
+// whole wave cooperates on one row at a time -- lane group k takes sources c+k, c+k+8, ... and
+// the 8 partial sums are folded with three xor-shuffles (lanes with equal l8 hold the same columns)
+#define DESCO_COOP(it_, base_, ld_)                                                       \
+  {                                                                                       \
+    unsigned long long m_ = __ballot(c##it_ < n##it_);                                    \
+    while (m_) {                                                                          \
+      const int sl_ = __builtin_ctzll(m_);                                                \
+      const int og_ = sl_ >> 3;                                                           \
+      const int cc_ = __shfl(c##it_, sl_, 64), nn_ = __shfl(n##it_, sl_, 64);             \
+      float4 p_ = make_float4(0.f, 0.f, 0.f, 0.f), q_ = p_;                               \
+      for (int e_ = cc_ + g8; e_ < nn_; e_ += 8) {                                        \
+        const int64_t j_ = e_ < WCAP ? ec[e_] : g.vcol[ebase + e_];                       \
+        const float* s_ = (base_) + j_ * (ld_);                                           \
+        const float4 v0_ = *reinterpret_cast<const float4*>(s_);                          \
+        const float4 v1_ = *reinterpret_cast<const float4*>(s_ + 32);                     \
+        f4add(p_, v0_);                                                                   \
+        f4add(q_, v1_);                                                                   \
+      }                                                                                   \
+      _Pragma("unroll") for (int o_ = 8; o_ < 64; o_ <<= 1) {                             \
+        p_.x += __shfl_xor(p_.x, o_, 64);                                                 \
+        p_.y += __shfl_xor(p_.y, o_, 64);                                                 \
+        p_.z += __shfl_xor(p_.z, o_, 64);                                                 \
+        p_.w += __shfl_xor(p_.w, o_, 64);                                                 \
+        q_.x += __shfl_xor(q_.x, o_, 64);                                                 \
+        q_.y += __shfl_xor(q_.y, o_, 64);                                                 \
+        q_.z += __shfl_xor(q_.z, o_, 64);                                                 \
+        q_.w += __shfl_xor(q_.w, o_, 64);                                                 \
+      }                                                                                   \
+      if (g8 == og_) {                                                                    \
+        f4add(lo##it_, p_);                                                               \
+        f4add(hi##it_, q_);                                                               \
+        c##it_ = n##it_;                                                                  \
+      }                                                                                   \
+      m_ &= ~(0xffULL << (og_ * 8));                                                      \
+    }                                                                                     \
+  }
+// finish a gathered block whose first step is already in flight: consume it, up to EXTRA_STEPS more
+// batched steps (two sources per row each: all four rows of a lane group advance together), then
+// the cooperative path for rows that are heavier still (one row at a time, the whole wave on it)
+#define DESCO_FINISH(base_, ld_)                                                           \
+  {                                                                                        \
+    DESCO_CONSUME2(0) DESCO_CONSUME2(1)                                                    \
+    for (int st_ = 0; st_ < EXTRA_STEPS && DESCO_ANY_STAGED(); ++st_) {                    \
+      DESCO_ISSUE2(0, base_, ld_) DESCO_ISSUE2(1, base_, ld_)                              \
+      DESCO_CONSUME2(0) DESCO_CONSUME2(1)                                                  \
+    }                                                                                      \
+    if (__any((c0 < n0) | (c1 < n1))) {                                                    \
+      DESCO_COOP(0, base_, ld_) DESCO_COOP(1, base_, ld_)                                  \
+    }                                                                                      \
+  }
+// first step of block b_ (cursors + loads); nothing waits on the loads here
+#define DESCO_ISSUE_BLOCK(b_)                                                              \
+  {                                                                                        \
+    if ((b_) < KB - 1) {                                                                   \
+      DESCO_CURS(b_)                                                                       \
+      DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                \
+    } else if ((b_) == KB - 1) {                                                           \
+      DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1)                                              \
+    } else {                                                                               \
+      DESCO_ISSUE_TAB(0) DESCO_ISSUE_TAB(1)                                                \
+    }                                                                                      \
+  }
+// bit s of `live`: relation slot s (an MFMA slot) has at least one source among the wave's 16 rows
+#define DESCO_SLOT_LIVE(s_)                                                                \
+  (__any((rp[(0 * 8 + g8) * S + (s_) + 1] > rp[(0 * 8 + g8) * S + (s_)]) |                  \
+         (rp[(1 * 8 + g8) * S + (s_) + 1] > rp[(1 * 8 + g8) * S + (s_)]))                   \
+       ? 1 << (s_) : 0)
+#define DESCO_TILE_LIVE()                                        \
+  {                                                              \
+    live = 0;                                                    \
+    if (KB - 1 > 0) live |= DESCO_SLOT_LIVE(0);                  \
+    if (KB - 1 > 1) live |= DESCO_SLOT_LIVE(1);                  \
+    if (KB - 1 > 2) live |= DESCO_SLOT_LIVE(2);                  \
+  }
+// first step of the first LIVE block after block a_ (a_ = -1: of the tile); dead slots are left
+// out of the software pipeline altogether, so the block behind one is not issued late.  The slot
+// index is a wave-uniform runtime value here (one copy of the gather issue code per site).
+#define DESCO_ISSUE_AFTER(a_)                                                              \
+  {                                                                                        \
+    if ((a_) < KB - 1) {                                                                   \
+      int nb_ = KB - 1;                                                                    \
+      if ((a_) + 3 < KB - 1 && ((live >> ((a_) + 3)) & 1)) nb_ = (a_) + 3;                  \
+      if ((a_) + 2 < KB - 1 && ((live >> ((a_) + 2)) & 1)) nb_ = (a_) + 2;                  \
+      if ((a_) + 1 < KB - 1 && ((live >> ((a_) + 1)) & 1)) nb_ = (a_) + 1;                  \
+      if (nb_ < KB - 1) {                                                                  \
+        DESCO_CURS(nb_)                                                                    \
+        DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                  \
+      } else {                                                                             \
+        DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1)                                            \
+      }                                                                                    \
+    } else if ((a_) + 1 < NB) {                                                            \
+      DESCO_ISSUE_BLOCK((a_) + 1)                                                          \
+    }                                                                                      \
+  }
+// write one fp32 half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
+#define DESCO_PUT_F32(av_, it_)                         \
+  {                                                     \
+    float* d_ = Aw + ((it_) * 8 + g8) * AH + 4 * l8;    \
+    d_[0] = av_.x;                                      \
+    d_[1] = av_.y;                                      \
+    d_[2] = av_.z;                                      \
+    d_[3] = av_.w;                                      \
+  }
+// write one half image as three bf16 planes (row = it*8 + g8, 4 bf16 at 4*l8 of every plane).  Plane
+// rows are 64 B with no padding: the 16-byte chunk k/8 of row r sits at chunk (k/8) ^ (r/4), which
+// makes both this write (ds_write_b64) and the fragment read (ds_read_b128) conflict-free
+#define DESCO_PUT_X6(av_, it_)                                                  \
+  {                                                                             \
+    uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                      \
+    split2_bf16x3(av_.x, av_.y, h0_, m0_, l0_);                                   \
+    split2_bf16x3(av_.z, av_.w, h1_, m1_, l1_);                                   \
+    short* d_ = Ap + ((it_) * 8 + g8) * APS +                                   \
+                ((((l8 >> 1) ^ ((it_) * 2 + (g8 >> 2))) & 3) << 3) + 4 * (l8 & 1); \
+    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                       \
+    *reinterpret_cast<uint2*>(d_ + WR * APS) = make_uint2(m0_, m1_);            \
+    *reinterpret_cast<uint2*>(d_ + 2 * WR * APS) = make_uint2(l0_, l1_);        \
+  }
+// 24 bf16 MFMAs (6-product split) of v_mfma_f32_16x16x32_bf16 on the staged half (32 k) of block b_: lane
+// (r = lane&15, q = lane>>4) holds A[row r][k = 8 q + 0..7] and B[k = 8 q + 0..7][col 16 t + r] of every
+// plane, t = 0..3 (the four 16-column tiles of the 64 outputs)
+#define DESCO_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
+#define DESCO_MFMA_HALF_X6(b_, h_)                                                                \
+  {                                                                                               \
+    const short* ap_ = Ap + (lane & 15) * APS + ((((lane >> 4) ^ (lane >> 2)) & 3) << 3);         \
+    const short* bp_ = Wp + (lane & 15) * WST + (b_) * 64 + (h_) * 32 + 8 * (lane >> 4);          \
+    const bf16x8 ah_ = *reinterpret_cast<const bf16x8*>(ap_);                                     \
+    const bf16x8 am_ = *reinterpret_cast<const bf16x8*>(ap_ + WR * APS);                          \
+    const bf16x8 al_ = *reinterpret_cast<const bf16x8*>(ap_ + 2 * WR * APS);                      \
+    const bf16x8 b0h_ = *reinterpret_cast<const bf16x8*>(bp_);                                    \
+    const bf16x8 b0m_ = *reinterpret_cast<const bf16x8*>(bp_ + WPL);                              \
+    const bf16x8 b0l_ = *reinterpret_cast<const bf16x8*>(bp_ + 2 * WPL);                          \
+    const bf16x8 b1h_ = *reinterpret_cast<const bf16x8*>(bp_ + 16 * WST);                         \
+    const bf16x8 b1m_ = *reinterpret_cast<const bf16x8*>(bp_ + 16 * WST + WPL);                   \
+    const bf16x8 b1l_ = *reinterpret_cast<const bf16x8*>(bp_ + 16 * WST + 2 * WPL);               \
+    DESCO_M16(al_, b0h_, q0) DESCO_M16(al_, b1h_, q1)                                             \
+    DESCO_M16(ah_, b0l_, q0) DESCO_M16(ah_, b1l_, q1)                                             \
+    DESCO_M16(am_, b0m_, q0) DESCO_M16(am_, b1m_, q1)                                             \
+    const bf16x8 b2h_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST);                         \
+    const bf16x8 b2m_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST + WPL);                   \
+    const bf16x8 b2l_ = *reinterpret_cast<const bf16x8*>(bp_ + 32 * WST + 2 * WPL);               \
+    const bf16x8 b3h_ = *reinterpret_cast<const bf16x8*>(bp_ + 48 * WST);                         \
+    const bf16x8 b3m_ = *reinterpret_cast<const bf16x8*>(bp_ + 48 * WST + WPL);                   \
+    const bf16x8 b3l_ = *reinterpret_cast<const bf16x8*>(bp_ + 48 * WST + 2 * WPL);               \
+    DESCO_M16(am_, b0h_, q0) DESCO_M16(am_, b1h_, q1)                                             \
+    DESCO_M16(ah_, b0m_, q0) DESCO_M16(ah_, b1m_, q1)                                             \
+    DESCO_M16(ah_, b0h_, q0) DESCO_M16(ah_, b1h_, q1)                                             \
+    DESCO_M16(al_, b2h_, q2) DESCO_M16(al_, b3h_, q3)                                             \
+    DESCO_M16(ah_, b2l_, q2) DESCO_M16(ah_, b3l_, q3)                                             \
+    DESCO_M16(am_, b2m_, q2) DESCO_M16(am_, b3m_, q3)                                             \
+    DESCO_M16(am_, b2h_, q2) DESCO_M16(am_, b3h_, q3)                                             \
+    DESCO_M16(ah_, b2m_, q2) DESCO_M16(ah_, b3m_, q3)                                             \
+    DESCO_M16(ah_, b2h_, q2) DESCO_M16(ah_, b3h_, q3)                                             \
+  }
+// add the staged (fp32) table half rows (32 columns) in the C/D layout of two 16-column tiles:
+// lane (c = lane&15, g = lane>>4) holds rows 4 g + e, column 16 t + c
+#define DESCO_TAB_HALF(qa_, qb_)                                                            \
+  {                                                                                        \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                     \
+      const float* t_ = Aw + (4 * (lane >> 4) + e_) * AH + (lane & 15);                    \
+      qa_[e_] += t_[0];                                                                    \
+      qb_[e_] += t_[16];                                                                   \
+    }                                                                                      \
+  }
+
+// KB = sm + 1 resident weight blocks (1..3), ST table slots (0..2),
+// LD64: x rows are 64 floats and ytab rows 64*ST floats apart (the product path's layouts): source-row
+// addresses then need a shift instead of a 64-bit multiply per gathered row
+// POOL: fused pooling epilogue (instantiated for the count-row launches only)
+template <int NW, int KB, int ST, bool LD64, bool POOL>
+__global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WST = KB * 64 + 8;                         // weight plane row stride (shorts)
+  constexpr int WPL = 64 * WST;                            // shorts per weight plane
+  constexpr int W_FLOATS = 3 * WPL / 2;
+  short* Wp = reinterpret_cast<short*>(lds);               // [3][64 n][WST]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Aw = lds + W_FLOATS + wave * WAVE_LDS;            // fp32 half image [16][33] (table block)
+  short* Ap = reinterpret_cast<short*>(Aw);                // bf16 planes [3][16][32] of a half image
+  int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [16*S+1] row pointers (absolute)
+  int* ec = rpb + 2 * RPN;                                 // [WCAP] source ids of the current tile
+
+  // ---- resident weights -------------------------------------------------------------------
+  {
+    // global planes [3][64][KB*64] -> LDS [3][64][WST], 16 bytes at a time
+    constexpr int CH = KB * 8;                             // uint4 chunks per row
+    for (int i = tid; i < 3 * 64 * CH; i += NW * 64) {
+      const int row = i / CH, ch = i - row * CH;           // row = plane*64 + n
+      *reinterpret_cast<uint4*>(Wp + row * WST + 8 * ch) =
+          *reinterpret_cast<const uint4*>(g.wplanes + (int64_t)row * (KB * 64) + 8 * ch);
+    }
+  }
+  __syncthreads();
+
+  const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
+  const int S = g.S;
+  const int nslot = WR * S + 1;                            // <= 65: at most 2 per lane
+  const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
+  constexpr int NB = KB + (ST > 0 ? 1 : 0);                // K blocks incl. the table pseudo block
+  const int64_t LDX = LD64 ? 64 : g.ldx, LDY = LD64 ? 64 * (ST > 0 ? ST : 1) : g.ldy;
+  const float* xb = g.x + 4 * l8;
+  const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * LDY : nullptr;
+  const float* zrow = shmp16_zero_row + 4 * l8;
+  (void)yb;
+
+  // ---- this wave's first tile ---------------------------------------------------------------
+  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch) and its 4 MB L2,
+  // so a neighborhood's rows -- the sources of all its tiles -- should be gathered by ONE XCD.  Measured
+  // (profiles/r2_f_ab_xcd_order.log): +0.5 % on Syn_1827 / MSRC+IMDB shapes, 0 on COX2 shapes (the
+  // gathers are not what bounds the kernel); contiguous eighths per XCD were 8 % SLOWER on Syn shapes
+  // (the dataset is ordered by graph size: the XCD with the dense end finishes last).  Speed only: any
+  // block -> XCD placement gives the same result.
+  int64_t tile, tend = ntiles;
+  int tstride = gridDim.x;
+  if ((gridDim.x & 7) == 0) {
+    // chunks of (grid / 8) consecutive tiles go round robin over the XCDs: XCD x works on the 32
+    // neighbouring tiles of chunk 8 j + x in sweep j (locality), heavy and light regions of the dataset
+    // are spread over all XCDs (balance)
+    tile = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  } else {
+    tile = blockIdx.x;
+  }
+  int64_t w0 = tile * (NW * WR) + wave * WR;               // first row of this wave (relative)
+  if (tile >= tend || w0 >= g.num_rows) return;            // no barrier below: idle waves may leave
+  int nr = (int)((g.num_rows - w0) < WR ? (g.num_rows - w0) : WR);
+  int64_t grow0 = g.row0 + w0;
+  int cur = 0;
+  int* rp = rpb;
+  if (S > 0) {                                             // S == 0: no CSR at all (plain row-wise Linear)
+    const int nptr = nr * S + 1;
+    for (int i = lane; i < nslot; i += 64)
+      rp[i] = g.vrowptr[grow0 * S + (i < nptr ? i : nptr - 1)];
+    const int eb = rp[0], ecnt = rp[WR * S] - eb;
+    for (int i = lane; i < ecnt && i < WCAP; i += 64) ec[i] = g.vcol[eb + i];
+  } else if (lane == 0) {
+    rp[0] = 0;
+    rpb[RPN] = 0;
+  }
+  int ebase = rp[0];
+
+  float4 lo0, lo1, hi0, hi1;                               // gathered sums of the current block
+  float4 u00, u01, u10, u11;                               // in flight: first source (lo, hi) of row it
+  float4 w00, w01, w10, w11;                               // in flight: second source
+  w00 = w01 = w10 = w11 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c0 = 0, c1 = 0, n0 = 0, n1 = 0;                      // cursors [c, n) rel. to ebase
+  // bit b: relation slot b has at least one source among this wave's 16 rows.  A slot that is empty
+  // for the whole wave tile (triangle edges in molecule graphs, tride edges in clique unions) is an
+  // all-zero K block: it is left out of the tile's block sequence (wave-uniform; it would add exact
+  // zeros), and the first gather step of the block behind it is issued in its place
+  int live = 0;
+  DESCO_TILE_LIVE()
+  DESCO_ISSUE_AFTER(-1)
+
+  for (;;) {
+    int* rpn = rpb + (cur ^ 1) * RPN;
+    // ---- prefetch the row pointers of the next tile (registers now, LDS later) --------------
+    const int64_t tn = tile + tstride;
+    const int64_t w0n = tn * (NW * WR) + wave * WR;
+    const bool has_next = tn < tend && w0n < g.num_rows;
+    const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
+    int p0 = 0, p1 = 0;
+    if (has_next && S > 0) {
+      const int nptr = nrn * S + 1;
+      const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
+      p0 = src[lane < nptr ? lane : nptr - 1];
+      if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
+    }
+    int qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0;   // source ids of the next tile (registers until the tile ends)
+    int ebn = 0, ecntn = 0;
+    // fused pooling: this tile's segment-end bitmap and first partial slot (wave-uniform address:
+    // scalar loads, in flight under the whole tile)
+    uint32_t pool_e = 0;
+    int pool_s = 0;
+    if constexpr (POOL) {
+      const int t16 = __builtin_amdgcn_readfirstlane((int)(grow0 >> 4));
+      pool_e = g.pool_bits[t16];
+      pool_s = g.pool_slot[t16];
+    }
+
+    // ---- accumulator init: bias ----------------------------------------------------------------
+    f32x4 q0, q1, q2, q3;                        // 16 rows x 64 columns: four 16-column tiles
+    {
+      const int c_ = lane & 15;
+      const float b0_ = g.bias ? g.bias[c_] : 0.f, b1_ = g.bias ? g.bias[16 + c_] : 0.f;
+      const float b2_ = g.bias ? g.bias[32 + c_] : 0.f, b3_ = g.bias ? g.bias[48 + c_] : 0.f;
+      q0 = f32x4{b0_, b0_, b0_, b0_};
+      q1 = f32x4{b1_, b1_, b1_, b1_};
+      q2 = f32x4{b2_, b2_, b2_, b2_};
+      q3 = f32x4{b3_, b3_, b3_, b3_};
+    }
+    // K blocks: b < KB-1 = relation slot b (gathered x rows), b == KB-1 = the row itself,
+    // b == KB (ST > 0) = table pseudo block (gathered ytab rows, added in the C/D layout)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < KB - 1 && !((live >> b) & 1)) continue;      // empty relation slot (wave-uniform)
+      // ---- complete the gather of block b ------------------------------------------------------
+      DESCO_ZERO_SUMS()
+      if (b < KB - 1) {
+        DESCO_FINISH(xb, LDX)
+      } else if (b == KB - 1) {
+        lo0 = u00; hi0 = u01; lo1 = u10; hi1 = u11;
+      } else {
+        // canonical->count relations have at most one source per row: one step covers both table
+        // slots; anything beyond that (general inputs) takes the cooperative path
+        int d0, d1, m0, m1;
+        DESCO_CONSUME_TAB(0) DESCO_CONSUME_TAB(1)
+        if (__any((c0 < n0) | (c1 < n1))) {
+          DESCO_COOP(0, yb, LDY) DESCO_COOP(1, yb, LDY)
+        }
+        if (ST > 1 && __any((d0 < m0) | (d1 < m1))) {
+          c0 = d0; c1 = d1;
+          n0 = m0; n1 = m1;
+          DESCO_COOP(0, yb + 64, LDY) DESCO_COOP(1, yb + 64, LDY)
+        }
+      }
+      if (b == KB - 1 && has_next) {
+        // next tile's row pointers have landed: publish them, then fetch its source ids
+        rpn[lane] = p0;
+        if (lane + 64 < nslot) rpn[lane + 64] = p1;
+        ebn = rpn[0];
+        ecntn = rpn[WR * S] - ebn;
+        if (lane < ecntn) qn0 = g.vcol[ebn + lane];
+        if (lane + 64 < ecntn) qn1 = g.vcol[ebn + lane + 64];
+        if (lane + 128 < ecntn) qn2 = g.vcol[ebn + lane + 128];
+        if (lane + 192 < ecntn) qn3 = g.vcol[ebn + lane + 192];
+      }
+      // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
+      //      under this block's MFMAs (after the low halves have left their registers)
+      {
+        if (b < KB) {
+          DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1)
+        } else {
+          DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1)
+        }
+      }
+      DESCO_ISSUE_AFTER(b)
+      {
+        if (b >= KB) {
+          DESCO_TAB_HALF(q0, q1)
+        } else {
+          DESCO_MFMA_HALF_X6(b, 0)
+        }
+        if (b < KB) {
+          DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1)
+        } else {
+          DESCO_PUT_F32(hi0, 0) DESCO_PUT_F32(hi1, 1)
+        }
+        if (b >= KB) {
+          DESCO_TAB_HALF(q2, q3)
+        } else {
+          DESCO_MFMA_HALF_X6(b, 1)
+        }
+      }
+    }
+
+    // ---- switch to the next tile: publish its source ids and launch its first gather step ------
+    const int64_t grow_out = grow0;
+    const int nr_out = nr;
+    if (has_next) {
+      if (lane < ecntn) ec[lane] = qn0;            // (the current tile's ids are dead by now)
+      if (lane + 64 < ecntn) ec[lane + 64] = qn1;
+      if (lane + 128 < ecntn) ec[lane + 128] = qn2;
+      if (lane + 192 < ecntn) ec[lane + 192] = qn3;
+      cur ^= 1;
+      rp = rpn;
+      ebase = ebn;
+      tile = tn;
+      w0 = w0n;
+      nr = nrn;
+      grow0 = g.row0 + w0n;
+      DESCO_TILE_LIVE()
+      DESCO_ISSUE_AFTER(-1)
+    }
+
+    // ---- epilogue.  C/D map of a 16x16 tile: lane (c = lane&15, g = lane>>4) holds rows 4 g + e of
+    //      column 16 t + c.  A 4x4 transpose over the lane quarters (tile t of quarter g <-> tile g of
+    //      quarter t: v_permlane32_swap, then v_permlane16_swap) leaves lane = column with the 16 rows
+    //      of the tile in registers, row 4 t + e in q_t[e]: every store is one full 256-byte row, and
+    //      the pooling pass is a running sum in row order ------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q0[e] = apply_act(q0[e], g.act, g.slope);
+      q1[e] = apply_act(q1[e], g.act, g.slope);
+      q2[e] = apply_act(q2[e], g.act, g.slope);
+      q3[e] = apply_act(q3[e], g.act, g.slope);
+    }
+    {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // quarters {2,3} of q0 <-> quarters {0,1} of q2, likewise q1 / q3
+        u32x2 t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(q0[e]), __float_as_uint(q2[e]), false, false);
+        q0[e] = __uint_as_float(t_[0]);
+        q2[e] = __uint_as_float(t_[1]);
+        t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(q1[e]), __float_as_uint(q3[e]), false, false);
+        q1[e] = __uint_as_float(t_[0]);
+        q3[e] = __uint_as_float(t_[1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // odd quarters of q0 <-> even quarters of q1, likewise q2 / q3
+        u32x2 t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(q0[e]), __float_as_uint(q1[e]), false, false);
+        q0[e] = __uint_as_float(t_[0]);
+        q1[e] = __uint_as_float(t_[1]);
+        t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(q2[e]), __float_as_uint(q3[e]), false, false);
+        q2[e] = __uint_as_float(t_[0]);
+        q3[e] = __uint_as_float(t_[1]);
+      }
+    }
+    const int nru = __builtin_amdgcn_readfirstlane(nr_out);
+#define DESCO_ROW(r_) ((r_) < 4 ? q0[(r_) & 3] : (r_) < 8 ? q1[(r_) & 3] : (r_) < 12 ? q2[(r_) & 3] : q3[(r_) & 3])
+    if (!POOL || g.out) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r < nru) {
+          g.out[(grow_out + r) * g.ldo + lane] = DESCO_ROW(r);
+          if (g.out2) g.out2[(grow_out - g.row0 + r) * g.ldo2 + lane] = DESCO_ROW(r);
+        }
+      }
+    }
+    if constexpr (POOL) {
+      const uint32_t E = __builtin_amdgcn_readfirstlane(pool_e);
+      int slot = __builtin_amdgcn_readfirstlane(pool_s);
+      float* pp = g.pool_part + lane;
+      float run = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r < nru) {                                        // (wave-uniform)
+          run += DESCO_ROW(r);
+          if ((E >> r) & 1u) {                                // row r ends its segment (wave-uniform)
+            pp[(int64_t)slot * 64] = run;
+            ++slot;
+            run = 0.f;
+          }
+        }
+      }
+      // the last segment of the tile continues in the next tile: its partial so far
+      if (nru > 0 && !((E >> (nru - 1)) & 1u)) pp[(int64_t)slot * 64] = run;
+    }
+#undef DESCO_ROW
+    if (!has_next) break;
+  }
+}
+
+
+#undef DESCO_CUR
+#undef DESCO_CURS
+#undef DESCO_ISSUE2
+#undef DESCO_CONSUME2
+#undef DESCO_ZERO_SUMS
+#undef DESCO_ANY_STAGED
+#undef DESCO_ISSUE_SELF
+#undef DESCO_TAB_CUR
+#undef DESCO_ISSUE_TAB
+#undef DESCO_CONSUME_TAB
+#undef DESCO_COOP
+#undef DESCO_FINISH
+#undef DESCO_ISSUE_BLOCK
+#undef DESCO_SLOT_LIVE
+#undef DESCO_TILE_LIVE
+#undef DESCO_ISSUE_AFTER
+#undef DESCO_PUT_F32
+#undef DESCO_PUT_X6
+#undef DESCO_M16
+#undef DESCO_MFMA_HALF_X6
+#undef DESCO_TAB_HALF
+
+template <int NW, int KB, int ST, bool LD64, bool POOL>
+void launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+  constexpr int WST = KB * 64 + 8;
+  constexpr size_t w_floats = (size_t)3 * 64 * WST / 2;
+  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS);
+  static_assert(shmem <= 160 * 1024, "SHMP layer (16-row tiles): LDS budget exceeded");
+  static DeviceOnce attr_once;        // function attributes are per device
+  if (!attr_once.done()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer16_kernel<NW, KB, ST, LD64, POOL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_once.mark();
+  }
+  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL>), dim3(grid), dim3(NW * 64), shmem, st, g);
+}
+
+template <int NW, int KB>
+bool launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st);
+  if (g.pool_part) {
+    if constexpr (KB == 3) {
+      if (g.st != 2) return false;
+      if (ld64)
+        launch_one<NW, 3, 2, true, true>(g, grid, st);
+      else
+        launch_one<NW, 3, 2, false, true>(g, grid, st);
+      return true;
+    } else {
+      return false;
+    }
+  }
+#define DESCO_ONE(ST_)                                \
+  if (ld64)                                           \
+    launch_one<NW, KB, ST_, true, false>(g, grid, st);    \
+  else                                                \
+    launch_one<NW, KB, ST_, false, false>(g, grid, st);
+  switch (g.st) {
+    case 0: DESCO_ONE(0) break;
+    case 1: DESCO_ONE(1) break;
+    case 2: DESCO_ONE(2) break;
+    default: return false;
+  }
+#undef DESCO_ONE
+  return true;
+}
+
+}  // namespace
+
+// x6 arguments validated by shmp_launch (shmp_layer.hip); g.wplanes set, g.sm <= 2
+template <int NW>
+bool launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
+  const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  switch (g.sm) {
+    case 0: return launch_st<NW, 1>(g, grid, st);
+    case 1: return launch_st<NW, 2>(g, grid, st);
+    default: return launch_st<NW, 3>(g, grid, st);
+  }
+}
+
+bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
+  if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
+  static const int nw = [] {
+    const char* e = getenv("DESCO_SHMP16_NW");
+    return e && atoi(e) == 16 ? 16 : 12;
+  }();
+  return nw == 16 ? launch_nw<16>(g, cus, (hipStream_t)stream) : launch_nw<12>(g, cus, (hipStream_t)stream);
+}
+
+}  // namespace desco

@@ -239,8 +239,9 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
 
 def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_ptr: torch.Tensor,
                 num_seg: int, extra: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[b] = sum of segment b's partial rows (left by ``shmp_layer(pool=...)``) + extra[b]."""
+                out: Optional[torch.Tensor] = None, tile_rows: Optional[int] = None) -> torch.Tensor:
+    """out[b] = sum of segment b's partial rows (left by ``shmp_layer(pool=...)``) + extra[b];
+    ``tile_rows`` = the tile size the index was built for (default: ``pool_tile_rows()``)."""
     if out is None:
         out = torch.empty((num_seg, 64), device=part.device, dtype=torch.float32)
     op, ldo = _rows(out, "out")
@@ -251,8 +252,15 @@ def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_
         _lib.check(L.desco_pool_reduce_f32(_dev(part, "pool_part"), _dev(bits, "pool_bits", torch.int32),
                                            _dev(slot, "pool_slot", torch.int32),
                                            _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, ep, lde, op, ldo,
+                                           pool_tile_rows() if tile_rows is None else tile_rows,
                                            _stream()), "pool_reduce")
     return out
+
+
+def pool_tile_rows() -> int:
+    """Rows per wave tile of the fused layer kernel (16, or 32 with DESCO_SHMP_ROWS=32): the
+    granularity of the fused-pooling index (``NeighborhoodBatch.pool_index``)."""
+    return int(_lib.lib().desco_shmp_pool_tile_rows())
 
 
 def linear64_planes(w: torch.Tensor) -> torch.Tensor:

@@ -219,15 +219,18 @@ int desco_shmp_layer_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrow
 /* desco_shmp_layer_bf16x6_f32 with the layer's global_add_pool (gnn_model.py:88-89, 107) fused into
  * the epilogue: besides (or instead of: out may be NULL, e.g. for the last layer, whose count rows
  * feed nothing but the pooling) storing the produced rows, every wave sums them per segment and
- * writes ONE partial row per (32-row tile, segment) to pool_part[slot][0:64]:
- *   pool_bits[t] bit r = 1  <=>  row 32 t + r is the LAST row of its segment (segments = contiguous row
- *                                ranges covering [row0, row0+num_rows); row0 % 32 == 0),
+ * writes ONE partial row per (wave tile, segment) to pool_part[slot][0:64].  A wave tile is
+ * TR = desco_shmp_pool_tile_rows() rows (16; 32 with DESCO_SHMP_ROWS=32 in the environment, the 32-row
+ * form of the kernel kept for A/B runs):
+ *   pool_bits[t] bit r = 1  <=>  row TR t + r is the LAST row of its segment (segments = contiguous row
+ *                                ranges covering [row0, row0+num_rows); row0 % TR == 0),
  *   pool_slot[t]            =    first slot of tile t (tiles use consecutive slots: one per segment
  *                                that has a row in the tile),
- * both [ceil((row0+num_rows)/32)], indexed by absolute row / 32.  desco_pool_reduce_f32 then adds the
- * partials of every segment in tile order (+ extra[b], like desco_segment_sum_f32) -- together they
- * replace one desco_segment_sum_f32 pass over the rows (a full read of x) by ~(1/32 + 1/segment
- * length) of its traffic, deterministically (no float atomics). */
+ * both [ceil((row0+num_rows)/TR)], indexed by absolute row / TR.  desco_pool_reduce_f32 (tile_rows =
+ * the same TR) then adds the partials of every segment in tile order (+ extra[b], like
+ * desco_segment_sum_f32) -- together they replace one desco_segment_sum_f32 pass over the rows (a
+ * full read of x) by ~(1/TR + 1/segment length) of its traffic, deterministically (no float atomics). */
+int desco_shmp_pool_tile_rows(void);
 int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
                                      const int32_t* vcol, int64_t row0, int64_t num_rows,
                                      int slots_stored, int slots_mfma, int slots_table,
@@ -237,7 +240,8 @@ int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, const int32_t*
                                      float* pool_part, desco_stream_t stream);
 int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, const int32_t* pool_slot,
                           const int32_t* seg_ptr, int64_t num_seg, const float* extra,
-                          int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream);
+                          int64_t ld_extra, float* out, int64_t ldo, int tile_rows,
+                          desco_stream_t stream);
 
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);

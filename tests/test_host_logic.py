@@ -217,29 +217,30 @@ def test_pool_index_slots_are_consistent_between_kernel_and_reduce():
             count_ptr = cp
         nb = NeighborhoodBatch.__new__(NeighborhoodBatch)
         nb.part, nb.device = _P, torch.device("cpu")
-        bits, slot, nslots = nb.pool_index()
-        bits = bits.numpy().view(np.uint32)
-        slot = slot.numpy()
-        nc = int(cp[-1])
-        vals = rng.standard_normal(nc)
-        part = np.full(nslots, np.nan)
-        for t in range((nc + 31) // 32):                        # the layer kernel's walk over tile t
-            s, run, nr = int(slot[t]), 0.0, min(32, nc - 32 * t)
-            for r in range(nr):
-                run += vals[32 * t + r]
-                if (bits[t] >> r) & 1:
+        for TR in (16, 32):
+            bits, slot, nslots = nb.pool_index(TR)
+            bits = bits.numpy().view(np.uint32)
+            slot = slot.numpy()
+            nc = int(cp[-1])
+            vals = rng.standard_normal(nc)
+            part = np.full(nslots, np.nan)
+            for t in range((nc + TR - 1) // TR):                # the layer kernel's walk over tile t
+                s, run, nr = int(slot[t]), 0.0, min(TR, nc - TR * t)
+                for r in range(nr):
+                    run += vals[TR * t + r]
+                    if (bits[t] >> r) & 1:
+                        assert np.isnan(part[s])
+                        part[s] = run
+                        s, run = s + 1, 0.0
+                if not (bits[t] >> (nr - 1)) & 1:
                     assert np.isnan(part[s])
                     part[s] = run
-                    s, run = s + 1, 0.0
-            if not (bits[t] >> (nr - 1)) & 1:
-                assert np.isnan(part[s])
-                part[s] = run
-        assert not np.isnan(part).any()
-        for b in range(len(lens)):                              # the reduce kernel's lookup
-            r0, r1 = int(cp[b]), int(cp[b + 1])
-            tot = 0.0
-            for t in range(r0 >> 5, ((r1 - 1) >> 5) + 1):
-                first = max(r0 - 32 * t, 0)
-                k = bin(int(bits[t]) & ((1 << first) - 1)).count("1")
-                tot += part[slot[t] + k]
-            assert abs(tot - vals[r0:r1].sum()) < 1e-9
+            assert not np.isnan(part).any()
+            for b in range(len(lens)):                          # the reduce kernel's lookup
+                r0, r1 = int(cp[b]), int(cp[b + 1])
+                tot = 0.0
+                for t in range(r0 // TR, (r1 - 1) // TR + 1):
+                    first = max(r0 - TR * t, 0)
+                    k = bin(int(bits[t]) & ((1 << first) - 1)).count("1")
+                    tot += part[slot[t] + k]
+                assert abs(tot - vals[r0:r1].sum()) < 1e-9

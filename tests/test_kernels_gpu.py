@@ -285,7 +285,8 @@ def test_fused_pooling_equals_segment_sum(num_rows, seg_kind):
     nb = NeighborhoodBatch.__new__(NeighborhoodBatch)
     nb.part, nb.device = _P, torch.device(DEV, torch.cuda.current_device())
     bits, slot, nslots = nb.pool_index()
-    assert nslots <= B + (num_rows + 31) // 32
+    TR = ops.pool_tile_rows()
+    assert TR in (16, 32) and nslots <= B + (num_rows + TR - 1) // TR
     wt = torch.randn(3 * 64, 64, generator=g) / 12
     bias = torch.randn(64, generator=g)
     planes = ops.split_bf16_planes(wt.t().contiguous().to(DEV))
