@@ -7,8 +7,14 @@
 // T(w) = a + b / w in the waves per CU (8 -> 4 waves costs 1.44-1.53x): the
 // gather latency is hidden by other waves, not by the two-source steps of one wave.  A wave tile of
 // 16 rows (v_mfma_f32_16x16x32_bf16: four 16-column tiles of the 64 outputs) needs a quarter of the
-// accumulators (16 instead of 64 registers... in AGPRs there, VGPRs here), half the A image and half
-// the staged ids, so NW16 = 16 waves (4 per SIMD, 128 registers each) fit beside three weight blocks.
+// accumulator registers, half the A image and half the staged ids, so 16 waves (4 per SIMD, the
+// 1024-thread block limit) fit beside three weight blocks -- if a wave stays within 128 registers:
+//   * wave-uniform bookkeeping (tile, row range, CSR bases) is forced into SGPRs (readfirstlane);
+//   * the next tile's row pointers and source ids go from global memory straight into LDS
+//     (global_load_lds_dword) instead of waiting in registers until the tile switch.
+// Measured (profiles/r2_h_ab_tile_rows.log): 8 x 32 rows -> 12 x 16 -> 16 x 16 waves x rows:
+// Syn_1827 x4 34.0k -> 37.4k -> 39.6k graphs/s, MSRC+IMDB x8 253k -> 266k -> 281k, COX2 x64 664k ->
+// 681k -> 696k.
 //
 // Everything else is the 32-row kernel's design (see its header): persistent blocks, wave-autonomous
 // tiles in XCD-aware order, CSR row pointers double-buffered in LDS, the first two sources of every
@@ -31,9 +37,9 @@ constexpr int APS = 32;       // half-K bf16 plane row stride (shorts, 64 B), ch
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 2;
 constexpr int EXTRA_STEPS = 9; // batched 2-source steps after the prefetched one (<= 20 sources per row)
-constexpr int WCAP = 256;     // source ids staged per wave (longer slices fall back to global)
+constexpr int WCAP = 224;     // source ids staged per wave and buffer (longer slices fall back to global)
 constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(16*33, 3*16*32/2) floats
-constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + WCAP;      // floats per wave
+constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
 
 // absent sources of a batched gather step read this row instead of being predicated away
@@ -48,6 +54,12 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   a.w += b.w;
 }
 
+// 4 bytes per lane from global straight into LDS: lane i's dword lands at dst_[i] (dst_ wave-uniform).
+// Completion is counted by vmcnt like any vector load, but the compiler does not order later LDS reads
+// behind it: the kernel waits explicitly where it first reads the data.
+#define DESCO_DMA4(src_, dst_)                                                                 \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_),      \
+                                   (__attribute__((address_space(3))) void*)(dst_), 4, 0, 0)
 // ---- gather machinery (macros: every temporary is a named register) ----------------
 // They use the enclosing scope's rp, ec, ebase, grow0, nr, xb, yb, zrow, g, S, g8, l8 and the
 // registers lo*/hi* (sums), u*/w* (loads in flight), c*/n* (cursors).
@@ -306,11 +318,13 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
   constexpr int WPL = 64 * WST;                            // shorts per weight plane
   constexpr int W_FLOATS = 3 * WPL / 2;
   short* Wp = reinterpret_cast<short*>(lds);               // [3][64 n][WST]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping stays in SGPRs
   float* Aw = lds + W_FLOATS + wave * WAVE_LDS;            // fp32 half image [16][33] (table block)
   short* Ap = reinterpret_cast<short*>(Aw);                // bf16 planes [3][16][32] of a half image
   int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [16*S+1] row pointers (absolute)
-  int* ec = rpb + 2 * RPN;                                 // [WCAP] source ids of the current tile
+  int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids (current / next tile)
+  int* ec = ecb;
 
   // ---- resident weights -------------------------------------------------------------------
   {
@@ -362,13 +376,14 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int nptr = nr * S + 1;
     for (int i = lane; i < nslot; i += 64)
       rp[i] = g.vrowptr[grow0 * S + (i < nptr ? i : nptr - 1)];
-    const int eb = rp[0], ecnt = rp[WR * S] - eb;
+    const int eb = __builtin_amdgcn_readfirstlane(rp[0]);
+    const int ecnt = __builtin_amdgcn_readfirstlane(rp[WR * S]) - eb;
     for (int i = lane; i < ecnt && i < WCAP; i += 64) ec[i] = g.vcol[eb + i];
   } else if (lane == 0) {
     rp[0] = 0;
     rpb[RPN] = 0;
   }
-  int ebase = rp[0];
+  int ebase = __builtin_amdgcn_readfirstlane(rp[0]);     // (wave-uniform values are kept in SGPRs)
 
   float4 lo0, lo1, hi0, hi1;                               // gathered sums of the current block
   float4 u00, u01, u10, u11;                               // in flight: first source (lo, hi) of row it
@@ -390,14 +405,14 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int64_t w0n = tn * (NW * WR) + wave * WR;
     const bool has_next = tn < tend && w0n < g.num_rows;
     const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
-    int p0 = 0, p1 = 0;
+    // global -> LDS directly (no staging registers): lane i's dword lands at rpn[i]
     if (has_next && S > 0) {
       const int nptr = nrn * S + 1;
       const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
-      p0 = src[lane < nptr ? lane : nptr - 1];
-      if (lane + 64 < nslot) p1 = src[lane + 64 < nptr ? lane + 64 : nptr - 1];
+      DESCO_DMA4(src + (lane < nptr ? lane : nptr - 1), rpn);
+      if (lane + 64 < nslot) DESCO_DMA4(src + (lane + 64 < nptr ? lane + 64 : nptr - 1), rpn + 64);
     }
-    int qn0 = 0, qn1 = 0, qn2 = 0, qn3 = 0;   // source ids of the next tile (registers until the tile ends)
+    int* ecn = ecb + (cur ^ 1) * WCAP;
     int ebn = 0, ecntn = 0;
     // fused pooling: this tile's segment-end bitmap and first partial slot (wave-uniform address:
     // scalar loads, in flight under the whole tile)
@@ -446,15 +461,18 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
         }
       }
       if (b == KB - 1 && has_next) {
-        // next tile's row pointers have landed: publish them, then fetch its source ids
-        rpn[lane] = p0;
-        if (lane + 64 < nslot) rpn[lane + 64] = p1;
-        ebn = rpn[0];
-        ecntn = rpn[WR * S] - ebn;
-        if (lane < ecntn) qn0 = g.vcol[ebn + lane];
-        if (lane + 64 < ecntn) qn1 = g.vcol[ebn + lane + 64];
-        if (lane + 128 < ecntn) qn2 = g.vcol[ebn + lane + 128];
-        if (lane + 192 < ecntn) qn3 = g.vcol[ebn + lane + 192];
+        // next tile's row pointers have landed (the self rows just consumed were issued after them and
+        // vector memory returns in order: the wait is free, it orders the LDS reads behind the
+        // LDS-direct load, which the compiler does not track); then fetch its source ids
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ebn = __builtin_amdgcn_readfirstlane(rpn[0]);
+        ecntn = __builtin_amdgcn_readfirstlane(rpn[WR * S]) - ebn;
+        const int32_t* src = g.vcol + ebn + lane;
+        const int ne = ecntn < WCAP ? ecntn : WCAP;
+        if (lane < ne) DESCO_DMA4(src, ecn);
+        if (lane + 64 < ne) DESCO_DMA4(src + 64, ecn + 64);
+        if (lane + 128 < ne) DESCO_DMA4(src + 128, ecn + 128);
+        if (lane + 192 < ne) DESCO_DMA4(src + 192, ecn + 192);
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
@@ -489,10 +507,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int64_t grow_out = grow0;
     const int nr_out = nr;
     if (has_next) {
-      if (lane < ecntn) ec[lane] = qn0;            // (the current tile's ids are dead by now)
-      if (lane + 64 < ecntn) ec[lane + 64] = qn1;
-      if (lane + 128 < ecntn) ec[lane + 128] = qn2;
-      if (lane + 192 < ecntn) ec[lane + 192] = qn3;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ids of the next tile are in LDS
+      ec = ecn;
       cur ^= 1;
       rp = rpn;
       ebase = ebn;
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
 }
 
 
+#undef DESCO_DMA4
 #undef DESCO_CUR
 #undef DESCO_CURS
 #undef DESCO_ISSUE2
@@ -660,7 +677,7 @@ bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
   if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
   static const int nw = [] {
     const char* e = getenv("DESCO_SHMP16_NW");
-    return e && atoi(e) == 16 ? 16 : 12;
+    return e && atoi(e) == 12 ? 12 : 16;     // 12: A/B runs only
   }();
   return nw == 16 ? launch_nw<16>(g, cus, (hipStream_t)stream) : launch_nw<12>(g, cus, (hipStream_t)stream);
 }
