@@ -43,15 +43,22 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (same guid
 # fp32-accurate kernels on the bf16 pipe ("bf16x6"): every algorithmic fp32 multiply-add is six bf16
 # MFMA products, so the speed of light of the ALGORITHM is the bf16 peak / 6 in fp32-equivalent flops
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-GATHER_KERNEL = "shmp_layer_f32_kernel<3,2,x6>"     # count-row launches of the fused SHMP layer
+
+
+def gather_kernel() -> str:
+    """Profiler key of the count-row launches of the fused SHMP layer (the gather-heavy kernel)."""
+    from desco_amd import ops
+    return ops.shmp_kernel_name(3, 2, True)
+
 
 
 def mfma_peak(kernel: str):
     """(peak TFLOP/s in algorithmic fp32 flops, pipe) for an MFMA-bound kernel, else None."""
     if kernel == "gemm_f32_kernel" or kernel.endswith(",f32>"):
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
-    if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>"):
-        return PEAK_X6_TFLOPS, "v_mfma_f32_32x32x16_bf16 x 6 products (bf16x6, fp32-accurate)"
+    if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>") or \
+            kernel.startswith("shmp_layer16_kernel<"):
+        return PEAK_X6_TFLOPS, "bf16 MFMA x 6 products (bf16x6, fp32-accurate)"
     return None
 
 
@@ -289,7 +296,7 @@ def main():
                 dt = float(t.item())
             summ2 = ops.PROFILER.summary()
             tot2 = sum(d["ms"] for d in summ2.values())
-            gk = summ2.get(GATHER_KERNEL)
+            gk = summ2.get(gather_kernel())
             dom, dd = max(summ2.items(), key=lambda kv: kv[1]["ms"])
             entry = {"value": g2.num_graphs * world * 3 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt / 3,
                      "graphs_per_gpu": g2.num_graphs, "neighborhood_rows_per_gpu": p2.partition.num_rows,
@@ -298,7 +305,7 @@ def main():
             if gk and gk["ms"] > 0:
                 gbs = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
                 tfs = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-                entry["gather"] = {"kernel": GATHER_KERNEL, "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                entry["gather"] = {"kernel": gather_kernel(), "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
                                    "mfma_TFLOPs": tfs, "mfma_frac_of_x6_peak": tfs / PEAK_X6_TFLOPS,
                                    "share_of_kernel_time": gk["ms"] / tot2,
                                    "avg_launch_ms": gk["ms"] / gk["calls"]}
@@ -367,14 +374,14 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                            "WRITE_SIZE passes, gfx950-corrected)" if roof["traffic"] else None})
             # the north_star's gather = the fused SHMP layer's count-row launches, priced against HBM
-            gk = summ.get(GATHER_KERNEL)
+            gk = summ.get(gather_kernel())
             if gk and gk["ms"] > 0:
                 gbs = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
                 tfs = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-                tr = traffic(GATHER_KERNEL)
+                tr = traffic(gather_kernel())
                 alg = gk["bytes"] / gk["calls"]
                 roof["gather"] = {
-                    "kernel": GATHER_KERNEL, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                    "kernel": gather_kernel(), "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": gk["calls"],
                     "avg_launch_ms": gk["ms"] / gk["calls"], "share_of_kernel_time": gk["ms"] / tot,
                     "algorithmic_bytes_per_launch": alg, "traffic": tr,

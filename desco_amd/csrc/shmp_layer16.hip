@@ -29,7 +29,6 @@
 #include "shmp_args.hpp"
 
 namespace desco {
-namespace {
 
 constexpr int WR = 16;        // rows per wave
 constexpr int AH = 33;        // half-K fp32 table image row stride (floats): conflict-free ds_read_b32
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
 #undef DESCO_TAB_HALF
 
 template <int NW, int KB, int ST, bool LD64, bool POOL>
-void launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 8;
   constexpr size_t w_floats = (size_t)3 * 64 * WST / 2;
   constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS);
@@ -630,15 +629,15 @@ void launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
 }
 
 template <int NW, int KB>
-bool launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
+static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st);
   if (g.pool_part) {
     if constexpr (KB == 3) {
       if (g.st != 2) return false;
       if (ld64)
-        launch_one<NW, 3, 2, true, true>(g, grid, st);
+        shmp16_launch_one<NW, 3, 2, true, true>(g, grid, st);
       else
-        launch_one<NW, 3, 2, false, true>(g, grid, st);
+        shmp16_launch_one<NW, 3, 2, false, true>(g, grid, st);
       return true;
     } else {
       return false;
@@ -646,9 +645,9 @@ bool launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   }
 #define DESCO_ONE(ST_)                                \
   if (ld64)                                           \
-    launch_one<NW, KB, ST_, true, false>(g, grid, st);    \
+    shmp16_launch_one<NW, KB, ST_, true, false>(g, grid, st);    \
   else                                                \
-    launch_one<NW, KB, ST_, false, false>(g, grid, st);
+    shmp16_launch_one<NW, KB, ST_, false, false>(g, grid, st);
   switch (g.st) {
     case 0: DESCO_ONE(0) break;
     case 1: DESCO_ONE(1) break;
@@ -659,27 +658,25 @@ bool launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   return true;
 }
 
-}  // namespace
-
-// x6 arguments validated by shmp_launch (shmp_layer.hip); g.wplanes set, g.sm <= 2
 template <int NW>
-bool launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
+static bool shmp16_launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   switch (g.sm) {
-    case 0: return launch_st<NW, 1>(g, grid, st);
-    case 1: return launch_st<NW, 2>(g, grid, st);
-    default: return launch_st<NW, 3>(g, grid, st);
+    case 0: return shmp16_launch_st<NW, 1>(g, grid, st);
+    case 1: return shmp16_launch_st<NW, 2>(g, grid, st);
+    default: return shmp16_launch_st<NW, 3>(g, grid, st);
   }
 }
 
+// x6 arguments validated by shmp_launch (shmp_layer.hip); g.wplanes set, g.sm <= 2
 bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
   if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
   static const int nw = [] {
     const char* e = getenv("DESCO_SHMP16_NW");
     return e && atoi(e) == 12 ? 12 : 16;     // 12: A/B runs only
   }();
-  return nw == 16 ? launch_nw<16>(g, cus, (hipStream_t)stream) : launch_nw<12>(g, cus, (hipStream_t)stream);
+  return nw == 16 ? shmp16_launch_nw<16>(g, cus, (hipStream_t)stream) : shmp16_launch_nw<12>(g, cus, (hipStream_t)stream);
 }
 
 }  // namespace desco

@@ -206,7 +206,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
     # profiler key = the device kernel's template instance (KB = sm + 1 weight blocks, ST table slots)
-    with _Timed(f"shmp_layer_f32_kernel<{slots_mfma + 1},{st},{'x6' if x6 else 'f32'}>", fl, nb):
+    with _Timed(shmp_kernel_name(slots_mfma + 1, st, x6), fl, nb):
         _lib.check(fn(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
                       _dev(vcol, "vcol", torch.int32), row0, num_rows,
                       slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
@@ -228,7 +228,7 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
     # x once (+ out once when stored) + indices + the partial rows (about one per 32 rows + one per segment)
     nb = (256.0 if out is None else 512.0) * num_rows + 4.0 * (num_rows * slots_stored +
                                                                 vcol.numel() * num_rows / max(x.shape[0], 1))
-    with _Timed(f"shmp_layer_f32_kernel<{slots_mfma + 1},{st},x6>", fl, nb):
+    with _Timed(shmp_kernel_name(slots_mfma + 1, st, True), fl, nb):
         _lib.check(L.desco_shmp_layer_pool_bf16x6_f32(
             xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
             slots_stored, slots_mfma, st, _dev(wt, "wt", torch.int16), _dev(bias.contiguous(), "bias"), yp, ldy,
@@ -255,6 +255,14 @@ def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_
                                            pool_tile_rows() if tile_rows is None else tile_rows,
                                            _stream()), "pool_reduce")
     return out
+
+
+def shmp_kernel_name(kb: int, st: int, x6: bool) -> str:
+    """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
+    the bf16x6 form unless DESCO_SHMP_ROWS=32) and its <weight blocks, table slots>."""
+    if x6 and pool_tile_rows() == 16:
+        return f"shmp_layer16_kernel<{kb},{st}>"
+    return f"shmp_layer_f32_kernel<{kb},{st},{'x6' if x6 else 'f32'}>"
 
 
 def pool_tile_rows() -> int:

@@ -20,7 +20,10 @@ def load(path, cname):
         if r["Counter_Name"] != cname:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
-        if k.startswith("shmp_layer_f32_kernel<"):
+        if k.startswith("shmp_layer16_kernel<"):           # <NW, KB, ST, LD64, POOL>
+            a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            k = f"shmp_layer16_kernel<{a[1]},{a[2]}>"
+        elif k.startswith("shmp_layer_f32_kernel<"):
             # template <KB, ST, X6, LD64> -> the profiler key of desco_amd/ops.py
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
             k = f"shmp_layer_f32_kernel<{a[0]},{a[1]},{'x6' if a[2] == 'true' else 'f32'}>"
