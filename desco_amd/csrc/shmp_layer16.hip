@@ -304,11 +304,17 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   }
 
 // KB = sm + 1 resident weight blocks (1..3), ST table slots (0..2),
-// LD64: x rows are 64 floats and ytab rows 64*ST floats apart (the product path's layouts): source-row
-// addresses then need a shift instead of a 64-bit multiply per gathered row
+// LD64: x and out rows are 64 floats and ytab rows 64*ST floats apart (the product path's layouts):
+// source-row addresses then need a shift instead of a 64-bit multiply per gathered row, and the stores
+// of a tile are one address with immediate offsets
 // POOL: fused pooling epilogue (instantiated for the count-row launches only)
 template <int NW, int KB, int ST, bool LD64, bool POOL>
-__global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
+__global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const int32_t* __restrict__ rowptr_s,
+                                                              const uint32_t* __restrict__ pool_bits_s,
+                                                              const int32_t* __restrict__ pool_slot_s) {
+  // rowptr_s / pool_*_s = g.vrowptr / g.pool_bits / g.pool_slot once more, as read-only restrict
+  // parameters: their wave-uniform loads then go through the scalar cache (s_load, counted by lgkmcnt)
+  // instead of queueing behind the gathers in the in-order vector memory pipe
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WST = KB * 64 + 16;                        // weight plane row stride (shorts): 32 B of padding, conflict-free B fragments
   constexpr int WPL = 64 * WST;                            // shorts per weight plane
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
   int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [16*S+1] row pointers (absolute)
   int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids (current / next tile)
   int* ec = ecb;
+  float* biasL = lds + W_FLOATS + NW * WAVE_LDS;           // [64] bias (zeros without one), block-shared
 
   // ---- resident weights -------------------------------------------------------------------
   {
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
           *reinterpret_cast<const uint4*>(g.wplanes + (int64_t)row * (KB * 64) + 8 * ch);
     }
   }
+  if (tid < 64) biasL[tid] = g.bias ? g.bias[tid] : 0.f;
   __syncthreads();
 
   const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
   constexpr int NB = KB + (ST > 0 ? 1 : 0);                // K blocks incl. the table pseudo block
   const int64_t LDX = LD64 ? 64 : g.ldx, LDY = LD64 ? 64 * (ST > 0 ? ST : 1) : g.ldy;
+  const int64_t LDO = LD64 ? 64 : g.ldo;
   const float* xb = g.x + 4 * l8;
   const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * LDY : nullptr;
   const float* zrow = shmp16_zero_row + 4 * l8;
@@ -380,6 +389,17 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     rpb[RPN] = 0;
   }
   int ebase = __builtin_amdgcn_readfirstlane(rp[0]);     // (wave-uniform values are kept in SGPRs)
+  // id range [ebn, een) of the NEXT tile: two scalar loads, one tile ahead of the LDS-direct load of the ids
+  int ebn = 0, een = 0;
+  {
+    const int64_t w0n = (tile + tstride) * (NW * WR) + wave * WR;
+    if (S > 0 && tile + tstride < tend && w0n < g.num_rows) {
+      const int nrn = (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR);
+      const int32_t* q_ = rowptr_s + (g.row0 + w0n) * S;
+      ebn = q_[0];
+      een = q_[nrn * S];
+    }
+  }
 
   float4 lo0, lo1, hi0, hi1;                               // gathered sums of the current block
   float4 u00, u01, u10, u11;                               // in flight: first source (lo, hi) of row it
@@ -401,31 +421,36 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int64_t w0n = tn * (NW * WR) + wave * WR;
     const bool has_next = tn < tend && w0n < g.num_rows;
     const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
-    // global -> LDS directly (no staging registers): lane i's dword lands at rpn[i]
-    if (has_next && S > 0) {
-      const int nptr = nrn * S + 1;
-      const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
-      DESCO_DMA4(src + (lane < nptr ? lane : nptr - 1), rpn);
-      if (lane + 64 < nslot) DESCO_DMA4(src + (lane + 64 < nptr ? lane + 64 : nptr - 1), rpn + 64);
-    }
     int* ecn = ecb + (cur ^ 1) * WCAP;
-    int ebn = 0, ecntn = 0;
+    const int ebn_cur = ebn, een_cur = een;                    // (id range of the next tile)
+    // id range of the tile after the next (scalar loads; consumed in the next iteration)
+    {
+      const int64_t t2 = tn + tstride;
+      const int64_t w02 = t2 * (NW * WR) + wave * WR;
+      ebn = 0;
+      een = 0;
+      if (S > 0 && t2 < tend && w02 < g.num_rows) {
+        const int nr2 = (int)((g.num_rows - w02) < WR ? (g.num_rows - w02) : WR);
+        const int32_t* q_ = rowptr_s + (g.row0 + w02) * S;
+        ebn = q_[0];
+        een = q_[nr2 * S];
+      }
+    }
     // fused pooling: this tile's segment-end bitmap and first partial slot (wave-uniform address:
     // scalar loads, in flight under the whole tile)
     uint32_t pool_e = 0;
     int pool_s = 0;
     if constexpr (POOL) {
       const int t16 = __builtin_amdgcn_readfirstlane((int)(grow0 >> 4));
-      pool_e = g.pool_bits[t16];
-      pool_s = g.pool_slot[t16];
+      pool_e = pool_bits_s[t16];
+      pool_s = pool_slot_s[t16];
     }
 
     // ---- accumulator init: bias ----------------------------------------------------------------
     f32x4 q0, q1, q2, q3;                        // 16 rows x 64 columns: four 16-column tiles
     {
       const int c_ = lane & 15;
-      const float b0_ = g.bias ? g.bias[c_] : 0.f, b1_ = g.bias ? g.bias[16 + c_] : 0.f;
-      const float b2_ = g.bias ? g.bias[32 + c_] : 0.f, b3_ = g.bias ? g.bias[48 + c_] : 0.f;
+      const float b0_ = biasL[c_], b1_ = biasL[16 + c_], b2_ = biasL[32 + c_], b3_ = biasL[48 + c_];
       q0 = f32x4{b0_, b0_, b0_, b0_};
       q1 = f32x4{b1_, b1_, b1_, b1_};
       q2 = f32x4{b2_, b2_, b2_, b2_};
@@ -456,19 +481,20 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
           DESCO_COOP(0, yb + 64, LDY) DESCO_COOP(1, yb + 64, LDY)
         }
       }
-      if (b == KB - 1 && has_next) {
-        // next tile's row pointers have landed (the self rows just consumed were issued after them and
-        // vector memory returns in order: the wait is free, it orders the LDS reads behind the
-        // LDS-direct load, which the compiler does not track); then fetch its source ids
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ebn = __builtin_amdgcn_readfirstlane(rpn[0]);
-        ecntn = __builtin_amdgcn_readfirstlane(rpn[WR * S]) - ebn;
-        const int32_t* src = (g.vcol + ebn) + (unsigned)lane;    // uniform base + 32-bit lane offset
-        const int ne = ecntn < WCAP ? ecntn : WCAP;
-        if (lane < ne) DESCO_DMA4(src, ecn);
-        if (lane + 64 < ne) DESCO_DMA4(src + 64, ecn + 64);
-        if (lane + 128 < ne) DESCO_DMA4(src + 128, ecn + 128);
-        if (lane + 192 < ne) DESCO_DMA4(src + 192, ecn + 192);
+      if (b == KB - 1 && has_next && S > 0) {
+        // CSR slice of the next tile, global -> LDS directly (no staging registers): lane i's dword lands
+        // at rpn[i] / ecn[i].  Issued behind the last relation-slot block: vector memory returns in order,
+        // and the on-demand steps of heavy rows should not queue behind these (slow) LDS-direct loads
+        const int nptr = nrn * S + 1;
+        const int32_t* src = g.vrowptr + (g.row0 + w0n) * S;
+        DESCO_DMA4(src + (lane < nptr ? lane : nptr - 1), rpn);
+        if (lane + 64 < nslot) DESCO_DMA4(src + (lane + 64 < nptr ? lane + 64 : nptr - 1), rpn + 64);
+        const int32_t* ids = (g.vcol + ebn_cur) + (unsigned)lane;    // uniform base + 32-bit lane offset
+        const int ne = (een_cur - ebn_cur) < WCAP ? (een_cur - ebn_cur) : WCAP;
+        if (lane < ne) DESCO_DMA4(ids, ecn);
+        if (lane + 64 < ne) DESCO_DMA4(ids + 64, ecn + 64);
+        if (lane + 128 < ne) DESCO_DMA4(ids + 128, ecn + 128);
+        if (lane + 192 < ne) DESCO_DMA4(ids + 192, ecn + 192);
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
@@ -503,11 +529,14 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int64_t grow_out = grow0;
     const int nr_out = nr;
     if (has_next) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ids of the next tile are in LDS
+      // the next tile's row pointers and ids are in LDS (every gather of this tile has been consumed:
+      // nothing else is outstanding, the wait orders the LDS reads behind the LDS-direct loads, which the
+      // compiler does not track)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ec = ecn;
       cur ^= 1;
       rp = rpn;
-      ebase = ebn;
+      ebase = ebn_cur;
       tile = tn;
       w0 = w0n;
       nr = nrn;
@@ -554,12 +583,20 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g) {
     const int nru = __builtin_amdgcn_readfirstlane(nr_out);
 #define DESCO_ROW(r_) ((r_) < 4 ? q0[(r_) & 3] : (r_) < 8 ? q1[(r_) & 3] : (r_) < 12 ? q2[(r_) & 3] : q3[(r_) & 3])
     if (!POOL || g.out) {
+      float* ob = g.out + grow_out * LDO + lane;               // LD64: row r at the immediate offset 256 r
+      if (nru == 16) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (r < nru) {
-          g.out[(grow_out + r) * g.ldo + lane] = DESCO_ROW(r);
-          if (g.out2) g.out2[(grow_out - g.row0 + r) * g.ldo2 + lane] = DESCO_ROW(r);
-        }
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < nru) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
+      }
+      if (g.out2) {
+        float* o2 = g.out2 + (grow_out - g.row0) * g.ldo2 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < nru) o2[r * g.ldo2] = DESCO_ROW(r);
       }
     }
     if constexpr (POOL) {
@@ -614,7 +651,7 @@ template <int NW, int KB, int ST, bool LD64, bool POOL>
 static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 16;
   constexpr size_t w_floats = (size_t)3 * 64 * WST / 2;
-  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS);
+  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS + 64);
   static_assert(shmem <= 160 * 1024, "SHMP layer (16-row tiles): LDS budget exceeded");
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
@@ -622,12 +659,13 @@ static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) 
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.mark();
   }
-  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL>), dim3(grid), dim3(NW * 64), shmem, st, g);
+  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL>), dim3(grid), dim3(NW * 64), shmem, st, g,
+                     g.vrowptr, g.pool_bits, g.pool_slot);
 }
 
 template <int NW, int KB>
 static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
-  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st);
+  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st) && (!g.out || g.ldo == 64);
   if (g.pool_part) {
     if constexpr (KB == 3) {
       if (g.st != 2) return false;
