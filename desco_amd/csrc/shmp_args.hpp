@@ -33,7 +33,5 @@ struct ShmpArgs {
 
 // 16-row-tile form (shmp_layer16.hip); returns false when the shape is not one it is built for
 bool shmp16_launch(const ShmpArgs& g, int cus, void* stream);
-// 16-row tiles with the gathers issued one tile ahead (shmp_layer16t.hip), same contract
-bool shmp16t_launch(const ShmpArgs& g, int cus, void* stream);
 
 }  // namespace desco

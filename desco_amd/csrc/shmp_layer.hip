@@ -838,11 +838,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              tile_rows};
   hipStream_t st = (hipStream_t)stream;
   if (x6 && tile_rows == 16) {
-    static const bool block_pipe = [] {            // A/B runs: the block-pipelined 16-row kernel
-      const char* e = getenv("DESCO_SHMP_PIPE");
-      return e && e[0] == 'b';
-    }();
-    if (!(block_pipe ? shmp16_launch(g, cus, stream) : shmp16t_launch(g, cus, stream))) return fail(DESCO_EINVAL, "desco_shmp_layer_bf16x6_f32: shape not built");
+    if (!shmp16_launch(g, cus, stream)) return fail(DESCO_EINVAL, "desco_shmp_layer_bf16x6_f32: shape not built");
     return launch_status(who);
   }
   if (x6) {

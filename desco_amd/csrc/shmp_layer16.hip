@@ -113,15 +113,19 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
   const int nb_ = ST > 1 ? rp[v_ + 2] - ebase : na_;                                        \
   const bool k0_ = ca_ < (na_ < WCAP ? na_ : WCAP);                                         \
   const bool k1_ = ST > 1 && na_ < (nb_ < WCAP ? nb_ : WCAP);
+// (a table slot without a source among the tile's rows -- live bits 8, 9 -- is neither loaded nor added:
+// only the rows next to the canonical node have one, half of the Syn_1827 tiles have none at all)
 #define DESCO_ISSUE_TAB(it_)                                                                \
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
     const int i0_ = ec[k0_ ? ca_ : 0], i1_ = ec[k1_ ? na_ : 0];                             \
-    const float* p0_ = k0_ ? yb + (int64_t)i0_ * LDY : zrow;                              \
-    u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                      \
-    u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                                 \
-    if (ST > 1) {                                                                           \
-      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * LDY : zrow;                       \
+    if (live & 0x100) {                                                                     \
+      const float* p0_ = k0_ ? yb + (int64_t)i0_ * LDY : zrow;                              \
+      u##it_##0 = *reinterpret_cast<const float4*>(p0_);                                    \
+      u##it_##1 = *reinterpret_cast<const float4*>(p0_ + 32);                               \
+    }                                                                                       \
+    if (ST > 1 && (live & 0x200)) {                                                         \
+      const float* p1_ = k1_ ? yb + 64 + (int64_t)i1_ * LDY : zrow;                         \
       w##it_##0 = *reinterpret_cast<const float4*>(p1_);                                    \
       w##it_##1 = *reinterpret_cast<const float4*>(p1_ + 32);                               \
     }                                                                                       \
@@ -130,9 +134,11 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #define DESCO_CONSUME_TAB(it_)                                                              \
   {                                                                                         \
     DESCO_TAB_CUR(it_)                                                                      \
-    f4add(lo##it_, u##it_##0);                                                              \
-    f4add(hi##it_, u##it_##1);                                                              \
-    if (ST > 1) {                                                                           \
+    if (live & 0x100) {                                                                     \
+      f4add(lo##it_, u##it_##0);                                                            \
+      f4add(hi##it_, u##it_##1);                                                            \
+    }                                                                                       \
+    if (ST > 1 && (live & 0x200)) {                                                         \
       f4add(lo##it_, w##it_##0);                                                            \
       f4add(hi##it_, w##it_##1);                                                            \
     }                                                                                       \
@@ -205,16 +211,18 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
     }                                                                                      \
   }
 // bit s of `live`: relation slot s (an MFMA slot) has at least one source among the wave's 16 rows
-#define DESCO_SLOT_LIVE(s_)                                                                \
+#define DESCO_SLOT_ANY(s_)                                                                 \
   (__any((rp[(0 * 8 + g8) * S + (s_) + 1] > rp[(0 * 8 + g8) * S + (s_)]) |                  \
-         (rp[(1 * 8 + g8) * S + (s_) + 1] > rp[(1 * 8 + g8) * S + (s_)]))                   \
-       ? 1 << (s_) : 0)
+         (rp[(1 * 8 + g8) * S + (s_) + 1] > rp[(1 * 8 + g8) * S + (s_)])) != 0)
+#define DESCO_SLOT_LIVE(s_) (DESCO_SLOT_ANY(s_) ? 1 << (s_) : 0)
 #define DESCO_TILE_LIVE()                                        \
   {                                                              \
     live = 0;                                                    \
     if (KB - 1 > 0) live |= DESCO_SLOT_LIVE(0);                  \
     if (KB - 1 > 1) live |= DESCO_SLOT_LIVE(1);                  \
     if (KB - 1 > 2) live |= DESCO_SLOT_LIVE(2);                  \
+    if (ST > 0) live |= DESCO_SLOT_ANY(g.sm) ? 0x100 : 0;        \
+    if (ST > 1) live |= DESCO_SLOT_ANY(g.sm + 1) ? 0x200 : 0;    \
   }
 // first step of the first LIVE block after block a_ (a_ = -1: of the tile); dead slots are left
 // out of the software pipeline altogether, so the block behind one is not issued late.  The slot
@@ -232,7 +240,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
       } else {                                                                             \
         DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1)                                            \
       }                                                                                    \
-    } else if ((a_) + 1 < NB) {                                                            \
+    } else if ((a_) + 1 < NB && (live & 0x300)) {                                          \
       DESCO_ISSUE_BLOCK((a_) + 1)                                                          \
     }                                                                                      \
   }
@@ -461,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < KB - 1 && !((live >> b) & 1)) continue;      // empty relation slot (wave-uniform)
+      if (b >= KB && !(live & 0x300)) continue;            // no table source in the tile
       // ---- complete the gather of block b ------------------------------------------------------
       DESCO_ZERO_SUMS()
       if (b < KB - 1) {
@@ -638,6 +647,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_COOP
 #undef DESCO_FINISH
 #undef DESCO_ISSUE_BLOCK
+#undef DESCO_SLOT_ANY
 #undef DESCO_SLOT_LIVE
 #undef DESCO_TILE_LIVE
 #undef DESCO_ISSUE_AFTER
