@@ -42,7 +42,12 @@ struct GemmSplitArgs {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-constexpr int SBK = 32, SST = 40;              // SST: plane row stride in bf16 (80 B)
+constexpr int SBK = 32, SST = 32;              // SST: plane row stride in bf16 (64 B, no padding)
+// 16-byte chunk c (0..3) of plane row r sits at chunk c ^ ((r >> 3) & 3): conflict-free for the fragment
+// reads (ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: their rows differ in r & 3 or in
+// (r >> 3) & 3) and for the staging stores (two whole 64-B rows per 128-B write window; the 80-B padded
+// rows were 2-way conflicted on every store: tools/micro/lds_banks.py, SQ_LDS_BANK_CONFLICT 0.33)
+__device__ __forceinline__ int gs_chunk(const int row, const int c) { return ((c ^ (row >> 3)) & 3) << 3; }
 
 // NP = 3: hi/mid/lo planes and six products (fp32-accurate); NP = 1: one round-to-nearest bf16 plane
 // and one product (plain bf16 MFMA with fp32 accumulation, the bf16 training mode).
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
   }
 #define DESCO_PUT(row_, v_)                                                                   \
   {                                                                                           \
-    short* d_ = Ap + (row_)*SST + 4 * ac4;                                                    \
+    short* d_ = Ap + (row_)*SST + gs_chunk((row_), ac4 >> 1) + 4 * (ac4 & 1);                 \
     if constexpr (NP == 3) {                                                                  \
       uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                  \
       split2_bf16x3(v_.x, v_.y, h0_, m0_, l0_);                                               \
@@ -143,10 +148,11 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
   }
 #define DESCO_STORE_WJ(j_, v_)                                                                \
   if (BJ > (j_) && (v_)) {                                                                    \
-    *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST) = rb##j_##0;                              \
+    short* bj_ = Bp + (brow + (j_) * BR) * SST + gs_chunk(brow + (j_) * BR, bpart);           \
+    *reinterpret_cast<uint4*>(bj_) = rb##j_##0;                                               \
     if constexpr (NP == 3) {                                                                  \
-      *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST + BPLANE) = rb##j_##1;                   \
-      *reinterpret_cast<uint4*>(b_ + (j_) * BR * SST + 2 * BPLANE) = rb##j_##2;               \
+      *reinterpret_cast<uint4*>(bj_ + BPLANE) = rb##j_##1;                                    \
+      *reinterpret_cast<uint4*>(bj_ + 2 * BPLANE) = rb##j_##2;                                \
     }                                                                                         \
   }
 #define DESCO_STORE_CHUNK()                                                                   \
@@ -155,7 +161,6 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
     DESCO_PUT(arow + AR, ra1)                                                                 \
     DESCO_PUT(arow + 2 * AR, ra2)                                                             \
     DESCO_PUT(arow + 3 * AR, ra3)                                                             \
-    short* b_ = Bp + brow * SST + 8 * bpart;                                                  \
     DESCO_STORE_WJ(0, v0) DESCO_STORE_WJ(1, v1) DESCO_STORE_WJ(2, v2)                         \
   }
 
@@ -180,22 +185,25 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
     DESCO_LOAD_W(chn * SBK)                // in flight under the MFMAs
     DESCO_LOAD_A(rn, chnn * SBK)           // two chunks ahead (HBM latency)
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
-    const short* ap = Ap + (wr * 64 + (lane & 31)) * SST + 8 * (lane >> 5);
-    const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST + 8 * (lane >> 5);
+    // (row + 32 i / 32 j keeps (row >> 3) & 3, so one swizzle per lane serves every tile)
+    const int fsw = (lane >> 3) & 3, fh = lane >> 5;
+    const short* ap = Ap + (wr * 64 + (lane & 31)) * SST;
+    const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST;
 #pragma unroll
     for (int s = 0; s < SBK / 16; ++s) {
       bf16x8 ah[2], am[2], al[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 16 * s);
+        const int co = (((2 * s + fh) ^ fsw) & 3) << 3;
+        ah[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + co);
         if constexpr (NP == 3) {
-          am[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + APLANE + 16 * s);
-          al[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 2 * APLANE + 16 * s);
+          am[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + APLANE + co);
+          al[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * SST + 2 * APLANE + co);
         }
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const short* bt = bp + j * 32 * SST + 16 * s;
+        const short* bt = bp + j * 32 * SST + ((((2 * s + fh) ^ fsw) & 3) << 3);
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bt);
         if constexpr (NP == 3) {
           const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bt + BPLANE);

@@ -63,3 +63,9 @@ if __name__ == "__main__":
             report(f"shmp16 table write AH={ah} (b128)", "write_b128", lambda l: ((l >> 3) * ah + 4 * (l & 7)) * 4)
         else:
             report(f"shmp16 table write AH={ah} (4 x b32)", "write_b32", lambda l: ((l >> 3) * ah + 4 * (l & 7)) * 4)
+    # gemm_split: A/W planes [rows][SST] bf16; fragment read lane (r = l & 31, h = l >> 5) at row r, 8 h shorts;
+    # A store: thread t -> row t >> 3, 8 bytes at 8 (t & 7); W store: row t >> 2, 16 bytes at 16 (t & 3)
+    for sst in (40, 48, 56, 72, 80, 88):
+        a = report(f"gemm_split fragment read, row stride {sst} shorts", "read_b128", lambda l: (l & 31) * sst * 2 + (l >> 5) * 16)
+        b = report(f"gemm_split A store (b64), row stride {sst}", "write_b64", lambda l: (l >> 3) * sst * 2 + (l & 7) * 8)
+        c = report(f"gemm_split W store (b128), row stride {sst}", "write_b128", lambda l: (l >> 2) * sst * 2 + (l & 3) * 16)
