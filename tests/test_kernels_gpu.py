@@ -225,6 +225,39 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
 
+@pytest.mark.parametrize("S,sm,st", [(4, 2, 2), (4, 2, 0), (2, 1, 0)])
+def test_fused_shmp_layer_strided_operands(S, sm, st):
+    """The general-stride instantiations of the bf16x6 layer kernel (LD64 = false): x, the table and the
+    output are column blocks of wider tensors (ldx = 96, ldy = 64 st + 32, ldo = 128)."""
+    num_rows, row0, max_deg = 3000, 16, 7
+    g = torch.Generator().manual_seed(77 + S + sm + st)
+    n_all = row0 + num_rows + 5
+    xw = torch.randn(n_all, 96, generator=g)
+    x = xw[:, 16:80]
+    ptr, col, cnt = _random_vcsr(n_all, S, max_deg, n_all, g)
+    wt = torch.randn((sm + 1) * 64, 64, generator=g) / 12
+    bias = torch.randn(64, generator=g)
+    agg = torch.zeros(n_all * S, 64, dtype=torch.double)
+    agg.index_add_(0, torch.repeat_interleave(torch.arange(n_all * S), cnt), x.double()[col.long()])
+    aggv = agg.view(n_all, S * 64)
+    ref = torch.cat([aggv[:, :sm * 64], x.double()], 1) @ wt.double() + bias.double()
+    ytab = None
+    if st:
+        wtab = torch.randn(64, 64 * st, generator=g) / 8
+        yw = torch.zeros(n_all, 64 * st + 32)
+        yw[:, :64 * st] = x @ wtab
+        for s in range(st):
+            ref = ref + aggv[:, (sm + s) * 64:(sm + s + 1) * 64] @ wtab.double()[:, s * 64:(s + 1) * 64]
+        ytab = yw.to(DEV)[:, :64 * st]
+    ref = torch.relu(ref)[row0:row0 + num_rows]
+    outw = torch.full((n_all, 128), -7.0, device=DEV)
+    out = outw[:, 32:96]
+    ops.shmp_layer(xw.to(DEV)[:, 16:80], ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm,
+                   ops.split_bf16_planes(wt.t().contiguous().to(DEV)), bias.to(DEV), out, ytab=ytab, ytab_row0=0)
+    _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
+    assert (outw[:, :32] == -7.0).all() and (outw[:, 96:] == -7.0).all() and (outw[:row0] == -7.0).all()
+
+
 @pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (300, 256, 64, 64), (5000, 128, 64, 64), (70001, 576, 0, 576),
                                        (4097, 64, 0, 256)])
 def test_linear_bwd_w_fused_weight_and_bias_gradient(m, k1, k2, n):
