@@ -746,11 +746,8 @@ static bool shmp16_launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
 // x6 arguments validated by shmp_launch (shmp_layer.hip); g.wplanes set, g.sm <= 2
 bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
   if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
-  static const int nw = [] {
-    const char* e = getenv("DESCO_SHMP16_NW");
-    return e && atoi(e) == 12 ? 12 : 16;     // 12: A/B runs only
-  }();
-  return nw == 16 ? shmp16_launch_nw<16>(g, cus, (hipStream_t)stream) : shmp16_launch_nw<12>(g, cus, (hipStream_t)stream);
+  // 16 waves per block (12 x 16 rows measured 2-6 % slower: profiles/r2_h_ab_tile_rows.log)
+  return shmp16_launch_nw<16>(g, cus, (hipStream_t)stream);
 }
 
 }  // namespace desco
