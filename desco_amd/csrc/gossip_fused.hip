@@ -38,8 +38,10 @@ constexpr int GT = 128;            // rows (nodes) per tile
 constexpr int GNT = 512;           // threads per block
 constexpr int PLN = GT * 64;       // shorts per activation plane
 constexpr int WPLN = 64 * 64;      // shorts per weight-block plane
-constexpr int PCAP = 512;          // neighbour records prefetched (one per thread) for the next tile
-constexpr int ECAP = 1024;         // neighbour records staged per pass (aliases weight buffer 1)
+constexpr int PCAP = 1216;         // neighbour records prefetched (up to three per thread) for the next tile: a 128-node tile
+                                   // of MSRC-21 / IMDB-shaped graphs has ~900 (512 sent nearly every such tile through
+                                   // the staged passes below: two barriers and two dependent global round trips each)
+constexpr int ECAP = 1216;         // neighbour records staged per pass (aliases weight buffer 1: 20 B each)
 constexpr int CST = 832;           // u, d1, tp, b3 (64 each), b5, w7 (256 each), zp_q (64)
 constexpr size_t GOSSIP_LDS_BYTES = (size_t)2 * 3 * PLN * 2 + (size_t)2 * 3 * WPLN * 2 + GT * 16 +
                                     132 * 4 + CST * 4 + 2 * GT * 4;
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   // The (rowptr -> col -> scalar record) chain of the NEXT item is fetched into these registers
   // in three stages spread over the current item's GEMMs and published to LDS when the current
   // item is done: a tile does not start with three dependent global-memory latencies.
-  float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow;
-  int n_rp = 0, n_col = 0, n_ebeg = 0, n_cnt = 0;
+  float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow, n_scal2 = n_srow, n_scal3 = n_srow;
+  int n_rp = 0, n_col = 0, n_col2 = 0, n_col3 = 0, n_ebeg = 0, n_cnt = 0;
   float n_zp = 0.f, n_gq = 0.f;            // the next item's per-query vectors (this lane's slice)
   float2 n_pc = make_float2(0.f, 0.f), n_zc = n_pc;
   const int f0 = 2 * (lane & 31);          // phase-1 lane map: features (f0, f0+1)
@@ -295,9 +297,17 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     n_zc = *reinterpret_cast<const float2*>(g.z + q_ * 64 + f0);                           \
   }
 #define GF_STAGE2() \
-  if (tid < n_cnt) n_col = g.col[n_ebeg + tid];
+  {                                                          \
+    if (tid < n_cnt) n_col = g.col[n_ebeg + tid];            \
+    if (tid + GNT < n_cnt) n_col2 = g.col[n_ebeg + tid + GNT]; \
+    if (tid + 2 * GNT < n_cnt) n_col3 = g.col[n_ebeg + tid + 2 * GNT]; \
+  }
 #define GF_STAGE3(it_) \
-  if (tid < n_cnt) n_scal = g.scal[(int64_t)n_col * Q + (int)((it_) % Q)];
+  {                                                                                          \
+    if (tid < n_cnt) n_scal = g.scal[(int64_t)n_col * Q + (int)((it_) % Q)];                 \
+    if (tid + GNT < n_cnt) n_scal2 = g.scal[(int64_t)n_col2 * Q + (int)((it_) % Q)];         \
+    if (tid + 2 * GNT < n_cnt) n_scal3 = g.scal[(int64_t)n_col3 * Q + (int)((it_) % Q)];     \
+  }
 
   GF_STAGE1(item)
   GF_STAGE2()
@@ -316,6 +326,14 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     if (tid < n_cnt) {
       ecol[tid] = n_col;
       escal[tid] = n_scal;
+      if (tid + GNT < n_cnt) {
+        ecol[tid + GNT] = n_col2;
+        escal[tid + GNT] = n_scal2;
+      }
+      if (tid + 2 * GNT < n_cnt) {
+        ecol[tid + 2 * GNT] = n_col3;
+        escal[tid + 2 * GNT] = n_scal3;
+      }
     }
     if (tid < 64) cst[768 + tid] = n_zp;
     const float gq = n_gq;                 // (a tile does not start with a global-memory round trip)
