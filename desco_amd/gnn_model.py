@@ -35,6 +35,7 @@ SHMP_BF16X6 = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
+_RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
 # metadata of to_hetero_old(tconv_target=True), lightning_model.py:376-383
@@ -452,6 +453,11 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
                     ops.gemm(agg[r0:r1, :su * H], e["wt"], e["b"], a2=X[-1][r0:r1],
                              act=ops.ACT_RELU, out=xn[r0:r1])
         X.append(xn)
+        if fpool and direct_canon and l >= 2 and l in pool_parts:
+            # layer l's rows have been consumed (their pooled sums sit in pool_parts[l], their canonical
+            # rows in `canon`): release them -- a block then holds three [N, 64] tensors instead of nine,
+            # which is what lets InferencePipeline run blocks of tens of millions of rows
+            X[l] = _RELEASED
     pooled = torch.empty((B, P), device=dev)
     if isinstance(batch, NeighborhoodBatch):
         c0 = x0["canonical"].expand(B, H) if const_input else X[0][Nc:]
@@ -473,14 +479,14 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     for l, xl in enumerate(X):                                             # :88-89, :107
         extra = None if anch is None else anch[:, l * H:(l + 1) * H]
         out_l = pooled[:, l * H:(l + 1) * H]
-        if xl is None:       # constant X_0: the segment sum is (rows in segment) * x0
+        if l in pool_parts:
+            ops.pool_reduce(pool_parts[l], pbits, pslot, seg_ptr, B, extra=extra, out=out_l)
+        elif xl is None:     # constant X_0: the segment sum is (rows in segment) * x0
             t0 = groups[0][0]
             ck = ("pool0_coef", t0)
             if ck not in pk:
                 pk[ck] = torch.stack([x0[t0], torch.zeros(H, device=dev)]).contiguous()
             ops.degree_affine(seg_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, out_l, extra=extra)
-        elif l in pool_parts:
-            ops.pool_reduce(pool_parts[l], pbits, pslot, seg_ptr, B, extra=extra, out=out_l)
         else:
             ops.segment_sum(xl[:Nc], seg_ptr, B, extra=extra, out=out_l)
     return _post_mp(pk, pooled)                                            # :108
