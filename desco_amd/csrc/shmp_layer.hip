@@ -658,6 +658,15 @@ __global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
     u##it_##0 = *reinterpret_cast<const float4*>(p_);                              \
     u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                         \
   }
+  // bias of the lane's two columns per output block, once: a load inside the tile loop is waited for at
+  // the accumulator init, and vector memory returns in order -- the wait would also drain the prefetch of
+  // the next tile's rows issued just before it
+  float bv[NJ][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    bv[j][0] = g.bias ? g.bias[64 * j + cl] : 0.f;
+    bv[j][1] = g.bias ? g.bias[64 * j + 32 + cl] : 0.f;
+  }
   DESCO_LIN_LOAD(0) DESCO_LIN_LOAD(1) DESCO_LIN_LOAD(2) DESCO_LIN_LOAD(3)
   for (;;) {
     const float4 lo0 = u00, hi0 = u01, lo1 = u10, hi1 = u11, lo2 = u20, hi2 = u21, lo3 = u30, hi3 = u31;
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
       const short* Wp = wbase + j * 3 * WPL;
       f32x16 acc0, acc1;
       {
-        const float bv0 = g.bias ? g.bias[64 * j + cl] : 0.f, bv1 = g.bias ? g.bias[64 * j + 32 + cl] : 0.f;
+        const float bv0 = bv[j][0], bv1 = bv[j][1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           acc0[i] = bv0;
@@ -687,13 +696,23 @@ __global__ __launch_bounds__(NW * 64) void linear64_kernel(Lin64Args g) {
       DESCO_MFMA_HALF_X6(0, 0)
       DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1) DESCO_PUT_X6(hi2, 2) DESCO_PUT_X6(hi3, 3)
       DESCO_MFMA_HALF_X6(0, 1)
+      if (nr == WR) {                       // whole tile: one base address, no per-row tests
+        float* o = g.out + (row_out + 4 * (lane >> 5)) * g.ldo + 64 * j + cl;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (r < nr) {
-          float* o = g.out + (row_out + r) * g.ldo + 64 * j + cl;
-          o[0] = apply_act(acc0[reg], g.act, g.slope);
-          o[32] = apply_act(acc1[reg], g.act, g.slope);
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2);
+          __builtin_nontemporal_store(apply_act(acc0[reg], g.act, g.slope), o + r * g.ldo);
+          __builtin_nontemporal_store(apply_act(acc1[reg], g.act, g.slope), o + r * g.ldo + 32);
+        }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+          if (r < nr) {
+            float* o = g.out + (row_out + r) * g.ldo + 64 * j + cl;
+            o[0] = apply_act(acc0[reg], g.act, g.slope);
+            o[32] = apply_act(acc1[reg], g.act, g.slope);
+          }
         }
       }
     }
