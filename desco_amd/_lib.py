@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdesco_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "desco_linear_bwd_w_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i32, vp, i64, vp, vp, vp]),
     "desco_colsum_f32": (c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),
+    "desco_count_head_bwd_workspace": (ctypes.c_size_t, [i64, i32, i32]),
     "desco_count_head_bwd_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, i64, i64, i32, vp, i64,
                                          vp, vp, vp, vp]),
     "desco_affine_rows_f32": (c_int, [vp, vp, i32, vp, i32, i32, f32, vp, i64, vp]),

@@ -9,8 +9,9 @@ mention other ``pytorch_lightning.*`` or ``subgraph_counting.*`` classes -- unpi
 packages this build does not have (reference: lightning_model.py:508-532 relies on
 ``pl.LightningModule.load_from_checkpoint``).
 
-``load_checkpoint`` unpickles with a RESTRICTED class resolver: torch / numpy / stdlib containers
-resolve normally, ``pytorch_lightning.*`` / ``lightning.*`` / ``subgraph_counting.*`` /
+``load_checkpoint`` unpickles with a RESTRICTED class resolver: an exact allow-list of (module, name)
+pairs -- the tensor rebuild functions, storages, dtypes, stdlib containers, Namespace, numpy arrays --
+resolves normally, ``pytorch_lightning.*`` / ``lightning.*`` / ``subgraph_counting.*`` /
 ``torchmetrics.*`` names resolve to inert stand-ins (``AttributeDict`` -> a dict subclass, anything
 else -> an attribute bag), and every other global is refused -- a checkpoint cannot run code here.
 """
@@ -26,8 +27,36 @@ import torch
 
 _STANDIN_PREFIXES = ("pytorch_lightning", "lightning", "lightning_fabric", "subgraph_counting",
                      "torchmetrics", "deepsnap", "torch_geometric")
-_SAFE_MODULES = ("torch", "numpy", "collections", "argparse", "builtins", "_codecs", "copyreg",
-                 "pathlib", "datetime", "functools", "typing", "enum")
+# Exact (module, name) pairs a tensor / container / Namespace checkpoint can legitimately refer to.
+# Nothing else resolves: a module-wide allow-list is NOT safe (torch.utils.collect_env.run,
+# torch.storage._load_from_bytes, numpy.testing._private.utils.runstring ... all execute code).
+_TORCH_STORAGES = tuple(t + "Storage" for t in (
+    "Float", "Double", "Half", "BFloat16", "Long", "Int", "Short", "Char", "Byte", "Bool",
+    "ComplexFloat", "ComplexDouble", "Untyped"))
+_TORCH_DTYPES = ("float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8",
+                 "bool", "complex64", "complex128", "float", "double", "half", "long", "int", "short")
+_ALLOWED = {
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"),
+    ("torch._tensor", "_rebuild_from_type_v2"), ("torch.nn.parameter", "Parameter"),
+    ("torch.serialization", "_get_layout"), ("torch", "strided"),
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque"),
+    ("argparse", "Namespace"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"),
+    ("copyreg", "_reconstructor"),
+    ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"),
+    ("datetime", "timedelta"), ("datetime", "datetime"),
+}
+_ALLOWED |= {("torch", n) for n in _TORCH_STORAGES} | {("torch.storage", "UntypedStorage"),
+                                                       ("torch.storage", "TypedStorage")}
+_ALLOWED |= {("torch", n) for n in _TORCH_DTYPES}
+_ALLOWED |= {("builtins", n) for n in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool",
+                                       "str", "bytes", "bytearray", "complex", "slice", "range", "object")}
+_ALLOWED |= {("numpy.dtypes", n) for n in ("Float32DType", "Float64DType", "Int64DType", "Int32DType",
+                                           "BoolDType", "UInt8DType", "Int8DType", "Int16DType")}
 
 
 class AttributeDict(dict):
@@ -67,17 +96,18 @@ def _standin(module: str, name: str):
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str):
+        # protocol-4 dotted names ("object.__getattribute__", "_sys.modules") walk attributes of an
+        # allowed global: never needed by a checkpoint, always refused
+        if "." in name:
+            raise pickle.UnpicklingError(f"checkpoint refers to the dotted name {module}:{name}: refused")
         top = module.split(".")[0]
         if top in _STANDIN_PREFIXES:
             return _standin(module, name)
-        if top in _SAFE_MODULES:
-            if top == "builtins" and name in ("eval", "exec", "compile", "open", "__import__", "getattr",
-                                              "setattr", "delattr", "input", "breakpoint"):
-                raise pickle.UnpicklingError(f"checkpoint refers to builtins.{name}: refused")
+        if (module, name) in _ALLOWED:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(
             f"checkpoint refers to {module}.{name}: not a tensor / container / Namespace -- refused "
-            "(desco_amd.ckpt loads checkpoints with a restricted unpickler)")
+            "(desco_amd.ckpt loads checkpoints with a restricted unpickler: exact allow-list)")
 
 
 class _PickleModule:

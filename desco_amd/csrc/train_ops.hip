@@ -408,6 +408,20 @@ extern "C" int desco_act_grad_f32(const float* dc, const float* c, int act, floa
   return launch_status("desco_act_grad_f32");
 }
 
+static int64_t count_head_bwd_splits(int64_t num_b) {
+  // slabs of >= 16 target rows, up to 1024 of them: a reference-size batch (512 rows) used to run on
+  // 8 blocks of 64 threads with 7 400 dependent iterations each (0.9 ms of a 7 ms training step)
+  int64_t splits = (num_b + 15) / 16;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+extern "C" size_t desco_count_head_bwd_workspace(int64_t num_b, int num_q, int hid) {
+  if (num_b < 0 || num_q < 1 || hid <= 0) return 0;
+  return (size_t)count_head_bwd_splits(num_b) * (size_t)(num_q + 1) * (size_t)hid * sizeof(float);
+}
+
 extern "C" int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq,
                                         int hid, const float* w2, float slope, const float* dl,
                                         int64_t lddl, int64_t num_b, int num_q, float* dt,
@@ -420,11 +434,7 @@ extern "C" int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float
   if (num_b > 0)
     hipLaunchKernelGGL(count_head_bwd_t_kernel, dim3((unsigned)((num_b + 3) / 4)), dim3(256), 0, st, t,
                        ldt, qh, ldq, hid, w2, slope, dl, lddl, dt, lddt, num_b, num_q);
-  // slabs of >= 16 target rows, up to 1024 of them: a reference-size batch (512 rows) used to run on
-  // 8 blocks of 64 threads with 7 400 dependent iterations each (0.9 ms of a 7 ms training step)
-  int64_t splits = (num_b + 15) / 16;
-  if (splits > 1024) splits = 1024;
-  if (splits < 1) splits = 1;
+  const int64_t splits = count_head_bwd_splits(num_b);
   const int64_t slab = (num_b + splits - 1) / splits;
   hipLaunchKernelGGL(count_head_bwd_q_kernel, dim3((hid + 63) / 64, (unsigned)splits), dim3(64), 0, st,
                      t, ldt, qh, ldq, hid, w2, slope, dl, lddl, num_b, num_q, slab > 0 ? slab : 1,

@@ -20,10 +20,12 @@ backend; collectives on device tensors are staged through host memory.
 """
 from __future__ import annotations
 
+import datetime
 import os
 import socket
 import subprocess
 import sys
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -75,6 +77,8 @@ def local_device(devices: Optional[Sequence[int]] = None, accelerator: str = "gp
         return torch.device("cuda", 0)
     _, world, lr = env_world()
     devs = [int(d) for d in devices] if isinstance(devices, (list, tuple)) else []
+    if not devs and os.environ.get("DESCO_DEVICES"):      # exported by ``launch(devices=...)``
+        devs = [int(d) for d in os.environ["DESCO_DEVICES"].split(",") if d != ""]
     if world > 1:
         return torch.device("cuda", devs[lr] if len(devs) >= world else lr)
     return torch.device("cuda", devs[0] if devs else 0)
@@ -101,10 +105,14 @@ def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] 
     if backend is None:
         cpu = device is None or device.type != "cuda"
         backend = "gloo" if (cpu or share_gpu()) else "nccl"
+    # collectives of this package are short; what is long is host work BETWEEN them (rank 0 building
+    # ground truth / partitions while the others wait): that phase waits on the store
+    # (``wait_for_rank0``), not in a collective, and the group timeout is generous on top
+    timeout = datetime.timedelta(seconds=float(os.environ.get("DESCO_PG_TIMEOUT_S", "7200")))
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=r, world_size=w, device_id=device)
+        dist.init_process_group("nccl", rank=r, world_size=w, device_id=device, timeout=timeout)
     else:
-        dist.init_process_group(backend, rank=r, world_size=w)
+        dist.init_process_group(backend, rank=r, world_size=w, timeout=timeout)
     if dist.get_world_size() != w:      # pragma: no cover
         raise RuntimeError("process group size mismatch")
     return True
@@ -127,15 +135,23 @@ def launch(argv: Sequence[str], nprocs: int, env: Optional[dict] = None,
         if devices is not None:
             e["DESCO_DEVICES"] = ",".join(str(int(d)) for d in devices)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    # poll ALL children: a rank that dies while the others sit in a collective must end the job
+    # (waiting for rank 0 first would hang until a watchdog fires -- never, under gloo)
     rc = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
     try:
-        for p in procs:
-            p.wait(timeout=timeout)
-            rc = rc or p.returncode
-            if p.returncode != 0:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
                 break
-    except subprocess.TimeoutExpired:
-        rc = 124
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -156,6 +172,17 @@ def _staged(t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
+class _StagedWork:
+    """Handle of an asynchronous all-reduce staged through the host (gloo on device tensors)."""
+
+    def __init__(self, work, host: torch.Tensor, dev: torch.Tensor):
+        self.work, self.host, self.dev = work, host, dev
+
+    def wait(self):
+        self.work.wait()
+        self.dev.copy_(self.host)
+
+
 def all_reduce_(t: torch.Tensor, op: str = "sum", async_op: bool = False):
     """In-place all-reduce; returns a handle with .wait() when async_op (None if already done)."""
     import torch.distributed as dist
@@ -164,6 +191,8 @@ def all_reduce_(t: torch.Tensor, op: str = "sum", async_op: bool = False):
     rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
     if _staged(t):
         h = t.detach().cpu()
+        if async_op:        # same contract as the device path: the caller may go on; .wait() lands it
+            return _StagedWork(dist.all_reduce(h, op=rop, async_op=True), h, t)
         dist.all_reduce(h, op=rop)
         t.copy_(h)
         return None
@@ -177,6 +206,30 @@ def barrier():
     import torch.distributed as dist
     if is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def rank0_first(fn: Callable, key: str = "desco_rank0_done", timeout_s: float = 7 * 86400.0):
+    """``fn()`` on rank 0 first, then on the other ranks (which then find rank 0's on-disk caches).
+    The others wait on the process group's STORE, not in a collective: a store wait has its own
+    (long) timeout and no NCCL / gloo watchdog behind it, so a cold-cache ground-truth or partition
+    build on rank 0 cannot abort the job (main.py workload construction).  A failure on rank 0 is
+    passed on instead of leaving the others waiting."""
+    import torch.distributed as dist
+    if not is_initialized() or dist.get_world_size() == 1:
+        return fn()
+    store = dist.distributed_c10d._get_default_store()
+    if dist.get_rank() == 0:
+        try:
+            out = fn()
+        except BaseException:
+            store.set(key, "fail")
+            raise
+        store.set(key, "ok")
+        return out
+    store.wait([key], datetime.timedelta(seconds=timeout_s))
+    if store.get(key) != b"ok":
+        raise RuntimeError("rank 0 failed while building the shared caches")
+    return fn()
 
 
 def broadcast_object(obj, src: int = 0):
@@ -306,19 +359,32 @@ class GradBuckets:
     all-reduce the moment it is complete -- backward of the earlier layers overlaps it.
     ``finish()`` issues the buckets whose parameters received no gradient (the never-used
     query-side ``anchor_mlp``, SURVEY A10: DDP's find_unused_parameters semantics, they reduce
-    zeros) and waits.  Collective order is identical on every rank because the autograd graph is.
+    zeros) and waits.  After the first step those parameters are moved into ONE last bucket, so that
+    from step 1 on every other bucket completes -- and is issued -- from the hooks.  Collective order is identical on every rank because the autograd graph is.
     """
 
     def __init__(self, params: Sequence[torch.nn.Parameter], num_buckets: int = 4):
         self.params = [p for p in params if p.requires_grad]
-        rev = list(reversed(self.params))
-        total = sum(p.numel() for p in rev)
-        target = max(1, -(-total // max(1, num_buckets)))
+        self.num_buckets = num_buckets
+        self._hooks = []
+        self._steps = 0
+        self._layout(list(reversed(self.params)), [])
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.active = False
+
+    def _layout(self, used: List[torch.nn.Parameter], unused: List[torch.nn.Parameter]):
+        """(Re)build the flat buffers: ``used`` (in gradient-production order) cut into
+        ``num_buckets`` buckets, then ONE last bucket of the parameters known to receive no gradient
+        -- so that no never-completing bucket sits in front of the others (buckets are issued in
+        index order).  Existing gradient values are carried over."""
+        old = {id(p): p.grad for p in self.params if p.grad is not None}
+        total = sum(p.numel() for p in used)
+        target = max(1, -(-total // max(1, self.num_buckets)))
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
         cur: List[torch.nn.Parameter] = []
         cur_n = 0
-        for p in rev:
+        for p in used:
             cur.append(p)
             cur_n += p.numel()
             if cur_n >= target:
@@ -326,9 +392,10 @@ class GradBuckets:
                 cur, cur_n = [], 0
         if cur:
             self._members.append(cur)
+        if unused:
+            self._members.append(list(unused))
         self._bucket_of = {}
         for b, members in enumerate(self._members):
-            n = sum(p.numel() for p in members)
             # 16-byte aligned slices keep every view usable by vectorised kernels
             offs, off = [], 0
             for p in members:
@@ -337,13 +404,15 @@ class GradBuckets:
             flat = torch.zeros(off, device=members[0].device, dtype=members[0].dtype)
             self.buckets.append(flat)
             for p, o in zip(members, offs):
-                p.grad = flat[o:o + p.numel()].view_as(p)
+                g = flat[o:o + p.numel()].view_as(p)
+                if id(p) in old:
+                    g.copy_(old[id(p)])
+                p.grad = g
                 self._bucket_of[id(p)] = b
         self._pending = [0] * len(self.buckets)
         self._next = 0
         self._handles = []
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self.active = False
+        self._seen = set()
 
     def close(self):
         for h in self._hooks:
@@ -370,8 +439,24 @@ class GradBuckets:
     def _on_grad(self, p):
         if not self.active:
             return
+        if self._steps == 0:
+            self._seen.add(id(p))
         self._pending[self._bucket_of[id(p)]] -= 1
         self._issue_ready()
+
+    def _demote_unused(self):
+        """After the FIRST step: parameters no rank produced a gradient for (agreed by a MAX
+        all-reduce of the per-parameter flags -- a rank without a batch in this step saw none) move
+        to the last bucket."""
+        flags = torch.tensor([1 if id(p) in self._seen else 0 for p in self.params],
+                             device=self.buckets[0].device, dtype=torch.int32)
+        all_reduce_(flags, "max")
+        flags = flags.tolist()
+        unused = [p for p, f in zip(self.params, flags) if not f]
+        last = len(self._members) - 1
+        if unused and len(unused) < len(self.params) and any(self._bucket_of[id(p)] != last for p in unused):
+            gone = {id(p) for p in unused}
+            self._layout([p for p in reversed(self.params) if id(p) not in gone], unused)
 
     def finish(self, scale: Optional[float] = None):
         """Issue what is left, wait for every bucket, optionally scale (mean = 1 / world)."""
@@ -380,6 +465,9 @@ class GradBuckets:
             h.wait()
         self._handles = []
         self.active = False
+        if self._steps == 0:
+            self._demote_unused()
+        self._steps += 1
         if scale is not None and scale != 1.0:
             for flat in self.buckets:
                 flat.mul_(scale)

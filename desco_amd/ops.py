@@ -645,10 +645,10 @@ def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: f
     dt = torch.empty((B, hid), device=t.device, dtype=torch.float32)
     dqh = torch.empty((Q, hid), device=t.device, dtype=torch.float32)
     dw2 = torch.empty((hid,), device=t.device, dtype=torch.float32)
-    ws = torch.empty((1024 * (Q + 1) * hid,), device=t.device, dtype=torch.float32)
+    L = _lib.lib()
+    ws = torch.empty((L.desco_count_head_bwd_workspace(B, Q, hid) // 4,), device=t.device, dtype=torch.float32)
     tp, ldt = _rows(t, "t")
     qp, ldq = _rows(qh, "qh")
-    L = _lib.lib()
     with _Timed("count_head_bwd", 6.0 * B * Q * hid, 4.0 * (2 * B * hid + Q * hid + B * Q)):
         _lib.check(L.desco_count_head_bwd_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"),
                                               slope, _dev(dl, "dl"), Q, B, Q, _dev(dt, "dt"), hid,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DESCO_ABI_VERSION 1
+#define DESCO_ABI_VERSION 2
 #define DESCO_H 64
 
 #define DESCO_EINVAL (-1)
@@ -379,7 +379,9 @@ int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, fl
 
 /* backward of desco_count_head_f32 (logit mode): given dl[b,q] = dLoss/dlogit,
  * dt[b,c], dqh[q,c] (contiguous [num_q, hid]), dw2[c];  (db2 = sum dl is left to the caller)
- * workspace: 1024 * (num_q+1) * hid floats */
+ * workspace: desco_count_head_bwd_workspace(num_b, num_q, hid) bytes (ABI 1 documented a constant of
+ * 256 * (num_q+1) * hid floats; the slab count grew to 1024 -- ask, do not assume) */
+size_t desco_count_head_bwd_workspace(int64_t num_b, int num_q, int hid);
 int desco_count_head_bwd_f32(const float* t, int64_t ldt, const float* qh, int64_t ldq, int hid,
                              const float* w2, float slope, const float* dl, int64_t lddl,
                              int64_t num_b, int num_q, float* dt, int64_t lddt, float* dqh,

@@ -86,12 +86,10 @@ def main(args_neighborhood, args_gossip, args_opt, train_neighborhood=True, trai
         return tw, vw, build_workload(args_opt.test_dataset, query_ids, nx_queries, depth, transform, ncpu,
                                       data_root, node_feat_len)
 
-    # rank 0 computes the ground truth / partitions and writes the on-disk caches; the others read them
-    if D.rank() == 0:
-        train_w, valid_w, test_w = build_all()
-    D.barrier()
-    if D.rank() != 0:
-        train_w, valid_w, test_w = build_all()
+    # rank 0 computes the ground truth / partitions and writes the on-disk caches; the others read
+    # them.  They wait on the process group's store, not in a collective: a cold-cache build may
+    # take longer than any collective watchdog allows
+    train_w, valid_w, test_w = D.rank0_first(build_all)
 
     # ---------------- neighborhood counting ----------------
     neigh_loader = LightningDataLoader(

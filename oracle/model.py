@@ -2,9 +2,12 @@
 gossip model, IN THE REFERENCE'S FORM (per-edge-type index_select + index_add_ + Linear, 29-iteration
 Python loops, query graphs re-embedded on every call).
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED by the reference: the reference has
-no tests / golden vectors for this path and torch_geometric is not importable here, so the
-third-party semantics marked [EXT] below are recalled from PyG 2.2.0, not executed.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference has no tests / golden vectors for this
+path.  Every function that restates the reference's OWN code is pinned bit-exactly by vectors that
+code produced when executed unbound in the build container (tests/golden/float_pieces.npz,
+float_flow.npz; the list is in oracle/__init__.py).  PARITY UNPINNED only for the third-party
+semantics marked [EXT] below (torch_geometric is not importable here): recalled from PyG 2.2.0, not
+executed.
 
 All functions take a plain ``state_dict`` (reference key names) and numpy/torch index
 arrays in PyG convention (``edge_index[0]`` = source index inside the source node type,
@@ -108,36 +111,66 @@ def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1, qfeats=None):
                            layer_num, input_dim, qfeats)
 
 
-def neighborhood_logits(sd, batch, qbatch, layer_num=8, input_dim=1, feats=None,
-                        emulate_quirk=True, qfeats=None):
-    """The [B,Q] pre-exponent outputs of graph_to_count / train_forward.
-
-    lightning_model.py:198-219 + embed_to_count :176-193: the queries are re-embedded on every
-    call, then per query ``count_model(cat(emb_target, query_emb.expand_as(emb_target)))``.
-    """
-    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim, qfeats)
-    emb_t = base_gnn_hetero(sd, "emb_model", batch, P.NODE_TYPES, P.EDGE_TYPES, layer_num,
-                            input_dim, feats, emulate_quirk)
+def head_logits(sd, emb_t, emb_q):
+    """The query loop of graph_to_count / train_forward (lightning_model.py:210-219) around
+    embed_to_count (:176-193): per query ``count_model(cat(emb_target, query_emb.expand_as(emb_target)))``,
+    columns concatenated.  PINNED by tests/golden/float_flow.npz (nm_*)."""
     outs = []
     for q in range(emb_q.shape[0]):
         e = torch.cat((emb_t, emb_q[q].expand_as(emb_t)), dim=-1)
         h = F.leaky_relu(_lin(sd, "count_model.0", e))        # nn.LeakyReLU() default slope 0.01
         outs.append(_lin(sd, "count_model.2", h))
-    return torch.cat(outs, dim=-1), emb_q
+    return torch.cat(outs, dim=-1)
+
+
+def count_from_logits(logits):
+    """lightning_model.py:221: ``2**pred - 1``."""
+    return 2 ** logits - 1
+
+
+def train_loss_from_logits(logits, y):
+    """train_forward, lightning_model.py:239-253 + criterion :285-289: per query
+    smooth_l1(out[:, q], log2(y[:, q] + 1)) (mean over the batch), mean over the queries."""
+    losses = [F.smooth_l1_loss(logits[:, q:q + 1], torch.log2(y[:, q].view(-1, 1) + 1))
+              for q in range(logits.shape[1])]
+    return torch.mean(torch.stack(losses))
+
+
+def eval_loss_from_logits(logits, y):
+    """test_forward, lightning_model.py:267-282: smooth_l1(relu(2**(out-1)), y) per query, mean."""
+    losses = [F.smooth_l1_loss(F.relu(2 ** (logits[:, q:q + 1] - 1)), y[:, q].view(-1, 1))
+              for q in range(logits.shape[1])]
+    return torch.mean(torch.stack(losses))
+
+
+def neighborhood_logits(sd, batch, qbatch, layer_num=8, input_dim=1, feats=None,
+                        emulate_quirk=True, qfeats=None):
+    """The [B,Q] pre-exponent outputs of graph_to_count / train_forward.
+
+    lightning_model.py:198-219: the queries are re-embedded on every call, then the head loop.
+    """
+    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim, qfeats)
+    emb_t = base_gnn_hetero(sd, "emb_model", batch, P.NODE_TYPES, P.EDGE_TYPES, layer_num,
+                            input_dim, feats, emulate_quirk)
+    return head_logits(sd, emb_t, emb_q), emb_q
 
 
 def neighborhood_graph_to_count(sd, batch, qbatch, **kw):
     """graph_to_count, lightning_model.py:198-222: ``2**pred - 1``."""
     logits, _ = neighborhood_logits(sd, batch, qbatch, **kw)
-    return 2 ** logits - 1
+    return count_from_logits(logits)
 
 
 def neighborhood_loss(sd, batch, qbatch, y, **kw):
     """train_forward, lightning_model.py:228-254 + criterion :285-289."""
     logits, _ = neighborhood_logits(sd, batch, qbatch, **kw)
-    losses = [F.smooth_l1_loss(logits[:, q:q + 1], torch.log2(y[:, q].view(-1, 1) + 1))
-              for q in range(logits.shape[1])]
-    return torch.mean(torch.stack(losses))
+    return train_loss_from_logits(logits, y)
+
+
+def neighborhood_test_loss(sd, batch, qbatch, y, **kw):
+    """test_forward, lightning_model.py:256-283."""
+    logits, _ = neighborhood_logits(sd, batch, qbatch, **kw)
+    return eval_loss_from_logits(logits, y)
 
 
 # ------------------------------------------------------------------------------------------
@@ -174,20 +207,33 @@ def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2):
     return post_mp(sd, "emb_model", emb)                                            # :102-103
 
 
-def gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num=2):
-    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: 29 sequential passes."""
+def gossip_query_loop(emb_fn, x, query_emb):
+    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: per query
+    ``neigh_pred + emb_model(batch, query_emb[q])`` with ``batch.node_feature = x[:, q]``, columns
+    concatenated.  ``emb_fn(x_col [N,1], query_emb [1,H]) -> [N,1]``.  PINNED by float_flow.npz (gm_*)."""
     outs = []
     for q in range(query_emb.shape[0]):
-        corr = gossip_single_query(sd, x[:, q].view(-1, 1), edge_index, query_emb[q].view(1, -1),
-                                   layer_num)
-        outs.append(x[:, q].view(-1, 1) + corr)
+        x_col = x[:, q].view(-1, 1)
+        outs.append(x_col + emb_fn(x_col, query_emb[q, :].view(1, -1)))
     return torch.cat(outs, dim=-1)
+
+
+def gossip_loss_from_pred(pred, y):
+    """train_forward + criterion, lightning_model.py:585-608, 630-635: log2(|pred - y| + 1) per node
+    and query, stacked per query and summed (sum, not mean)."""
+    return torch.sum(torch.stack([torch.log2(torch.abs(pred[:, q:q + 1] - y[:, q].view(-1, 1)) + 1)
+                                  for q in range(pred.shape[1])]))
+
+
+def gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num=2):
+    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: 29 sequential passes."""
+    return gossip_query_loop(
+        lambda x_col, qe: gossip_single_query(sd, x_col, edge_index, qe, layer_num), x, query_emb)
 
 
 def gossip_loss(sd, x, y, edge_index, query_emb, layer_num=2):
     """train_forward + criterion, lightning_model.py:585-608, 630-635 (sum, not mean)."""
-    pred = gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num)
-    return torch.sum(torch.log2(torch.abs(pred - y) + 1))
+    return gossip_loss_from_pred(gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num), y)
 
 
 def gossip_gate_values(sd, query_emb, layer_num=2):
@@ -204,6 +250,11 @@ def apply_neighborhood_count(count, indicator):
     x = torch.zeros(len(indicator), count.shape[1])
     x[torch.as_tensor(np.asarray(indicator, dtype=bool))] = count.detach()
     return x
+
+
+def apply_truth(truth, indicator):
+    """NeighborhoodDataset.apply_truth_from_dataset, workload.py:296-301."""
+    return truth[torch.as_tensor(np.asarray(indicator, dtype=bool)), :]
 
 
 def aggregate_by_index(count, graph_id, num_graphs):

@@ -239,3 +239,126 @@ def float_pieces():
 
 if __name__ == "__main__":
     float_pieces()
+
+
+def float_flow():
+    """Golden vectors for the reference-owned float CONTROL FLOW that is executable without PyG
+    (missing #1).  Every function below is the reference's own code, called UNBOUND with
+    a stand-in ``self`` whose sub-modules are plain torch modules or seeded callables (no reference
+    source is copied or modified; the stand-ins replace only what PyG / Lightning hold):
+      gnn_model.py:230-277      BaseGNNCore.forward, SAGE branch: pre_mp -> convs[i] -> updates[i](cat) ->
+                                relu -> dropout -> running cat.  ``convs[i]`` = index_add_ + Linear closure
+                                (the SAGEConv stand-in; PyG's propagate stays [EXT])
+      gnn_model.py:58-109       BaseGNN.forward, baseline == "gossip" path: core -> (no anchor) -> post_mp
+      lightning_model.py:198-222  NeighborhoodCountingModel.graph_to_count  (query loop, 2**pred - 1)
+      lightning_model.py:228-254  .train_forward  (log2(y+1), smooth_l1 per query, mean)
+      lightning_model.py:256-283  .test_forward   (relu(2**(pred-1)) vs y)
+      lightning_model.py:613-628  GossipCountingModel.graph_to_count  (neigh_pred + gossip_pred per query)
+      lightning_model.py:585-608  .train_forward  (sum over queries of log2(|pred-y|+1))
+      workload.py:107-112       GossipDataset.apply_neighborhood_count (zeros + masked row scatter)
+      workload.py:303-324       NeighborhoodDataset.aggregate_neighborhood_count (index_add_)
+      workload.py:296-301       NeighborhoodDataset.apply_truth_from_dataset (indicator row select)
+    """
+    import types
+    import torch
+    import torch.nn as nn
+    _ref_import.install()
+    import subgraph_counting.gnn_model as ref_gnn
+    import subgraph_counting.lightning_model as ref_lm
+    import subgraph_counting.workload as ref_wl
+
+    torch.manual_seed(4321)
+    out = {}
+    H, L = 64, 8
+    # ---- BaseGNNCore.forward, SAGE branch (homogeneous) -----------------------------------------
+    n, e = 19, 46
+    src, dst = torch.randint(0, n, (e,)), torch.randint(0, n, (e,))
+    keep = src != dst
+    ei = torch.stack((src[keep], dst[keep]))
+    pre_mp = nn.Sequential(nn.Linear(1, H))
+    lins = nn.ModuleList([nn.Linear(H, H) for _ in range(L)])
+    updates = nn.ModuleList([nn.Linear(2 * H, H) for _ in range(L)])
+
+    def conv(l):    # SAGEConv stand-in: aggr="add" at edge_index[1] of x_j = x[edge_index[0]], then lin
+        return lambda x, edge_index: lins[l](
+            torch.zeros(x.shape[0], H).index_add_(0, edge_index[1], x[edge_index[0]]))
+    core = types.SimpleNamespace(pre_mp=pre_mp, input_pattern_emb=False, conv_type="SAGE",
+                                 convs=[conv(l) for l in range(L)], updates=updates, dropout=0.0,
+                                 training=False)
+    x = torch.randn(n, 1)
+    with torch.no_grad():
+        emb = ref_gnn.BaseGNNCore.forward(core, x, ei)
+    assert emb.shape == (n, H * (L + 1))
+    out.update(core_x=x, core_ei=ei, core_emb=emb, core_pre_w=pre_mp[0].weight, core_pre_b=pre_mp[0].bias)
+    for l in range(L):
+        out.update({f"core_lin_w{l}": lins[l].weight, f"core_lin_b{l}": lins[l].bias,
+                    f"core_upd_w{l}": updates[l].weight, f"core_upd_b{l}": updates[l].bias})
+    # ---- BaseGNN.forward, gossip path: post_mp over the core output, no anchor, no pooling ----------
+    post = nn.Sequential(nn.Linear(256, H), nn.Dropout(0.0), nn.LeakyReLU(0.1), nn.Linear(H, H), nn.ReLU(),
+                         nn.Linear(H, 256), nn.ReLU(), nn.Linear(256, 1)).eval()
+    core_out = torch.randn(n, 256)
+    gnn = types.SimpleNamespace(use_hetero=False, kwargs={"baseline": "gossip"}, post_mp=post,
+                                anchor_mlp=None,
+                                gnn_core=types.SimpleNamespace(forward=lambda x, ei, query_emb=None: core_out))
+    data = types.SimpleNamespace(node_feature=torch.ones(n, 1), edge_index=ei,
+                                 batch=torch.zeros(n, dtype=torch.long))
+    with torch.no_grad():
+        gpost = ref_gnn.BaseGNN.forward(gnn, data, query_emb=torch.randn(1, H))
+    out.update(gpost_in=core_out, gpost_out=gpost,
+               **{f"gpost_w{i}": post[i].weight for i in (0, 3, 5, 7)},
+               **{f"gpost_b{i}": post[i].bias for i in (0, 3, 5, 7)})
+    # ---- NeighborhoodCountingModel: graph_to_count / train_forward / test_forward --------------------
+    B, Q = 37, 5
+    count_model = nn.Sequential(nn.Linear(2 * H, 4 * H), nn.LeakyReLU(), nn.Linear(4 * H, 1))
+    ET, EQ = torch.randn(B, H), torch.randn(Q, H)
+
+    class _QB:      # a query batch: only .to(device) is used (lightning_model.py:205)
+        def to(self, device):
+            return self
+    nm = types.SimpleNamespace(kwargs={}, count_model=count_model, device="cpu", query_loader=[_QB()],
+                               emb_model_query=lambda qb: EQ, emb_model=lambda b: ET)
+    nm.embed_to_count = types.MethodType(ref_lm.NeighborhoodCountingModel.embed_to_count, nm)
+    nm.criterion = types.MethodType(ref_lm.NeighborhoodCountingModel.criterion, nm)
+    y = torch.floor(torch.rand(B, Q) * 9)
+    batch = types.SimpleNamespace(y=y)
+    with torch.no_grad():
+        out.update(nm_count=ref_lm.NeighborhoodCountingModel.graph_to_count(nm, batch),
+                   nm_train_loss=ref_lm.NeighborhoodCountingModel.train_forward(nm, batch, 0),
+                   nm_test_loss=ref_lm.NeighborhoodCountingModel.test_forward(nm, batch, 0))
+    out.update(nm_emb_t=ET, nm_emb_q=EQ, nm_y=y, nm_w0=count_model[0].weight, nm_b0=count_model[0].bias,
+               nm_w2=count_model[2].weight, nm_b2=count_model[2].bias)
+    # ---- GossipCountingModel: graph_to_count / train_forward -------------------------------------------
+    N = 29
+    corr = nn.Linear(1 + H, 1)      # emb_model stand-in: any function of (batch.node_feature, query_emb)
+
+    def emb_model(b, query_emb=None):
+        return corr(torch.cat((b.node_feature, query_emb.expand(b.node_feature.shape[0], -1)), dim=-1))
+    gx, gy, gq = torch.rand(N, Q) * 7, torch.floor(torch.rand(N, Q) * 9), torch.randn(Q, H)
+    gm = types.SimpleNamespace(query_emb=gq, device="cpu", emb_model=emb_model)
+    gm.criterion = types.MethodType(ref_lm.GossipCountingModel.criterion, gm)
+    gb = types.SimpleNamespace(x=gx, y=gy)
+    with torch.no_grad():
+        out.update(gm_count=ref_lm.GossipCountingModel.graph_to_count(gm, gb),
+                   gm_train_loss=ref_lm.GossipCountingModel.train_forward(gm, gb, 0))
+    out.update(gm_x=gx, gm_y=gy, gm_q=gq, gm_corr_w=corr.weight, gm_corr_b=corr.bias)
+    # ---- dataset helpers -----------------------------------------------------------------------------
+    indicator = torch.rand(41) < 0.7
+    cnt = torch.rand(int(indicator.sum()), Q) * 5
+    gd = types.SimpleNamespace(data=types.SimpleNamespace(), slices={"y": torch.tensor([0, 20, 41])})
+    ref_wl.GossipDataset.apply_neighborhood_count(gd, cnt, indicator)
+    gids = torch.sort(torch.randint(0, 6, (cnt.shape[0],))).values
+    index = np.stack([gids.numpy(), np.arange(cnt.shape[0])], axis=1)
+    nd = types.SimpleNamespace(nx_neighs_index=index, dataset=list(range(7)), data=types.SimpleNamespace(),
+                               nx_neighs_indicator=indicator)
+    agg = ref_wl.NeighborhoodDataset.aggregate_neighborhood_count(nd, cnt)
+    truth = torch.floor(torch.rand(41, Q) * 4)
+    ref_wl.NeighborhoodDataset.apply_truth_from_dataset(nd, truth)
+    out.update(ds_indicator=indicator, ds_count=cnt, ds_x=gd.data.x, ds_index=torch.from_numpy(index),
+               ds_agg=agg, ds_truth=truth, ds_y=nd.data.y)
+    np.savez_compressed(os.path.join(HERE, "float_flow.npz"),
+                        **{k: v.detach().numpy() for k, v in out.items()})
+    print("float_flow.npz written")
+
+
+if __name__ == "__main__":
+    float_flow()

@@ -143,14 +143,17 @@ def _worker(rank, world, port, q, tmp):
         m = _Model("mean")
         data = _Data(SIZES)
         bk = D.GradBuckets(list(m.parameters()), num_buckets=3)
-        grads = []
+        grads, issued = [], []
         for group in D.step_groups(SIZES, world):
             bk.zero()
             i = group[rank]
             if i is not None:
                 (m._loss(data.batches[i]) * D.mean_loss_weight(SIZES, group, rank)).backward()
+            issued.append(bk._next)              # buckets already issued from the hooks
             bk.finish()
             grads.append([p.grad.clone() for p in m.parameters()])
+        res["bucket_layout"] = (bk._bucket_of[id(m.unused.weight)], bk._bucket_of[id(m.unused.bias)],
+                                len(bk.buckets), issued)
         bk.close()
         res["bucket_grads"] = grads
         # Trainer.fit / predict in ddp mode
@@ -238,6 +241,91 @@ def test_bucketed_weighted_gradients_equal_union_batch_gradient(world2):
             got = world2[r]["bucket_grads"][step]
             for g, w in zip(got, want):
                 torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
+
+
+def test_unused_parameters_move_to_the_last_bucket_after_step_0(world2):
+    """a never-used parameter in an early bucket blocked every hook-issued all-reduce
+    until finish().  Step 0 finds it (flags agreed over the ranks), step 1 issues every other bucket
+    from the hooks (rank 0 has the batch of the short last group)."""
+    for r in (0, 1):
+        bw, bb, nb, issued = world2[r]["bucket_layout"]
+        assert bw == bb == nb - 1, (bw, bb, nb)
+    issued0 = world2[0]["bucket_layout"][3]
+    assert issued0[0] == 0                       # step 0: bucket 0 still held the unused parameters
+    assert issued0[1] == world2[0]["bucket_layout"][2] - 1      # step 1: all but the unused bucket
+
+
+_RANK_SCRIPT = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch
+from desco_amd import distributed as D
+mode = sys.argv[1]
+r = int(os.environ["RANK"])
+if mode == "crash":
+    if r == 1:
+        sys.exit(3)
+    time.sleep(120)
+elif mode == "rank0_first":
+    os.environ["DESCO_PG_TIMEOUT_S"] = "2"          # shorter than rank 0's build below
+    D.init_from_env(torch.device("cpu"))
+    order = []
+    def build():
+        if D.rank() == 0:
+            time.sleep(5)
+        open(os.path.join(sys.argv[2], "built_%d" % D.rank()), "w").write(str(time.time()))
+        return D.rank()
+    assert D.rank0_first(build) == r
+    import torch.distributed as dist
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    assert t.item() == 2
+    dist.destroy_process_group()
+elif mode == "rank0_fails":
+    D.init_from_env(torch.device("cpu"))
+    def build():
+        if D.rank() == 0:
+            raise ValueError("no data")
+        return 1
+    D.rank0_first(build)
+"""
+
+
+def _script(tmp_path):
+    p = tmp_path / "rank_script.py"
+    p.write_text(_RANK_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    return str(p)
+
+
+def test_launch_notices_a_crashed_rank_while_others_block(tmp_path):
+    """launch() waited for rank 0 first and never saw rank 1 die."""
+    import time
+    t0 = time.time()
+    rc = D.launch([_script(tmp_path), "crash"], 2)
+    assert rc == 3 and time.time() - t0 < 60
+
+
+def test_rank0_first_waits_on_the_store_not_in_a_collective(tmp_path):
+    """a long cache build on rank 0 must not trip the process group's watchdog: the other
+    ranks wait on the store (PG timeout 2 s here, build 5 s) and build after rank 0."""
+    rc = D.launch([_script(tmp_path), "rank0_first", str(tmp_path)], 2, timeout=120)
+    assert rc == 0
+    t = [float(open(tmp_path / f"built_{r}").read()) for r in (0, 1)]
+    assert t[1] >= t[0]
+
+
+def test_rank0_first_passes_a_failure_on(tmp_path):
+    rc = D.launch([_script(tmp_path), "rank0_fails"], 2, timeout=120)
+    assert rc != 0
+
+
+def test_local_device_honours_launch_devices(monkeypatch):
+    monkeypatch.setenv("DESCO_DEVICES", "5,7")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.delenv("DESCO_SHARE_GPU", raising=False)
+    assert D.local_device() == torch.device("cuda", 7)
+    assert D.local_device([2, 3]) == torch.device("cuda", 3)     # an explicit list wins
 
 
 @pytest.mark.parametrize("reduce", ["mean", "sum"])

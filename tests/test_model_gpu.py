@@ -137,9 +137,9 @@ def test_full_size_run_is_replica_invariant(setup):
         assert worst < 1e-5, (key, worst)
 
 
-@pytest.mark.parametrize("workload", ["syn_1827", "msrc_imdb"])
+@pytest.mark.parametrize("workload", ["mutag", "syn_1827", "msrc_imdb"])
 def test_full_size_dense_workloads_are_shard_invariant(workload):
-    """BASELINE configs 3-5 at their full dataset size (Syn_1827-shaped: 1 827 graphs, 246 k nodes,
+    """BASELINE config 1 (MUTAG-shaped, 188 graphs) and configs 3-5 at their full dataset size (Syn_1827-shaped: 1 827 graphs, 246 k nodes,
     19 M neighborhood rows, 78 M directed neighborhood edges, neighborhoods of up to ~790 nodes;
     MSRC-21 + IMDB-BINARY-shaped: 1 563 graphs): size-independent properties of the whole two-stage
     pass -- everything finite, and the dataset processed as ONE shard equals the dataset processed
@@ -173,6 +173,28 @@ def test_full_size_dense_workloads_are_shard_invariant(workload):
         print(f"[property] {workload} {key}: whole vs two halves, worst log2-space deviation "
               f"{float(dev.max()):.2e} (relative {worst:.2e}); max |count| {float(ref.abs().max()):.3e}")
         assert worst < 1e-4, (key, worst)
+
+
+def test_mutag_shaped_pipeline_vs_oracle(setup):
+    """BASELINE config 1 on its own workload: the whole two-stage pass (main.py:296-423) over 24
+    MUTAG-shaped graphs (the first of the 188-graph set of ``synthetic.mutag_shaped``) against the CPU
+    oracle in the reference's form -- partition index / indicator bit-exact, counts to the fp32
+    tolerance of this suite."""
+    from desco_amd import synthetic
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    gs = synthetic.WORKLOADS["mutag"]().subset(0, 24)
+    graphs = gs.edge_lists()
+    ref = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), graphs, queries, emulate_quirk=False)
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV)
+    out = pipe.run()
+    assert (pipe.partition.neigh_index == ref["index"]).all()
+    assert (pipe.partition.indicator == ref["indicator"]).all()
+    assert ref["neigh_count"].shape[0] > 300
+    for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
+        report("mutag " + k, out[k], ref[k])
+        assert torch.isfinite(ref[k]).all() and float(ref[k].std()) > 0
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
 
 
 def test_gossip_conv_standalone_forward(setup):
