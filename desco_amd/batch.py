@@ -96,6 +96,38 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def _seg_ptr_device(self):
         return self.count_ptr
 
+    def resident_plan(self):
+        """Work list of the neighborhood-resident multi-layer kernel (desco_shmp_resident_bf16x6_f32),
+        built once per batch: packs of consecutive neighborhoods within the kernel's LDS limits, and
+        the neighborhoods above them as a self-contained sub-batch for the layer-by-layer kernels.
+        Returns None when the block has no neighborhoods."""
+        if "_resident_plan" not in self.__dict__:
+            from . import ops
+            part = self.part
+            plan = None
+            if part.num_neigh > 0:
+                elig, nb0, nnb = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count)
+                cp = part.count_ptr.astype(np.int64)
+                n = np.diff(cp)
+                v = part.vrowptr.astype(np.int64)
+                e = (v[4 * cp[1:]] - v[4 * cp[:-1]]) + (v[4 * (part.num_count + np.arange(part.num_neigh)) + 4]
+                                                         - v[4 * (part.num_count + np.arange(part.num_neigh))])
+                rows = int(n[elig].sum() + elig.sum())
+                tiles = int(((n[elig] + 15) // 16).sum())
+                over = np.nonzero(~elig)[0]
+                dev = self.device
+                plan = {
+                    "num_packs": len(nb0), "pack_nb0": _i32(nb0, dev), "pack_nnb": _i32(nnb, dev),
+                    "rows": rows, "edges": int(e[elig].sum()), "tile_rows": 16 * tiles + 16 * len(nb0),
+                    "counter": torch.zeros(1, device=dev, dtype=torch.int32),
+                    "oversize_index": None, "oversize_batch": None,
+                }
+                if len(over):
+                    plan["oversize_index"] = torch.from_numpy(over).to(dev)
+                    plan["oversize_batch"] = NeighborhoodBatch(part.select(over), dev, input_dim=self.input_dim)
+            self.__dict__["_resident_plan"] = plan
+        return self.__dict__["_resident_plan"]
+
     def pool_index(self, tile_rows: Optional[int] = None):
         """(pool_bits, pool_slot, num_slots) of the fused pooling (desco_shmp_layer_pool_bf16x6_f32):
         per wave tile (``tile_rows`` = 16 or 32 count rows; default: what the library's layer kernel

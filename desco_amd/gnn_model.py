@@ -35,6 +35,13 @@ SHMP_BF16X6 = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
+# Neighborhood-resident multi-layer kernel (csrc/shmp_resident.hip): every SHMP layer of a pack of
+# neighborhoods in one launch with the node features in LDS.  "auto": used for target batches with the
+# constant (all-zero) input whose neighborhoods are large enough that aligning each to 16-row tiles
+# wastes little (padded rows / real rows <= RESIDENT_MAX_PAD: Syn_1827 1.13, MSRC-21 + IMDB 1.28,
+# COX2 / MUTAG 2.2 -> those stay on the layer-by-layer kernels); True / False force the choice.
+RESIDENT_SHMP = "auto"
+RESIDENT_MAX_PAD = 1.6
 _RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
@@ -362,8 +369,91 @@ def _post_mp(pk, pooled):
     return ops.gemm(h, w7, b7)
 
 
+def _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev):
+    """[S+1, 64] coefficients of the closed-form first layer for destination type ``t`` (folded once per
+    weight version): rows s < su = x0_src(s) W_s, unused slots zero, last row = x0_t W_self + bias."""
+    ck = ("layer0_coef", t, S)
+    if ck not in pk:
+        e = pk["layers"][0][t]
+        wt = e["wt"]                                    # [(su+1)*64, 64]
+        rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
+        rows += [torch.zeros(H, device=dev)] * (S - su)  # unused slots of this type
+        rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
+        pk[ck] = torch.stack(rows).contiguous()
+    return pk[ck]
+
+
+def _resident_operands(pk, core, dev):
+    """Operands of desco_shmp_resident_bf16x6_f32, folded once per weight version: first-layer
+    coefficients [2][5][64], fragment stream [L-1][16][3][4][64][8], biases [L-1][2][64]."""
+    if "resident" not in pk:
+        x0 = {t: pk["pre"][t][1] for t in ("count", "canonical")}
+        src = lambda t, s: "count" if s < 2 else "canonical"              # noqa: E731
+        l0 = torch.stack([_first_layer_coef(pk, "count", 4, 4, x0, src, dev),
+                          _first_layer_coef(pk, "canonical", 2, 4, x0, src, dev)]).contiguous()
+        frags, biases = [], []
+        for l in range(1, core.layer_num):
+            ec, ek = pk["layers"][l]["count"], pk["layers"][l]["canonical"]
+            frags.append(ops.resident_fragments(ec["wt_tab"], ek["wt"], ec["wt_mfma"]))
+            biases.append(torch.stack([ec["b"], ek["b"]]))
+        pk["resident"] = (l0, torch.stack(frags).contiguous(), torch.stack(biases).contiguous())
+    return pk["resident"]
+
+
+def _use_resident(gnn: BaseGNN, batch) -> bool:
+    if RESIDENT_SHMP is False or not isinstance(batch, NeighborhoodBatch):
+        return False
+    core = gnn.gnn_core
+    ok = (batch.node_feature is None and FUSED_SHMP_LAYER and SHMP_BF16X6 and GEMM_BF16X6
+          and core.layer_num >= 2 and "wt_tab" in gnn.packed()["layers"][0].get("count", {}))
+    if not ok:
+        if RESIDENT_SHMP is True:
+            raise NotImplementedError("the resident SHMP kernel needs the tconv hetero model on constant input")
+        return False
+    plan = batch.resident_plan()
+    if plan is None or plan["num_packs"] == 0:
+        return False
+    return RESIDENT_SHMP is True or plan["tile_rows"] <= RESIDENT_MAX_PAD * plan["rows"]
+
+
+def _shmp_pooled_resident(gnn: BaseGNN, batch) -> torch.Tensor:
+    """pooled [B, 576] of BaseGNN.forward's hetero path (gnn_model.py:58-107) with ALL layers of the packed
+    neighborhoods in one launch (csrc/shmp_resident.hip); neighborhoods above the kernel's pack limits
+    run through the layer-by-layer kernels as a sub-batch."""
+    pk = gnn.packed()
+    core = gnn.gnn_core
+    dev = batch.vrowptr.device
+    plan = batch.resident_plan()
+    l0, wfrag, bias = _resident_operands(pk, core, dev)
+    B = batch.num_graphs
+    P = H * (core.layer_num + 1)
+    pooled = torch.zeros((B, P), device=dev)
+    canon = torch.zeros((B, P), device=dev)
+    ops.shmp_resident(batch.count_ptr, batch.vrowptr, batch.vcol, batch.num_count, plan["pack_nb0"],
+                      plan["pack_nnb"], l0, wfrag, bias, pooled, canon, plan["counter"],
+                      work=(plan["rows"], plan["edges"]))
+    canon[:, :H] = pk["pre"]["canonical"][1]                      # x^0 of a canonical row: pre_mp's bias
+    anch = ops.gemm_split(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)      # gnn_model.py:69-73
+    ck = ("pool0_coef", "count")
+    if ck not in pk:
+        pk[ck] = torch.stack([pk["pre"]["count"][1], torch.zeros(H, device=dev)]).contiguous()
+    # block 0: (count rows in the neighborhood) * x0 + anchored canonical row; blocks 1..: + anchored row
+    ops.degree_affine(batch.count_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, pooled[:, :H], extra=anch[:, :H])
+    pooled[:, H:] += anch[:, H:]
+    if plan["oversize_batch"] is not None:
+        pooled[plan["oversize_index"]] = _shmp_pooled(gnn, plan["oversize_batch"], allow_resident=False)
+    return pooled
+
+
 def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     """BaseGNN.forward, hetero path (gnn_model.py:58-109) -> graph embeddings [B, 64]."""
+    return _post_mp(gnn.packed(), _shmp_pooled(gnn, batch))                 # :108
+
+
+def _shmp_pooled(gnn: BaseGNN, batch, allow_resident: bool = True) -> torch.Tensor:
+    """The pooled embeddings [B, 64 (L+1)] of BaseGNN.forward before post_mp (gnn_model.py:58-107)."""
+    if allow_resident and _use_resident(gnn, batch):
+        return _shmp_pooled_resident(gnn, batch)
     pk = gnn.packed()
     core = gnn.gnn_core
     dev = batch.vrowptr.device
@@ -386,16 +476,8 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
         for t, r0, r1, su in groups:
             if r1 <= r0:
                 continue
-            ck = ("layer0_coef", t, S)
-            if ck not in pk:                                    # folded once per weight version
-                e = pk["layers"][0][t]
-                wt = e["wt"]                                    # [(su+1)*64, 64]
-                rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
-                rows += [torch.zeros(H, device=dev)] * (S - su)  # unused slots of this type
-                rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
-                pk[ck] = torch.stack(rows).contiguous()
-            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, pk[ck],
-                              ops.ACT_RELU, 0.0, xn)
+            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S,
+                              _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev), ops.ACT_RELU, 0.0, xn)
         X = [None, xn]
         first = 1
     else:
@@ -489,7 +571,7 @@ def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
             ops.degree_affine(seg_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, out_l, extra=extra)
         else:
             ops.segment_sum(xl[:Nc], seg_ptr, B, extra=extra, out=out_l)
-    return _post_mp(pk, pooled)                                            # :108
+    return pooled
 
 
 def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:

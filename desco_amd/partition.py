@@ -77,6 +77,33 @@ class NeighborhoodPartition:
             count_orig=self.count_orig[c0:c1], vrowptr=vr.astype(np.int32),
             vcol=col.astype(np.int32), depth=self.depth, quirk_batch=self.quirk_batch)
 
+    def select(self, idx) -> "NeighborhoodPartition":
+        """The neighborhoods ``idx`` (ascending indices, any subset) as a self-contained block: what
+        ``slice`` does for a contiguous range.  Used to hand the few neighborhoods that exceed the
+        resident kernel's pack limits to the layer-by-layer kernels."""
+        idx = np.asarray(idx, dtype=np.int64)
+        M = len(idx)
+        cp, Nc = self.count_ptr.astype(np.int64), self.num_count
+        n = cp[idx + 1] - cp[idx]
+        cp2 = np.concatenate([[0], np.cumsum(n)])
+        nc2 = int(cp2[-1])
+        rows_old = np.repeat(cp[idx] - cp2[:-1], n) + np.arange(nc2, dtype=np.int64)
+        v = self.vrowptr.astype(np.int64)
+        four = np.arange(4, dtype=np.int64)
+        vr_old = np.concatenate([(rows_old[:, None] * 4 + four).ravel(), ((Nc + idx)[:, None] * 4 + four).ravel()])
+        deg = v[vr_old + 1] - v[vr_old]
+        vr2 = np.concatenate([[0], np.cumsum(deg)])
+        e_old = np.repeat(v[vr_old] - vr2[:-1], deg) + np.arange(int(vr2[-1]), dtype=np.int64)
+        col_old = self.vcol[e_old].astype(np.int64)
+        nb_of_vr = np.concatenate([np.repeat(np.repeat(np.arange(M, dtype=np.int64), n), 4),
+                                   np.repeat(np.arange(M, dtype=np.int64), 4)])
+        nb_of_e = np.repeat(nb_of_vr, deg)
+        col_new = np.where(col_old < Nc, col_old + (cp2[:-1] - cp[idx])[nb_of_e], nc2 + nb_of_e)
+        return NeighborhoodPartition(
+            neigh_index=self.neigh_index[idx], indicator=self.indicator, count_ptr=cp2.astype(np.int32),
+            count_orig=self.count_orig[rows_old], vrowptr=vr2.astype(np.int32), vcol=col_new.astype(np.int32),
+            depth=self.depth, quirk_batch=self.quirk_batch)
+
     # ---- PyG-convention view (tests / interop) ---------------------------------------------
     def edge_index_dict(self) -> Dict[Tuple[str, str, str], np.ndarray]:
         """The six typed ``edge_index`` arrays of the collated HeteroData batch (PyG convention:

@@ -243,6 +243,43 @@ int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, con
                           int64_t ld_extra, float* out, int64_t ldo, int tile_rows,
                           desco_stream_t stream);
 
+/* Neighborhood-resident multi-layer SHMP (csrc/shmp_resident.hip): ALL layers of BaseGNNCore.forward's
+ * SAGE branch for the hetero count / canonical block (gnn_model.py:230-277, 372-404) in ONE launch, the
+ * node features of a PACK of neighborhoods resident in LDS from the first layer to the last, plus the
+ * global_add_pool of the count rows (gnn_model.py:88-89, 107).  Constant input only (the default
+ * pipeline's all-zero node features, workload.py:431-440): the first layer is the closed degree-affine
+ * form of desco_degree_affine_f32.
+ *   packs: pack p = neighborhoods [pack_nb0[p], pack_nb0[p] + pack_nnb[p]) of the 4-slot block
+ *          (count_ptr / vrowptr / vcol as for desco_shmp_layer_*), built by desco_resident_plan:
+ *          <= 16 neighborhoods, <= 31 tiles of 16 count rows (every neighborhood starts a tile),
+ *          <= desco_shmp_resident_limits edges; neighborhoods above the limits are flagged
+ *          eligible[b] = 0, belong to no pack and must go through the layer-by-layer entry points.
+ *   l0coef [2][5][64]: first-layer coefficients, count rows (slots 0..3, constant) then canonical rows
+ *          (slots 0, 1, two unused rows, constant): x1 = relu(const + sum_s deg_s coef_s).
+ *   wfrag  [num_layers][16][3][4][64][8] bf16: the layers' weight planes as MFMA B fragments in
+ *          consumption order -- per layer 4 K-steps of the canonical->count table weights ([W_2|W_3],
+ *          order (h0,j0) (h0,j1) (h1,j0) (h1,j1)), 6 of the canonical-destination weights (slot 0,
+ *          slot 1, self; two 32-deep halves each), 6 of the count-destination weights; step =
+ *          [plane hi/mid/lo][16-column tile][lane][8]: lane (n = lane & 15, q = lane >> 4) holds
+ *          W[k = 32 h + 8 q .. + 7][16 t + n]  (desco_amd.ops.resident_fragments builds it).
+ *   bias   [num_layers][2][64]: folded bias of the count rows, of the canonical rows.
+ *   pooled [B][ldp], canon [B][ldc]: column block l (64 floats at 64 l) receives, for l = 1 ..
+ *          num_layers + 1, the sum of the neighborhood's count rows of x^l / its canonical row of x^l
+ *          (block 0, the constant input layer, is left to the caller); rows of ineligible neighborhoods
+ *          are not touched.  counter: one int32 of device scratch (pack hand-out).
+ * Every sum has a fixed order that depends only on the neighborhood itself (tiles are aligned to
+ * neighborhood starts; a row switches to the cooperative gather by its OWN degree): results do not
+ * depend on which other neighborhoods share the launch, pack or shard. */
+int desco_shmp_resident_limits(int* max_count_rows, int* max_edges, int* max_neigh);
+int desco_resident_plan(const int32_t* count_ptr, const int32_t* vrowptr, int64_t num_neigh,
+                        int64_t num_count, uint8_t* eligible, int32_t* pack_nb0, int32_t* pack_nnb,
+                        int64_t* num_packs);
+int desco_shmp_resident_bf16x6_f32(const int32_t* count_ptr, const int32_t* vrowptr, const int32_t* vcol,
+                                   int64_t num_count, const int32_t* pack_nb0, const int32_t* pack_nnb,
+                                   int num_packs, const float* l0coef, const int16_t* wfrag,
+                                   const float* bias, int num_layers, float* pooled, int64_t ldp,
+                                   float* canon, int64_t ldc, int32_t* counter, desco_stream_t stream);
+
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);
  * w_planes[num_blocks][3][64 n][64 k] = desco_split_bf16x3_f32 of every 64-row block of the
