@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdesco_hip.so")
+# DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_resident.sh)
+LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
 ABI_VERSION = 2
 
 _lib = None
@@ -40,8 +41,8 @@ SIGNATURES = {
     "desco_shmp_layer_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_layer_pool_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
     "desco_shmp_resident_limits": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
-    "desco_resident_plan": (c_int, [vp, vp, i64, i64, vp, vp, vp, POINTER(i64)]),
-    "desco_shmp_resident_bf16x6_f32": (c_int, [vp, vp, vp, i64, vp, vp, i32, vp, vp, vp, i32, vp, i64, vp, i64,
+    "desco_resident_plan": (c_int, [vp, vp, i64, i64, vp, vp, POINTER(i64)]),
+    "desco_shmp_resident_bf16x6_f32": (c_int, [vp, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i64, vp, i64,
                                                vp, vp]),
     "desco_pool_reduce_f32": (c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]),
     "desco_shmp_pool_tile_rows": (c_int, []),

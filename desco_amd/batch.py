@@ -106,7 +106,7 @@ class NeighborhoodBatch(_TrainIndexMixin):
             part = self.part
             plan = None
             if part.num_neigh > 0:
-                elig, nb0, nnb = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count)
+                elig, plist = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count)
                 cp = part.count_ptr.astype(np.int64)
                 n = np.diff(cp)
                 v = part.vrowptr.astype(np.int64)
@@ -117,8 +117,8 @@ class NeighborhoodBatch(_TrainIndexMixin):
                 over = np.nonzero(~elig)[0]
                 dev = self.device
                 plan = {
-                    "num_packs": len(nb0), "pack_nb0": _i32(nb0, dev), "pack_nnb": _i32(nnb, dev),
-                    "rows": rows, "edges": int(e[elig].sum()), "tile_rows": 16 * tiles + 16 * len(nb0),
+                    "num_packs": len(plist), "pack_list": _i32(plist, dev),
+                    "rows": rows, "edges": int(e[elig].sum()), "tile_rows": 16 * tiles + 16 * len(plist),
                     "counter": torch.zeros(1, device=dev, dtype=torch.int32),
                     "oversize_index": None, "oversize_batch": None,
                 }

@@ -38,10 +38,12 @@ FUSED_POOLING = True
 # Neighborhood-resident multi-layer kernel (csrc/shmp_resident.hip): every SHMP layer of a pack of
 # neighborhoods in one launch with the node features in LDS.  "auto": used for target batches with the
 # constant (all-zero) input whose neighborhoods are large enough that aligning each to 16-row tiles
-# wastes little (padded rows / real rows <= RESIDENT_MAX_PAD: Syn_1827 1.13, MSRC-21 + IMDB 1.28,
-# COX2 / MUTAG 2.2 -> those stay on the layer-by-layer kernels); True / False force the choice.
+# wastes little (padded rows / real rows <= RESIDENT_MAX_PAD: Syn_1827 1.13 -> resident, as fast as the
+# layer-by-layer kernels there and bit-for-bit independent of placement; MSRC-21 + IMDB 1.28 and
+# COX2 / MUTAG 2.2 -> layer-by-layer kernels, measured faster: DESIGN.md section 8, round 3);
+# True / False force the choice.
 RESIDENT_SHMP = "auto"
-RESIDENT_MAX_PAD = 1.6
+RESIDENT_MAX_PAD = 1.2
 _RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
@@ -429,8 +431,8 @@ def _shmp_pooled_resident(gnn: BaseGNN, batch) -> torch.Tensor:
     P = H * (core.layer_num + 1)
     pooled = torch.zeros((B, P), device=dev)
     canon = torch.zeros((B, P), device=dev)
-    ops.shmp_resident(batch.count_ptr, batch.vrowptr, batch.vcol, batch.num_count, plan["pack_nb0"],
-                      plan["pack_nnb"], l0, wfrag, bias, pooled, canon, plan["counter"],
+    ops.shmp_resident(batch.count_ptr, batch.vrowptr, batch.vcol, batch.num_count, plan["pack_list"],
+                      l0, wfrag, bias, pooled, canon, plan["counter"],
                       work=(plan["rows"], plan["edges"]))
     canon[:, :H] = pk["pre"]["canonical"][1]                      # x^0 of a canonical row: pre_mp's bias
     anch = ops.gemm_split(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)      # gnn_model.py:69-73

@@ -268,21 +268,19 @@ def resident_limits():
 
 def resident_plan(count_ptr, vrowptr, num_count: int):
     """Host side of the resident kernel's work list (desco_resident_plan): numpy int32 arrays in,
-    (eligible bool [B], pack_nb0 int32 [P], pack_nnb int32 [P]) out."""
+    (eligible bool [B], pack_list int32 [P, 16] of neighborhood indices, -1 = unused slot) out."""
     import ctypes
     import numpy as np
     cp = np.ascontiguousarray(count_ptr, dtype=np.int32)
     vr = np.ascontiguousarray(vrowptr, dtype=np.int32)
     B = len(cp) - 1
     elig = np.zeros(max(B, 1), dtype=np.uint8)
-    nb0 = np.zeros(max(B, 1), dtype=np.int32)
-    nnb = np.zeros(max(B, 1), dtype=np.int32)
+    plist = np.full((max(B, 1), 16), -1, dtype=np.int32)
     npk = ctypes.c_int64()
     _lib.check(_lib.lib().desco_resident_plan(cp.ctypes.data, vr.ctypes.data, B, int(num_count),
-                                              elig.ctypes.data, nb0.ctypes.data, nnb.ctypes.data,
-                                              ctypes.byref(npk)), "resident_plan")
-    P = npk.value
-    return elig[:B].astype(bool), nb0[:P].copy(), nnb[:P].copy()
+                                              elig.ctypes.data, plist.ctypes.data, ctypes.byref(npk)),
+               "resident_plan")
+    return elig[:B].astype(bool), plist[:npk.value].copy()
 
 
 def _fragment_steps(planes: torch.Tensor, order) -> torch.Tensor:
@@ -307,12 +305,13 @@ def resident_fragments(wt_tab: torch.Tensor, wt_canon: torch.Tensor, wt_count: t
 
 
 def shmp_resident(count_ptr: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, num_count: int,
-                  pack_nb0: torch.Tensor, pack_nnb: torch.Tensor, l0coef: torch.Tensor, wfrag: torch.Tensor,
+                  pack_list: torch.Tensor, l0coef: torch.Tensor, wfrag: torch.Tensor,
                   bias: torch.Tensor, pooled: torch.Tensor, canon: torch.Tensor, counter: torch.Tensor,
                   work=None) -> None:
     """All SHMP layers for the packs' neighborhoods in one launch (see desco_hip.h); ``work`` =
     (rows, directed edges) of the packs for the launch profiler."""
-    P = pack_nb0.numel()
+    P = pack_list.shape[0]
+    assert pack_list.dim() == 2 and pack_list.shape[1] == 16 and pack_list.is_contiguous()
     nl = wfrag.shape[0]
     assert wfrag.dtype == torch.int16 and wfrag.is_contiguous() and tuple(wfrag.shape[1:]) == (16, 3, 4, 64, 8)
     assert l0coef.is_contiguous() and tuple(l0coef.shape) == (2, 5, 64)
@@ -321,13 +320,13 @@ def shmp_resident(count_ptr: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Te
     cp_, ldc = _rows(canon, "canon")
     rows, edges = work if work is not None else (0, 0)
     fl = 2.0 * rows * 192 * 64 * nl
-    nb = 4.0 * (edges + 4 * rows) + 2.0 * 4 * 64 * (nl + 1) * max(1, int(P))
+    nb = 4.0 * (edges + 4 * rows)        # CSR once (+ 2 x 256 B per neighborhood and layer, negligible)
     L = _lib.lib()
     with _Timed("shmp_resident_kernel", fl, nb):
         _lib.check(L.desco_shmp_resident_bf16x6_f32(
             _dev(count_ptr, "count_ptr", torch.int32), _dev(vrowptr, "vrowptr", torch.int32),
-            _dev(vcol, "vcol", torch.int32), int(num_count), _dev(pack_nb0, "pack_nb0", torch.int32),
-            _dev(pack_nnb, "pack_nnb", torch.int32), int(P), _dev(l0coef, "l0coef"),
+            _dev(vcol, "vcol", torch.int32), int(num_count), _dev(pack_list, "pack_list", torch.int32),
+            int(P), _dev(l0coef, "l0coef"),
             _dev(wfrag, "wfrag", torch.int16), _dev(bias, "bias"), int(nl), pp, ldp, cp_, ldc,
             _dev(counter, "counter", torch.int32), _stream()), "shmp_resident")
 

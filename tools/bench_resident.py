@@ -54,6 +54,17 @@ def main():
         print(f"resident={mode}: {dt * 1e3:.2f} ms per pass", flush=True)
         for k, v in sorted(ops.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"])[:6]:
             print(f"    {k:40s} {v['calls'] // 3:4d} calls {v['ms'] / 3:9.3f} ms  {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.1f} TF/s")
+    if os.environ.get("RES_PROF"):
+        import ctypes
+        from desco_amd import _lib
+        buf = (ctypes.c_ulonglong * 32)()
+        _lib.lib().desco_debug_resident_prof(buf, 1)
+        names = ["prologue", "heads+closed", "w0 table", "-", "count steps", "wait A", "epilogue",
+                 "wait B", "pool out", "bar+pool(1)"]
+        tot0, tot1 = sum(buf[:12]), sum(buf[16:28])
+        for i, nm_ in enumerate(names):
+            print(f"  phase {nm_:14s} wave0 {100.0 * buf[i] / max(tot0, 1):5.1f} %   waves1-7 {100.0 * buf[16 + i] / max(tot1, 1):5.1f} %")
+        print(f"  phase totals (cycles over all packs/passes): wave0 {tot0:.3e}, waves1-7 {tot1:.3e} (7 waves)")
     d = (out[True] - out[False]).abs().max().item()
     print(f"max |resident - layerwise| logits: {d:.3e} (max |logit| {out[False].abs().max().item():.3e})")
 
