@@ -41,7 +41,7 @@ SIGNATURES = {
     "desco_shmp_layer_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_layer_pool_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
     "desco_shmp_resident_limits": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
-    "desco_resident_plan": (c_int, [vp, vp, i64, i64, vp, vp, POINTER(i64)]),
+    "desco_resident_plan": (c_int, [vp, vp, i64, i64, i32, vp, vp, POINTER(i64)]),
     "desco_shmp_resident_bf16x6_f32": (c_int, [vp, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i64, vp, i64,
                                                vp, vp]),
     "desco_pool_reduce_f32": (c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]),

@@ -745,9 +745,9 @@ extern "C" int desco_shmp_resident_limits(int* max_count_rows, int* max_edges, i
 }
 
 extern "C" int desco_resident_plan(const int32_t* count_ptr, const int32_t* vrowptr, int64_t num_neigh,
-                                   int64_t num_count, uint8_t* eligible, int32_t* pack_list,
-                                   int64_t* num_packs) {
-  if (!count_ptr || !vrowptr || !eligible || !pack_list || !num_packs || num_neigh < 0)
+                                   int64_t num_count, int min_count_rows, uint8_t* eligible,
+                                   int32_t* pack_list, int64_t* num_packs) {
+  if (!count_ptr || !vrowptr || !eligible || !pack_list || !num_packs || num_neigh < 0 || min_count_rows < 1)
     return fail(DESCO_EINVAL, "desco_resident_plan: bad argument");
   // Bin packing by tiles (first fit, largest first): every pack is filled towards the kernel's 30 count
   // tiles, so that its eight waves have the same number of tiles and the per-pack fixed costs are paid as
@@ -760,7 +760,8 @@ extern "C" int desco_resident_plan(const int32_t* count_ptr, const int32_t* vrow
     const int64_t e = ((int64_t)vrowptr[4 * c1] - vrowptr[4 * c0]) +
                       ((int64_t)vrowptr[4 * (num_count + b) + 4] - vrowptr[4 * (num_count + b)]);
     const int64_t t = (n + 15) / 16;
-    const bool ok = n >= 1 && t <= res::MAXCT && e <= res::ECAP;
+    // eligibility is a property of the neighborhood alone: the same choice in every shard / block
+    const bool ok = n >= min_count_rows && t <= res::MAXCT && e <= res::ECAP;
     eligible[b] = ok ? 1 : 0;
     if (ok) {
       tiles[(size_t)b] = (int32_t)t;

@@ -36,14 +36,17 @@ SHMP_BF16X6 = True
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
 # Neighborhood-resident multi-layer kernel (csrc/shmp_resident.hip): every SHMP layer of a pack of
-# neighborhoods in one launch with the node features in LDS.  "auto": used for target batches with the
-# constant (all-zero) input whose neighborhoods are large enough that aligning each to 16-row tiles
-# wastes little (padded rows / real rows <= RESIDENT_MAX_PAD: Syn_1827 1.13 -> resident, as fast as the
-# layer-by-layer kernels there and bit-for-bit independent of placement; MSRC-21 + IMDB 1.28 and
-# COX2 / MUTAG 2.2 -> layer-by-layer kernels, measured faster: DESIGN.md section 8, round 3);
-# True / False force the choice.
-RESIDENT_SHMP = "auto"
-RESIDENT_MAX_PAD = 1.2
+# neighborhoods in one launch with the node features in LDS.  When True, target batches with the constant
+# (all-zero) input send every neighborhood with at least RESIDENT_MIN_ROWS count rows that fits the
+# kernel's pack limits through it and the others (aligning a small neighborhood to 16-row tiles wastes too
+# much) through the layer-by-layer kernels; the rule looks at the neighborhood alone, so every shard /
+# block / rank takes the same path for it, and a packed neighborhood's result is bit-for-bit independent
+# of its placement.  OFF by default: measured end to end it is 5 % (Syn_1827 shapes) to 13 % (MSRC-21 +
+# IMDB shapes) SLOWER than the layer-by-layer kernels (the kernel's count
+# phase is VALU-issue-bound beside its MFMAs and 35 % of its time goes to barriers, epilogues and per-pack
+# set-up).
+RESIDENT_SHMP = False
+RESIDENT_MIN_ROWS = 48
 _RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
@@ -403,29 +406,22 @@ def _resident_operands(pk, core, dev):
 
 
 def _use_resident(gnn: BaseGNN, batch) -> bool:
-    if RESIDENT_SHMP is False or not isinstance(batch, NeighborhoodBatch):
+    if not RESIDENT_SHMP or not isinstance(batch, NeighborhoodBatch):
         return False
     core = gnn.gnn_core
     ok = (batch.node_feature is None and FUSED_SHMP_LAYER and SHMP_BF16X6 and GEMM_BF16X6
           and core.layer_num >= 2 and "wt_tab" in gnn.packed()["layers"][0].get("count", {}))
-    if not ok:
-        if RESIDENT_SHMP is True:
-            raise NotImplementedError("the resident SHMP kernel needs the tconv hetero model on constant input")
-        return False
-    plan = batch.resident_plan()
-    if plan is None or plan["num_packs"] == 0:
-        return False
-    return RESIDENT_SHMP is True or plan["tile_rows"] <= RESIDENT_MAX_PAD * plan["rows"]
+    return bool(ok) and batch.resident_plan(RESIDENT_MIN_ROWS)["num_packs"] > 0
 
 
 def _shmp_pooled_resident(gnn: BaseGNN, batch) -> torch.Tensor:
     """pooled [B, 576] of BaseGNN.forward's hetero path (gnn_model.py:58-107) with ALL layers of the packed
-    neighborhoods in one launch (csrc/shmp_resident.hip); neighborhoods above the kernel's pack limits
-    run through the layer-by-layer kernels as a sub-batch."""
+    neighborhoods in one launch (csrc/shmp_resident.hip); the other neighborhoods (small, or above the
+    kernel's pack limits) run through the layer-by-layer kernels as a sub-batch."""
     pk = gnn.packed()
     core = gnn.gnn_core
     dev = batch.vrowptr.device
-    plan = batch.resident_plan()
+    plan = batch.resident_plan(RESIDENT_MIN_ROWS)
     l0, wfrag, bias = _resident_operands(pk, core, dev)
     B = batch.num_graphs
     P = H * (core.layer_num + 1)
@@ -442,8 +438,8 @@ def _shmp_pooled_resident(gnn: BaseGNN, batch) -> torch.Tensor:
     # block 0: (count rows in the neighborhood) * x0 + anchored canonical row; blocks 1..: + anchored row
     ops.degree_affine(batch.count_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, pooled[:, :H], extra=anch[:, :H])
     pooled[:, H:] += anch[:, H:]
-    if plan["oversize_batch"] is not None:
-        pooled[plan["oversize_index"]] = _shmp_pooled(gnn, plan["oversize_batch"], allow_resident=False)
+    if plan["rest_batch"] is not None:
+        pooled[plan["rest_index"]] = _shmp_pooled(gnn, plan["rest_batch"], allow_resident=False)
     return pooled
 
 

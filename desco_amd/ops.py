@@ -266,7 +266,7 @@ def resident_limits():
     return a.value, b.value, c.value
 
 
-def resident_plan(count_ptr, vrowptr, num_count: int):
+def resident_plan(count_ptr, vrowptr, num_count: int, min_count_rows: int = 1):
     """Host side of the resident kernel's work list (desco_resident_plan): numpy int32 arrays in,
     (eligible bool [B], pack_list int32 [P, 16] of neighborhood indices, -1 = unused slot) out."""
     import ctypes
@@ -278,7 +278,8 @@ def resident_plan(count_ptr, vrowptr, num_count: int):
     plist = np.full((max(B, 1), 16), -1, dtype=np.int32)
     npk = ctypes.c_int64()
     _lib.check(_lib.lib().desco_resident_plan(cp.ctypes.data, vr.ctypes.data, B, int(num_count),
-                                              elig.ctypes.data, plist.ctypes.data, ctypes.byref(npk)),
+                                              int(min_count_rows), elig.ctypes.data, plist.ctypes.data,
+                                              ctypes.byref(npk)),
                "resident_plan")
     return elig[:B].astype(bool), plist[:npk.value].copy()
 

@@ -253,8 +253,10 @@ int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, con
  *          vrowptr / vcol of desco_shmp_layer_*; -1 = unused slot), built by desco_resident_plan (bin
  *          packing towards full packs): <= 16 neighborhoods, <= 30 tiles of 16 count rows (every
  *          neighborhood starts a tile), <= desco_shmp_resident_limits edges; neighborhoods above the
- *          limits are flagged eligible[b] = 0, belong to no pack and must go through the
- *          layer-by-layer entry points.  pack_list must hold 16 * num_neigh entries for the plan.
+ *          limits or with fewer than min_count_rows count rows (tile alignment wastes too much on
+ *          them) are flagged eligible[b] = 0, belong to no pack and must go through the
+ *          layer-by-layer entry points -- a per-neighborhood rule, so every shard decides alike.
+ *          pack_list must hold 16 * num_neigh entries for the plan.
  *   l0coef [2][5][64]: first-layer coefficients, count rows (slots 0..3, constant) then canonical rows
  *          (slots 0, 1, two unused rows, constant): x1 = relu(const + sum_s deg_s coef_s).
  *   wfrag  [num_layers][16][3][4][64][8] bf16: the layers' weight planes as MFMA B fragments in
@@ -273,7 +275,8 @@ int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, con
  * depend on which other neighborhoods share the launch, pack or shard. */
 int desco_shmp_resident_limits(int* max_count_rows, int* max_edges, int* max_neigh);
 int desco_resident_plan(const int32_t* count_ptr, const int32_t* vrowptr, int64_t num_neigh,
-                        int64_t num_count, uint8_t* eligible, int32_t* pack_list, int64_t* num_packs);
+                        int64_t num_count, int min_count_rows, uint8_t* eligible, int32_t* pack_list,
+                        int64_t* num_packs);
 int desco_shmp_resident_bf16x6_f32(const int32_t* count_ptr, const int32_t* vrowptr, const int32_t* vcol,
                                    int64_t num_count, const int32_t* pack_list, int num_packs,
                                    const float* l0coef, const int16_t* wfrag,

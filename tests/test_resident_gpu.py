@@ -29,14 +29,14 @@ def _model(gains=(1.3, 1.4)):
     return nm, queries
 
 
-def _logits(nm, batch, mode):
-    old = GM.RESIDENT_SHMP
-    GM.RESIDENT_SHMP = mode
+def _logits(nm, batch, mode, min_rows=1):
+    old = GM.RESIDENT_SHMP, GM.RESIDENT_MIN_ROWS
+    GM.RESIDENT_SHMP, GM.RESIDENT_MIN_ROWS = mode, min_rows
     try:
         with torch.no_grad():
             return nm._logits(batch, exp2=False)
     finally:
-        GM.RESIDENT_SHMP = old
+        GM.RESIDENT_SHMP, GM.RESIDENT_MIN_ROWS = old
 
 
 def test_fragment_layout_is_the_mfma_b_operand():
@@ -67,8 +67,8 @@ def test_resident_vs_oracle_and_layerwise_on_golden_graphs():
     graphs = golden_graphs(max_n=60)
     part = build_partition(GraphSet.from_edge_lists(graphs), 4)
     batch = NeighborhoodBatch(part, DEV)
-    plan = batch.resident_plan()
-    assert plan["num_packs"] > 1 and plan["oversize_batch"] is None
+    plan = batch.resident_plan(1)
+    assert plan["num_packs"] > 1 and plan["rest_batch"] is None
     res = _logits(nm, batch, True)
     lay = _logits(nm, batch, False)
     _, _, neighs = OP.neighborhood_dataset(graphs, 4)
@@ -95,15 +95,20 @@ def test_resident_dense_shapes_vs_layerwise_incl_oversize_and_hubs():
     nm, queries = _model(gains=(0.8, 1.2))
     part = build_partition(GraphSet.from_edge_lists(_dense_graphs()), 4)
     batch = NeighborhoodBatch(part, DEV)
-    plan = batch.resident_plan()
+    plan = batch.resident_plan(1)
     n = np.diff(part.count_ptr)
     print(f"[shape] {part.num_neigh} neighborhoods, {part.num_rows} rows, max {n.max()} count rows; "
-          f"{plan['num_packs']} packs, oversize {0 if plan['oversize_index'] is None else len(plan['oversize_index'])}")
-    assert plan["oversize_batch"] is not None and n.max() > 500
+          f"{plan['num_packs']} packs, oversize {0 if plan['rest_index'] is None else len(plan['rest_index'])}")
+    assert plan["rest_batch"] is not None and n.max() > 500
     rmax = ops.resident_limits()[0]
-    assert int((n <= rmax).sum()) + len(plan["oversize_index"]) == part.num_neigh
+    assert int((n <= rmax).sum()) + len(plan["rest_index"]) == part.num_neigh
     res = _logits(nm, batch, True)
     lay = _logits(nm, batch, False)
+    # the product setting: small neighborhoods take the layer-by-layer path too
+    mix = _logits(nm, batch, True, min_rows=GM.RESIDENT_MIN_ROWS)
+    pm = batch.resident_plan(GM.RESIDENT_MIN_ROWS)
+    assert 0 < pm["neighborhoods"] < plan["neighborhoods"]
+    torch.testing.assert_close(mix, lay, rtol=1e-4, atol=1e-4)
     assert torch.isfinite(lay).all() and float(lay.std()) > 0
     report("resident vs layer-by-layer (dense)", res, lay)
     torch.testing.assert_close(res, lay, rtol=1e-4, atol=1e-4)
@@ -145,3 +150,12 @@ def test_resident_results_do_not_depend_on_placement():
     assert int(packed.sum()) > 100 and int((~packed).sum()) > 10
     assert torch.equal(sub[packed], want[packed])
     torch.testing.assert_close(sub[~packed], want[~packed], rtol=1e-4, atol=1e-4)
+    # the product setting (neighborhoods under RESIDENT_MIN_ROWS count rows stay on the layer-by-layer kernels):
+    # the packed ones are still bit-identical in any composition
+    mr = GM.RESIDENT_MIN_ROWS
+    full2 = _logits(nm, NeighborhoodBatch(part, DEV), True, min_rows=mr)
+    sub2 = _logits(nm, NeighborhoodBatch(part.select(idx), DEV), True, min_rows=mr)
+    nsel = np.diff(part.count_ptr)[idx]
+    packed2 = torch.from_numpy((nsel <= rmax) & (nsel >= mr)).to(DEV)
+    assert int(packed2.sum()) > 50
+    assert torch.equal(sub2[packed2], full2[torch.from_numpy(idx).to(DEV)][packed2])

@@ -31,10 +31,11 @@ def main():
         gs = gs.replicate(rep)
     part = build_partition_device(gs, 4, dev)
     batch = NeighborhoodBatch(part, dev)
-    plan = batch.resident_plan()
-    print(f"{wl} x{rep}: {part.num_neigh} neighborhoods, {part.num_rows} rows; {plan['num_packs']} packs, "
-          f"{plan['rows']} packed rows ({plan['tile_rows']} with padding), oversize "
-          f"{0 if plan['oversize_index'] is None else len(plan['oversize_index'])}", flush=True)
+    GM.RESIDENT_MIN_ROWS = int(os.environ.get("RES_MIN_ROWS", GM.RESIDENT_MIN_ROWS))
+    plan = batch.resident_plan(GM.RESIDENT_MIN_ROWS)
+    print(f"{wl} x{rep}: {part.num_neigh} neighborhoods, {part.num_rows} rows; min rows {GM.RESIDENT_MIN_ROWS}: "
+          f"{plan['num_packs']} packs, {plan.get('rows', 0)} packed rows ({plan.get('tile_rows', 0)} with padding), "
+          f"other neighborhoods {0 if plan['rest_index'] is None else len(plan['rest_index'])}", flush=True)
     out = {}
     for mode in (False, True):
         GM.RESIDENT_SHMP = mode
