@@ -62,9 +62,11 @@ def mfma_peak(kernel: str):
     return None
 
 
-def build_models(device, seed=0):
+def build_models(device, seed=0, gains=(1.3, 1.4)):
     """Random-init weights of the reference architecture (no checkpoint is reachable offline):
-    default nn.Linear init, matrices widened so that 8 relu layers keep O(1), finite activations."""
+    default nn.Linear init, matrices widened by ``gains`` (neighborhood, gossip model) so that 8 relu
+    layers keep O(1), finite activations: (1.3, 1.4) for molecule-sized neighborhoods, (0.8, 1.2) for the
+    dense shapes (rows there sum over many more neighbours; 2**logit must stay finite)."""
     import torch
     from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
     na = argparse.Namespace(layer_num=8, conv_type="SAGE", use_hetero=True, dropout=0.0, depth=4,
@@ -77,7 +79,7 @@ def build_models(device, seed=0):
     gm = GossipCountingModel(1, 64, ga, emb_channels=64, input_pattern_emb=True)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
-        for m, gain in ((nm, 1.3), (gm, 1.4)):
+        for m, gain in ((nm, gains[0]), (gm, gains[1])):
             for p in m.parameters():
                 if p.dim() == 2:
                     p.mul_(gain)
@@ -171,6 +173,190 @@ def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0):
                       f"value = best of k=1 ({runs[1]:.1f}) and k={phys} physical cores ({runs[phys]:.1f})"}, ref, n
 
 
+def train_leg(device, batch_size=512, stride=4, precision="fp32"):
+    """BASELINE configs 3 / 4 (Syn_1827 training): the neighborhood model's training step -- forward,
+    backward (every op a C-ABI kernel, desco_amd.autograd), Adam -- on REAL-size batches: all 1 827
+    Syn_1827-shaped graphs, the reference's batch of 512 neighborhoods (config.py:255; about 52 k rows per
+    batch on average, 150 k+ for the largest graphs), labels = exact canonical counts of the 29 queries
+    computed on the device (desco_canonical_counts_dev).  shuffle=False (main.py:195) fixes the batch
+    stream; every ``stride``-th batch of the epoch is timed (the batches grow with the graph size, so a
+    prefix is not representative), after one untimed pass over the same batches.  Reference:
+    lightning_model.py:228-254, 160-173."""
+    import torch
+    from desco_amd import autograd as AG, ops, synthetic
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.data import STANDARD_QUERY_IDS, graph_atlas_plus
+    from desco_amd.groundtruth import canonical_counts
+    from desco_amd.partition import build_partition_device
+    AG.set_precision(precision)
+    nm, _ = build_models(device, gains=(0.8, 1.2))
+    nm.set_queries(STANDARD_QUERY_IDS)
+    gs = synthetic.WORKLOADS["syn_1827"]()
+    t0 = time.perf_counter()
+    part = build_partition_device(gs, 4, device)
+    queries = [graph_atlas_plus(i) for i in STANDARD_QUERY_IDS]
+    truth = canonical_counts(gs, queries, backend="auto").float()
+    y_all = truth[torch.from_numpy(part.indicator)]
+    t_prep = time.perf_counter() - t0
+    starts = list(range(0, part.num_neigh, batch_size))[::stride]
+    batches = [NeighborhoodBatch(part.slice(b0, b0 + batch_size), device, y=y_all[b0:b0 + batch_size])
+               for b0 in starts]
+    opt = nm.configure_optimizers()["optimizer"]
+
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = nm.training_step(b, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    first = last = None
+    for b in batches:            # untimed pass: builds the backward indices of every batch, warms caches
+        last = step(b)
+        first = last if first is None else first
+    torch.cuda.synchronize(device)
+    ops.PROFILER.enabled = True
+    ops.PROFILER.reset()
+    t0 = time.perf_counter()
+    for b in batches:
+        last = step(b)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    ops.PROFILER.enabled = False
+    summ = ops.PROFILER.summary()
+    tot = sum(v["ms"] for v in summ.values())
+    n = sum(b.num_graphs for b in batches)
+    rows = sum(b.num_rows for b in batches)
+    # the same steps replayed from hipGraphs (what Trainer(graph_capture=True) / main.py --graph_capture do:
+    # shuffle=False makes every epoch the same batch stream, so a batch's whole step -- forward, backward,
+    # Adam with capturable state -- is captured once and replayed): the eager step is host-bound
+    # (~216 launches + autograd bookkeeping around ~5 ms of kernels)
+    for g_ in opt.param_groups:
+        g_["capturable"] = True
+        g_["lr"] = torch.tensor(float(g_["lr"]), device=device)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    graphs = []
+    with torch.cuda.stream(side):
+        for b in batches[:2]:          # Adam's capturable state is created by an eager step on this stream
+            step(b)
+        for b in batches:
+            opt.zero_grad(set_to_none=True)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                nm.train_forward(b, 0).backward()
+                opt.step()
+            graphs.append(cg)
+        for cg in graphs[:4]:
+            cg.replay()
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for cg in graphs:
+        cg.replay()
+    torch.cuda.synchronize(device)
+    dt_graph = time.perf_counter() - t0
+    del graphs
+    dt_eager, dt = dt, dt_graph
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    peak = {"gemm_f32_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": PEAK_F32_MFMA_TFLOPS,
+            "gemm_tn_partial_kernel": PEAK_F32_MFMA_TFLOPS, "gemm_bf16_kernel": PEAK_BF16_MFMA_TFLOPS,
+            "gemm_split_kernel": PEAK_X6_TFLOPS}.get(name)
+    if peak:
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+    else:
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS}
+    roof.update({"launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"], "share_of_kernel_time": d["ms"] / tot,
+                 "traffic": None})
+    AG.set_precision("fp32")
+    return {
+        "metric": "neighborhoods/s (neighborhood-model training step: forward, backward, Adam)",
+        "value": n / dt, "unit": "neighborhoods/s", "ms_per_step": 1e3 * dt / len(batches),
+        "rows_per_s": rows / dt, "steps": len(batches), "rows_per_step": rows / len(batches),
+        "max_rows_per_step": max(b.num_rows for b in batches), "kernel_ms_per_step": tot / len(batches),
+        "launches_per_step": sum(v["calls"] for v in summ.values()) / len(batches),
+        "launch_mode": "hipGraph replay per batch",
+        "eager": {"value": n / dt_eager, "ms_per_step": 1e3 * dt_eager / len(batches),
+                  "note": "same steps as eager launches with per-launch HIP events (host-bound)"},
+        "dtype": "f32" if precision == "fp32" else "bf16 products, fp32 accumulate", "data": "synthetic",
+        "loss_first_pass_first_batch": float(first), "loss_last_batch": float(last),
+        "config": {"workload": f"Syn_1827-shaped synthetic, all {gs.num_graphs} graphs ({part.num_neigh} neighborhoods, "
+                               f"{part.num_rows} rows), batch {batch_size} neighborhoods, every {stride}-th batch of the "
+                               f"epoch, 29 queries, exact canonical-count labels, Adam (torch)",
+                   "prep_s": round(t_prep, 2)},
+        "roofline": roof,
+        "kernels": {k: {"launches_per_step": round(v["calls"] / len(batches), 1),
+                        "ms_per_step": round(v["ms"] / len(batches), 3)}
+                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+    }
+
+
+def nccl_selftest(args):
+    """--selftest-nccl: the RCCL path without an 8-GPU node.  With >= 2 visible devices, two ranks (one per
+    GPU, backend "nccl") run ONE real neighborhood training step each on their half of a union batch with the
+    gradient buckets all-reduced asynchronously from the autograd hooks (desco_amd.distributed.GradBuckets) and
+    compare the result with the single-process gradient of the union batch; prints one JSON line.  Skips
+    cleanly (status "skipped") on a 1-device box.  Reference: main.py:242-255."""
+    import torch
+    from desco_amd import distributed as D
+    ndev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ:
+        if ndev < 2:
+            print(json.dumps({"selftest": "nccl", "status": "skipped", "reason": f"{ndev} visible device(s); needs 2"}))
+            return 0
+        return D.launch([os.path.abspath(__file__), "--selftest-nccl"], 2, devices=[0, 1], timeout=600)
+    rank, world, _ = D.env_world()
+    device = D.local_device()
+    D.init_from_env(device, backend="nccl")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from desco_amd import synthetic
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.data import STANDARD_QUERY_IDS
+    from desco_amd.partition import build_partition
+    nm, _ = build_models(device, gains=(0.8, 1.2))
+    nm.set_queries(STANDARD_QUERY_IDS)
+    gs = synthetic.syn_1827_shaped(60)
+    part = build_partition(gs, 4)
+    B = min(part.num_neigh, 768)
+    g = torch.Generator().manual_seed(4)
+    y = torch.floor(torch.rand(B, len(STANDARD_QUERY_IDS), generator=g) ** 3 * 40)
+    cut = B // 2 + 37                                   # unequal halves: count-weighted mean loss
+    lo, hi = (0, cut) if rank == 0 else (cut, B)
+    mine = NeighborhoodBatch(part.slice(lo, hi), device, y=y[lo:hi])
+    params = [p for p in nm.parameters() if p.requires_grad]
+    bk = D.GradBuckets(params, 4)
+    bk.zero()
+    (nm.training_step(mine, 0) * ((hi - lo) / B)).backward()     # bucket all-reduces start from the hooks
+    issued = bk._next
+    bk.finish()
+    got = [p.grad.detach().clone() for p in params]
+    bk.close()
+    for p in params:
+        p.grad = None
+    union = NeighborhoodBatch(part.slice(0, B), device, y=y)
+    nm.training_step(union, 0).backward()
+    worst = 0.0
+    for gdist, p in zip(got, params):
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        den = float(ref.abs().max()) + 1e-12
+        worst = max(worst, float((gdist - ref).abs().max()) / den)
+    t = torch.tensor([worst], device=device)
+    D.all_reduce_(t, "max")
+    if rank == 0:
+        ok = float(t) < 1e-4
+        print(json.dumps({"selftest": "nccl", "status": "ok" if ok else "FAILED", "world": world,
+                          "backend": torch.distributed.get_backend(), "buckets": len(bk.buckets),
+                          "buckets_issued_from_hooks": issued, "grad_bytes": sum(b.numel() for b in bk.buckets) * 4,
+                          "worst_rel_grad_diff_vs_union_batch": float(t)}))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if float(t) < 1e-4 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +382,15 @@ def main():
                     help="(node x query) row budget of a gossip block (InferencePipeline max_gossip_rows)")
     ap.add_argument("--by-shape", action="store_true",
                     help="diagnostic: key GEMM launches by shape in the kernel table")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training leg (Syn_1827-shaped neighborhood training steps, N=1 only)")
+    ap.add_argument("--train-stride", type=int, default=4, help="training leg: time every k-th batch of the epoch")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--selftest-nccl", action="store_true",
+                    help="2-rank RCCL gradient all-reduce check (needs 2 visible GPUs; skips otherwise)")
     args = ap.parse_args()
+    if args.selftest_nccl:
+        sys.exit(nccl_selftest(args))
 
     from desco_amd import distributed as D      # (imports torch; no GPU call)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,9 +458,7 @@ def main():
         gathered = pipe.gather(out)
         if rank == 0:
             assert gathered["graph_gossip_count"].shape[0] == graphs.num_graphs
-            # (random-init weights: 2**logit overflows to +inf on the dense shapes -- Syn_1827, MSRC+IMDB --
-            # exactly as the reference's formula would; a NaN would be a bug)
-            assert not torch.isnan(gathered["graph_gossip_count"]).any()
+            assert torch.isfinite(gathered["graph_gossip_count"]).all()
     elif world > 1:
         g_all = D.gather_rows(out["graph_gossip_count"])
         if rank == 0:
@@ -276,14 +468,19 @@ def main():
     # secondary workloads (every rank runs them; rank 0 reports): weak scaling, 3 timed steps
     secondary = {}
     if not args.no_secondary:
+        # narrower random-init weights for the dense shapes, so that every output is finite and checked
+        nm2, gm2 = build_models(device, gains=(0.8, 1.2))
+        nm2.set_queries(STANDARD_QUERY_IDS)
         for wname, wrep in (("syn_1827", 2), ("msrc_imdb", 8)):
             if wname == args.workload:
                 continue
             g2 = synthetic.WORKLOADS[wname]().replicate(wrep)
-            p2 = InferencePipeline(nm, gm, g2, depth=4, device=device, max_neigh_rows=args.neigh_rows,
+            p2 = InferencePipeline(nm2, gm2, g2, depth=4, device=device, max_neigh_rows=args.neigh_rows,
                                    max_gossip_rows=args.gossip_rows, rank=0, world=1)
-            p2.run()
+            o2 = p2.run()
             sync()
+            assert torch.isfinite(o2["graph_gossip_count"]).all() and torch.isfinite(o2["node_count"]).all(), wname
+            del o2
             ops.PROFILER.enabled = True
             ops.PROFILER.reset()
             t0 = time.perf_counter()
@@ -301,6 +498,7 @@ def main():
             gk = summ2.get(gather_kernel())
             dom, dd = max(summ2.items(), key=lambda kv: kv[1]["ms"])
             entry = {"value": g2.num_graphs * world * 3 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt / 3,
+                     "outputs": "finite (checked); random-init weights with gains (0.8, 1.2)",
                      "graphs_per_gpu": g2.num_graphs, "neighborhood_rows_per_gpu": p2.partition.num_rows,
                      "neighborhood_directed_edges_per_gpu": p2.partition.num_edges,
                      "dominant_kernel": dom, "dominant_share_of_kernel_time": dd["ms"] / tot2}
@@ -314,6 +512,7 @@ def main():
             secondary[f"{wname}_x{wrep}"] = entry
             del p2, g2
             torch.cuda.empty_cache()
+        del nm2, gm2
 
     graphs_per_step = graphs.num_graphs if strong else graphs.num_graphs * world
     value = graphs_per_step * args.steps / elapsed
@@ -353,9 +552,26 @@ def main():
             # workload (tools/profile_round.sh; gfx950-corrected), keyed "<workload>_x<replicas>"
             pmc = pmc_all.get("workloads", {}).get(f"{args.workload}_x{args.replicas}", {})
 
-            def traffic(kernel):
+            stale = []
+
+            def traffic(kernel, algorithmic=None, hbm_bound=False):
+                """HBM bytes per launch of ``kernel`` from the committed PMC passes -- only if they were
+                taken on a tree with the SAME launches per step as this run (else the figure belongs to other
+                launches: null + a note) and, for an HBM-bound kernel, not below 0.9 x its algorithmic bytes
+                (a kernel cannot move less than it must: such a figure is an artefact)."""
                 e = pmc.get("kernels", {}).get(kernel)
-                return None if not e or world != 1 else e["hbm_bytes_per_launch"]
+                if not e or world != 1 or kernel not in summ:
+                    return None
+                live = summ[kernel]["calls"] / args.steps
+                lps = e.get("launches_per_step")
+                if lps is None or abs(lps - live) > 1e-6:
+                    stale.append(f"{kernel}: PMC pass has {lps} launches/step, this run {live:g}")
+                    return None
+                t = e["hbm_bytes_per_step"] / lps
+                if hbm_bound and algorithmic and t < 0.9 * algorithmic:
+                    stale.append(f"{kernel}: PMC traffic {t:.3e} B/launch below 0.9 x algorithmic {algorithmic:.3e}")
+                    return None
+                return t
 
             mp = mfma_peak(name)
             if mp is not None:
@@ -369,7 +585,7 @@ def main():
             else:
                 ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic(name)}
+                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic(name, d["bytes"] / calls, hbm_bound=True)}
             roof.update({"kernel": name, "launches": calls, "avg_launch_ms": d["ms"] / calls,
                          "share_of_kernel_time": d["ms"] / tot,
                          "algorithmic_per_launch": (d["flops"] if roof["bound"] == "mfma" else d["bytes"]) / calls,
@@ -380,8 +596,8 @@ def main():
             if gk and gk["ms"] > 0:
                 gbs = gk["bytes"] / (gk["ms"] * 1e-3) / 1e9
                 tfs = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-                tr = traffic(gather_kernel())
                 alg = gk["bytes"] / gk["calls"]
+                tr = traffic(gather_kernel(), alg, hbm_bound=True)
                 roof["gather"] = {
                     "kernel": gather_kernel(), "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches": gk["calls"],
@@ -404,6 +620,8 @@ def main():
                             "note": "bare MFMA loop of that shape on random data on this device, measured in this "
                                     "run (tools/micro/mfma_peak): the chip lowers its clock under dense matrix "
                                     "work, so the datasheet peak (2.4 GHz) is not reachable by any kernel"}
+            if stale:
+                roof["stale_pmc"] = stale
             result["roofline"] = roof
             result["kernels"] = {
                 k: {"calls": v["calls"], "ms": round(v["ms"], 3),
@@ -432,6 +650,11 @@ def main():
             lat["note"] = ("one pass over the un-replicated dataset; InferencePipeline.step() replays a "
                            "hipGraph for shards under 400k neighborhood rows (launch-bound otherwise)")
             result["latency_x1"] = lat
+        # ---- training leg (BASELINE configs 3 / 4), N=1 only -------------------------------------------------
+        if world == 1 and not args.no_train:
+            del pipe
+            torch.cuda.empty_cache()
+            result["train_syn_1827"] = train_leg(device, stride=args.train_stride, precision=args.train_precision)
         # ---- CPU baseline (N=1 only) + parity of the sample ------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as f:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json.
 
-usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>" [<workload key, e.g. cox2_x64>] [<round tag>]
+usage: tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> "<command>" [<workload key, e.g. cox2_x64>] [<round tag>] [<passes = steps + warmup of the command>]
 The output file holds one entry per workload key ("<workload>_x<replicas>", what bench.py looks up);
 an existing file is updated in place.
 Per kernel and launch: raw counters (KB) and HBM bytes corrected as MI355X_MICROARCH.md (HBM
@@ -37,14 +37,18 @@ def load(path, cname):
 def main():
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     key = sys.argv[5] if len(sys.argv) > 5 else "cox2_x64"
+    passes = int(sys.argv[7]) if len(sys.argv) > 7 else 3
     entry = {"command": sys.argv[4] if len(sys.argv) > 4 else "", "round": sys.argv[6] if len(sys.argv) > 6 else "",
-             "kernels": {}}
+             "passes": passes, "kernels": {}}
     for k in sorted(f, key=lambda k: -f[k][1]):
         if "_kernel" not in k:
             continue
         fk = f[k][1] / f[k][0]
         wk = w[k][1] / w[k][0] if k in w and w[k][0] else 0.0
-        entry["kernels"][k] = {"launches": f[k][0], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+        # per STEP figures: bench.py compares launches_per_step with the live run before using the bytes
+        entry["kernels"][k] = {"launches": f[k][0], "launches_per_step": f[k][0] / passes,
+                               "hbm_bytes_per_step": (2 * fk + wk) * 1024 * f[k][0] / passes,
+                               "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                                "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
                                "hbm_bytes_per_launch_uncorrected": (fk + wk) * 1024}
     try:

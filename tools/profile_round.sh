@@ -21,18 +21,18 @@ for WL in $WLS; do
   python3 bench.py $ARGS --steps 10 --warmup 3 > $OUT/bench_$K.json 2> $OUT/bench_$K.err
   head -c 300 $OUT/bench_$K.json; echo
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$K -- python3 $ROOT/bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-x1 --no-secondary --no-attainable > $OUT/stats_$K.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$K -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-profile > $OUT/pmc_fetch_$K.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$K -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-profile > $OUT/pmc_write_$K.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$K -- python3 $ROOT/bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train > $OUT/stats_$K.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$K -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train --no-profile > $OUT/pmc_fetch_$K.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$K -- python3 $ROOT/bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train --no-profile > $OUT/pmc_write_$K.log 2>&1
   i=0
   for P in "$P1" "$P2" "$P3"; do
     i=$((i+1))
-    rocprofv3 --pmc $P --output-format csv -d $OUT/sq_${K}_p$i -- python3 $ROOT/bench.py $ARGS --steps 1 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-profile > $OUT/sq_${K}_p$i.log 2>&1
+    rocprofv3 --pmc $P --output-format csv -d $OUT/sq_${K}_p$i -- python3 $ROOT/bench.py $ARGS --steps 1 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train --no-profile > $OUT/sq_${K}_p$i.log 2>&1
   done
   cd $ROOT
   F=$(find $OUT/pmc_fetch_$K -name "*counter_collection.csv" | head -1)
   Wf=$(find $OUT/pmc_write_$K -name "*counter_collection.csv" | head -1)
-  python3 tools/pmc_summary.py "$F" "$Wf" $OUT/pmc_traffic.json "python3 bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-profile" $K $TAG > /dev/null
+  python3 tools/pmc_summary.py "$F" "$Wf" $OUT/pmc_traffic.json "python3 bench.py $ARGS --steps 2 --warmup 1 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train --no-profile" $K $TAG 3 > /dev/null
   S=$(find $OUT/stats_$K -name "*kernel_stats.csv" | head -1)
   cp "$S" $OUT/kernel_stats_$K.csv 2>/dev/null
   python3 - "$OUT" "$K" <<'PY'
@@ -62,4 +62,4 @@ PY
   find $OUT/stats_$K $OUT/pmc_fetch_$K $OUT/pmc_write_$K $OUT/sq_${K}_p1 $OUT/sq_${K}_p2 $OUT/sq_${K}_p3 -name "*.csv" ! -name "*kernel_stats.csv" -delete 2>/dev/null
   head -6 $OUT/kernel_stats_$K.csv
 done
-python3 bench.py --steps 50 --warmup 5 --replicas 1 --no-cpu-baseline > $OUT/bench_cox2_x1.json 2>> $OUT/bench_cox2_x64.err
+python3 bench.py --steps 50 --warmup 5 --replicas 1 --no-cpu-baseline --no-train > $OUT/bench_cox2_x1.json 2>> $OUT/bench_cox2_x64.err
