@@ -380,6 +380,9 @@ def main():
                     help="row budget of a neighborhood block (InferencePipeline max_neigh_rows)")
     ap.add_argument("--gossip-rows", type=int, default=4_000_000,
                     help="(node x query) row budget of a gossip block (InferencePipeline max_gossip_rows)")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="placement-independent mode (InferencePipeline chunks): N ranks reproduce the 1-rank "
+                         "result bit for bit; a multiple of --gpus")
     ap.add_argument("--by-shape", action="store_true",
                     help="diagnostic: key GEMM launches by shape in the kernel table")
     ap.add_argument("--no-train", action="store_true",
@@ -423,7 +426,7 @@ def main():
     t0 = time.perf_counter()
     pipe = InferencePipeline(nm, gm, graphs, depth=4, device=device, max_neigh_rows=args.neigh_rows,
                              max_gossip_rows=args.gossip_rows,
-                             rank=rank if strong else 0, world=world if strong else 1)
+                             rank=rank if strong else 0, world=world if strong else 1, chunks=args.chunks)
     t_build = time.perf_counter() - t0
     part = pipe.partition
 

@@ -38,14 +38,24 @@ class InferencePipeline:
                  max_gossip_rows: int = 4_000_000, num_threads: int = 0,
                  partition: Optional[NeighborhoodPartition] = None,
                  partition_backend: str = "device", rank: Optional[int] = None,
-                 world: Optional[int] = None, graph_replay_rows: int = 400_000):
+                 world: Optional[int] = None, graph_replay_rows: int = 400_000,
+                 chunks: Optional[int] = None):
         """``rank`` / ``world`` (default: the initialised torch.distributed group): this process
         keeps the ``rank``-th of ``world`` contiguous, cost-balanced graph ranges
         (distributed.shard_graphs) with all their neighborhoods -- no data-path collective; the
         results of all ranks are assembled in dataset order by ``gather()``.
         ``graph_replay_rows``: ``step()`` replays the pass from a hipGraph when the shard has fewer
         neighborhood rows than this (a 467-graph COX2 pass is ~70 launches of a few microseconds:
-        launch-bound when issued eagerly)."""
+        launch-bound when issued eagerly).
+        ``chunks`` (None, or a multiple of ``world``): placement-independent mode.  The WHOLE dataset is
+        first cut into ``chunks`` contiguous cost-balanced graph ranges -- a decomposition that does not
+        depend on the number of ranks -- and every chunk is processed through launches of its own
+        (neighborhood block, gossip blocks), exactly as a stand-alone pipeline on that chunk would; rank r
+        takes chunks [r chunks / world, (r + 1) chunks / world), which is the same graph range
+        ``shard_graphs`` gives it.  A chunk's launches see the same rows in the same tiles whichever rank
+        runs them, so N ranks reproduce the 1-rank result BIT FOR BIT (without it they agree to fp32
+        rounding: a neighborhood's pooled partial sums depend on where 16-row tiles cut it).
+        Costs one launch set per chunk instead of one per 32 M-row block: off by default."""
         from . import distributed as D
         self.nm, self.gm = neigh_model, gossip_model
         self.rank = D.rank() if rank is None else int(rank)
@@ -54,12 +64,26 @@ class InferencePipeline:
             raise ValueError(f"rank {self.rank} outside world of {self.world}")
         self.num_graphs_total = graphs.num_graphs
         self.graph_range = (0, graphs.num_graphs)
-        if self.world > 1:
+        self.chunks = None if chunks is None else int(chunks)
+        chunk_cuts = None                       # graph boundaries of this rank's chunks, relative to its shard
+        Q0 = len(getattr(neigh_model, "queries_flat", [])) or 29
+        if self.chunks is not None:
+            if self.chunks < 1 or self.chunks % self.world:
+                raise ValueError(f"chunks = {self.chunks} must be a positive multiple of world = {self.world}")
+            if partition is not None:
+                raise ValueError("chunks: let the pipeline build the partition")
+            ranges = D.contiguous_shards(D.graph_costs(graphs, Q0), self.chunks)
+            per = self.chunks // self.world
+            mine = ranges[self.rank * per:(self.rank + 1) * per]
+            self.graph_range = (mine[0][0], mine[-1][1])
+            chunk_cuts = [mine[0][0] - self.graph_range[0]] + [b - self.graph_range[0] for _, b in mine]
+            graphs = graphs.subset(*self.graph_range)
+        elif self.world > 1:
             if partition is not None:
                 raise ValueError("pass the partition of the local shard, or let the pipeline build it")
-            Q = len(getattr(neigh_model, "queries_flat", [])) or 29
-            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q)
+            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q0)
         self.graphs = graphs
+        self._chunk_cuts = chunk_cuts
         from .batch import _norm_device
         self.device = _norm_device(device)
         device = self.device
@@ -96,16 +120,23 @@ class InferencePipeline:
         self.num_queries = None
         # neighborhood blocks by row budget
         rows_per_neigh = np.diff(part.count_ptr).astype(np.int64) + 1
-        cuts = _split_by_budget(rows_per_neigh, max_neigh_rows)
+        per_graph = np.bincount(part.neigh_index[:, 0], minlength=graphs.num_graphs)
+        ngp = np.concatenate([[0], np.cumsum(per_graph)]).astype(np.int64)     # neighborhoods are ordered by graph
+        if self._chunk_cuts is None:
+            cuts = _split_by_budget(rows_per_neigh, max_neigh_rows)
+        else:       # a block never crosses a chunk boundary, and is cut by the budget from the chunk's start
+            cuts = [0]
+            for ga, gb in zip(self._chunk_cuts[:-1], self._chunk_cuts[1:]):
+                a, b = int(ngp[ga]), int(ngp[gb])
+                if b > a:
+                    cuts += [a + c for c in _split_by_budget(rows_per_neigh[a:b], max_neigh_rows)[1:]]
         self.neigh_batches = [NeighborhoodBatch(part.slice(b0, b1), device)
-                              for b0, b1 in zip(cuts[:-1], cuts[1:])]
+                              for b0, b1 in zip(cuts[:-1], cuts[1:]) if b1 > b0]
         # neighborhood b -> node row of the gossip x matrix (apply_neighborhood_count)
         rows = graphs.graph_ptr[part.neigh_index[:, 0]] + part.neigh_index[:, 1]
         self.scatter_index = torch.from_numpy(rows.astype(np.int32)).to(device)
         # neighborhoods are ordered by graph: segment pointer for aggregate_neighborhood_count
-        per_graph = np.bincount(part.neigh_index[:, 0], minlength=graphs.num_graphs)
-        self.neigh_graph_ptr = torch.from_numpy(
-            np.concatenate([[0], np.cumsum(per_graph)]).astype(np.int32)).to(device)
+        self.neigh_graph_ptr = torch.from_numpy(ngp.astype(np.int32)).to(device)
         self.node_graph_ptr = torch.from_numpy(graphs.graph_ptr.astype(np.int32)).to(device)
         # gossip blocks by (node x query) row budget, cut on graph boundaries
         self._gossip_cuts_budget = max_gossip_rows
@@ -115,7 +146,13 @@ class InferencePipeline:
         if self.gossip_batches is not None and self.num_queries == Q:
             return
         sizes = np.diff(self.graphs.graph_ptr) * Q
-        cuts = _split_by_budget(sizes, self._gossip_cuts_budget)
+        if self._chunk_cuts is None:
+            cuts = _split_by_budget(sizes, self._gossip_cuts_budget)
+        else:
+            cuts = [0]
+            for ga, gb in zip(self._chunk_cuts[:-1], self._chunk_cuts[1:]):
+                if gb > ga:
+                    cuts += [ga + c for c in _split_by_budget(sizes[ga:gb], self._gossip_cuts_budget)[1:]]
         self.gossip_batches = []
         for g0, g1 in zip(cuts[:-1], cuts[1:]):
             n0, n1 = int(self.graphs.graph_ptr[g0]), int(self.graphs.graph_ptr[g1])

@@ -22,11 +22,12 @@ def main():
     import multirank_common as C
     from desco_amd.graphs import GraphSet
     res = {}
-    if mode == "pipeline":
+    if mode in ("pipeline", "pipeline_chunks"):
         from desco_amd.pipeline import InferencePipeline
         nm, gm, qids, queries = C.models(dev)
         gs = GraphSet.from_edge_lists(C.mixed_graphs())
-        pipe = InferencePipeline(nm, gm, gs, depth=4, device=dev)      # rank / world from the group
+        pipe = InferencePipeline(nm, gm, gs, depth=4, device=dev,      # rank / world from the group
+                                 chunks=C.CHUNKS if mode == "pipeline_chunks" else None)
         assert (pipe.rank, pipe.world) == (rank, world)
         out = pipe.run()
         full = pipe.gather(out, node_level=True)

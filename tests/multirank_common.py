@@ -40,3 +40,4 @@ def gossip_inputs(num_nodes, num_q, seed=7):
 TRAIN_GRAPHS = 16          # graphs of the training checks
 NEIGH_BATCH = 96           # neighborhoods per DataLoader batch there (ragged last batch)
 GOSSIP_BATCH = 5           # graphs per gossip batch (16 graphs -> 4 batches, last one short)
+CHUNKS = 4                 # placement-independent mode of InferencePipeline (rank-count-independent chunks)

@@ -65,6 +65,28 @@ def test_two_rank_pipeline_equals_one_rank(tmp_path):
     assert float(one["graph_gossip_count"].abs().max()) > 1e-3
 
 
+def test_two_rank_pipeline_is_bit_identical_to_one_rank_in_chunk_mode(tmp_path):
+    """SURVEY 8e, "N ranks == 1 rank": with the dataset cut into rank-count-independent chunks
+    (InferencePipeline(chunks=...)) every chunk runs through the same launches whichever rank owns it, so
+    the 2-rank result equals the 1-rank result bit for bit -- per graph, per node, per neighborhood."""
+    from desco_amd.pipeline import InferencePipeline
+    r0, r1 = _run2("pipeline_chunks", tmp_path)
+    nm, gm, qids, queries = C.models(DEV)
+    gs = GraphSet.from_edge_lists(C.mixed_graphs())
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV, rank=0, world=1, chunks=C.CHUNKS)
+    assert len(pipe.neigh_batches) == C.CHUNKS
+    one = pipe.run()
+    (a0, b0), (a1, b1) = r0["range"], r1["range"]
+    assert a0 == 0 and b0 == a1 and b1 == gs.num_graphs and 0 < b0 < gs.num_graphs
+    for k in ("graph_neigh_count", "graph_gossip_count", "neigh_count", "node_count", "x"):
+        assert torch.equal(r0[k], one[k].cpu()), k
+    # and the chunked 1-rank run agrees with the un-chunked one to fp32 rounding
+    plain = InferencePipeline(nm, gm, gs, depth=4, device=DEV, rank=0, world=1).run()
+    for k in ("graph_gossip_count", "node_count"):
+        worst = float(((one[k] - plain[k]).abs() / (1.0 + plain[k].abs())).max())
+        assert worst < 1e-4, (k, worst)
+
+
 def test_more_ranks_than_graphs(tmp_path):
     from desco_amd.pipeline import InferencePipeline
     r0, r1 = _run2("tiny", tmp_path)
