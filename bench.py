@@ -212,17 +212,18 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
 
     first = last = None
     for b in batches:            # untimed pass: builds the backward indices of every batch, warms caches
-        last = step(b)
-        first = last if first is None else first
+        last = step(b).detach()  # (detached: a kept loss would keep its autograd graph -- and the AccumulateGrad
+        first = last if first is None else first        # nodes of this stream -- alive into the capture below)
     torch.cuda.synchronize(device)
     ops.PROFILER.enabled = True
     ops.PROFILER.reset()
     t0 = time.perf_counter()
     for b in batches:
-        last = step(b)
+        last = step(b).detach()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     ops.PROFILER.enabled = False
+    first, last = float(first), float(last)
     summ = ops.PROFILER.summary()
     tot = sum(v["ms"] for v in summ.values())
     n = sum(b.num_graphs for b in batches)
@@ -231,15 +232,17 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     # shuffle=False makes every epoch the same batch stream, so a batch's whole step -- forward, backward,
     # Adam with capturable state -- is captured once and replayed): the eager step is host-bound
     # (~216 launches + autograd bookkeeping around ~5 ms of kernels)
-    for g_ in opt.param_groups:
-        g_["capturable"] = True
-        g_["lr"] = torch.tensor(float(g_["lr"]), device=device)
+    lr0 = float(opt.param_groups[0]["lr"])
+    del opt
+    opt = torch.optim.Adam(nm.parameters(), lr=torch.tensor(lr0, device=device), capturable=True)
     side = torch.cuda.Stream(device)
     side.wait_stream(torch.cuda.current_stream(device))
     graphs = []
     with torch.cuda.stream(side):
-        for b in batches[:2]:          # Adam's capturable state is created by an eager step on this stream
-            step(b)
+        for b in batches[:2]:          # Adam's (device-resident, capturable) state is created by eager steps
+            opt.zero_grad(set_to_none=True)
+            nm.train_forward(b, 0).backward()
+            opt.step()
         for b in batches:
             opt.zero_grad(set_to_none=True)
             cg = torch.cuda.CUDAGraph()
