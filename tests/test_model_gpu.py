@@ -35,7 +35,7 @@ def test_query_embeddings(setup):
     got = nm.get_query_emb()
     ref = OM.neighborhood_embed_queries(cpu_sd(nm), OP.query_batch(queries), 8)
     report("query_emb", got, ref)
-    torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5)        # measured 2.0e-6 (29 graphs, 135 nodes)
 
 
 @pytest.mark.parametrize("quirk", [0, 512, 16])
@@ -87,7 +87,9 @@ def test_gossip_vs_oracle(setup):
     ref = OM.gossip_graph_to_count(cpu_sd(gm), x, batch.edge_index.numpy(), qemb.cpu(), 2)
     report("gossip_pred", got, ref)
     report("gossip_corr", got.cpu() - x, ref - x)
-    torch.testing.assert_close(got.cpu() - x, ref - x, rtol=RTOL, atol=ATOL)
+    # corrections of magnitude 2.5: measured 3.8e-6 (the fp32-accurate six-product form); the gate is 2e-5 -- a
+    # two-plane activation form measured 8.2e-5 and was declined for that (profiles/r3_b_ab_gossip_two_plane.log)
+    torch.testing.assert_close(got.cpu() - x, ref - x, rtol=2e-5, atol=2e-5)
     gates = gm._gate_value(qemb)
     torch.testing.assert_close(gates.cpu(), OM.gossip_gate_values(cpu_sd(gm), qemb.cpu()),
                                rtol=1e-5, atol=1e-6)
