@@ -94,6 +94,122 @@ class Linear(torch.autograd.Function):
         return da1, da2, dwt, dbias, None, None
 
 
+# (fp32 precision runs on v_mfma_f32_32x32x2_f32: the six-product bf16 form of gemm_split.hip was measured on the
+#  real-size training batches -- 54 k rows, N = 64 / 320 -- at 35 us per launch against 26 us, 7.02 vs 6.58 ms per
+#  replayed step, and pushes one gradient tensor to 2e-3 of the oracle's: not used here)
+def _mm_fwd(a1, a2, wt, bias, act, slope, out=None):
+    """act([a1 | a2] @ wt + bias) in the training precision (see Linear)."""
+    if PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0:
+        return ops.gemm_bf16(a1, ops.round_bf16(wt.t()), bias, a2=a2, act=act, slope=slope, out=out)
+    return ops.gemm(a1, wt, bias, a2=a2, act=act, slope=slope, out=out)
+
+
+def _mm_bwd_da(dz, wt, out=None):
+    """dA = dZ @ wt^T  ([m, n] x [k, n]^T -> [m, k])."""
+    if PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0:
+        return ops.gemm_bf16(dz, ops.round_bf16(wt), out=out)
+    return ops.gemm(dz, wt.t().contiguous(), out=out)
+
+
+class ShmpTrunk(torch.autograd.Function):
+    """BaseGNNCore.forward's SAGE loop (gnn_model.py:253-277) + anchor_mlp on the canonical rows (:69-73) +
+    global_add_pool per layer block (:88-89, 107) as ONE autograd node: pooled [B, 64 (L+1)] from x0 [N, 64]
+    and the folded per-layer weights.  Forward and backward are C-ABI launches on buffers this node owns --
+    no torch.cat / slice / accumulate kernels between them (the per-op autograd wiring of round 2 spent as
+    much GPU time in ~900 torch glue launches per step as in the 216 kernels that do the work).
+
+    args: x0, batch (NeighborhoodBatch / QueryBatch), groups [(type, r0, r1, su)], num_layers, has_anchor,
+          then tensors: [anchor wt (K-major [P, P]), anchor bias] if has_anchor, then per layer and group
+          (wt [(su+1) 64, 64], bias [64]).
+    Gradient of a row of X_l = pooling broadcast + (canonical rows) its column block of d(anchor operand) +
+    self block + transposed gather of the aggregate blocks of layer l: assembled in one buffer per layer."""
+
+    @staticmethod
+    def forward(ctx, x0, batch, groups, num_layers, has_anchor, *w):
+        ti = batch.train_index()
+        N, S = batch.num_rows, batch.slots
+        dev = x0.device
+        H = 64
+        k = 2 if has_anchor else 0
+        aw, ab = (w[0], w[1]) if has_anchor else (None, None)
+        lw = [[(w[k + 2 * (l * len(groups) + g)], w[k + 2 * (l * len(groups) + g) + 1])
+               for g in range(len(groups))] for l in range(num_layers)]
+        Nc = groups[0][2] if has_anchor else N
+        seg_ptr = batch.count_ptr if has_anchor else batch.graph_ptr
+        B = batch.num_graphs
+        P = H * (num_layers + 1)
+        X, AGG = [x0.contiguous()], []
+        for l in range(num_layers):
+            agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
+            xn = torch.empty((N, H), device=dev)
+            for (t, r0, r1, su), (wt, b) in zip(groups, lw[l]):
+                if r1 > r0:
+                    _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], wt.contiguous(), b, ops.ACT_RELU, 0.0, out=xn[r0:r1])
+            AGG.append(agg)
+            X.append(xn)
+        pooled = torch.empty((B, P), device=dev)
+        canon = anch = None
+        if has_anchor:
+            canon = torch.empty((B, P), device=dev)
+            for l, xl in enumerate(X):
+                canon[:, l * H:(l + 1) * H] = xl[Nc:]
+            anch = _mm_fwd(canon, None, aw.contiguous(), ab, ops.ACT_LEAKY, 0.1)
+        for l, xl in enumerate(X):
+            ops.segment_sum(xl[:Nc], seg_ptr, B, extra=None if anch is None else anch[:, l * H:(l + 1) * H],
+                            out=pooled[:, l * H:(l + 1) * H])
+        ctx.batch, ctx.groups, ctx.num_layers, ctx.has_anchor = batch, groups, num_layers, has_anchor
+        ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
+        ctx.save_for_backward(*w)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        w = ctx.saved_tensors
+        batch, groups, L, has_anchor = ctx.batch, ctx.groups, ctx.num_layers, ctx.has_anchor
+        X, AGG = ctx.X, ctx.AGG
+        ti = batch.train_index()
+        N, S = batch.num_rows, batch.slots
+        H = 64
+        dev = dpooled.device
+        k = 2 if has_anchor else 0
+        Nc = groups[0][2] if has_anchor else N
+        dpooled = dpooled.contiguous()
+        grads = [None] * len(w)
+        dcanon = None
+        if has_anchor:
+            aw, canon, anch = w[0], ctx.canon, ctx.anch
+            dza = ops.act_grad(dpooled, anch, ops.ACT_LEAKY, 0.1)                 # extra rows pass the gradient on
+            grads[0], grads[1] = ops.linear_bwd_w(canon, None, dza, True)
+            dcanon = _mm_bwd_da(dza, aw.contiguous())                             # [B, P]
+
+        def seed(l):
+            """gradient of X_l from the pooling (count rows) and from the anchor operand (canonical rows)"""
+            e = torch.empty((N, H), device=dev)
+            ops.csr_gather_sum(dpooled[:, l * H:(l + 1) * H], ti["ident_ptr"], ti["seg_id"], Nc, 1, out=e[:Nc])
+            if has_anchor:
+                e[Nc:] = dcanon[:, l * H:(l + 1) * H]
+            return e
+
+        dxn = seed(L)
+        D = torch.empty((N, (S + 1) * H), device=dev)
+        for l in range(L - 1, -1, -1):
+            dz = ops.act_grad(dxn, X[l + 1], ops.ACT_RELU, 0.0)
+            e = seed(l)
+            for g, (t, r0, r1, su) in enumerate(groups):
+                if r1 <= r0:
+                    continue
+                wi = k + 2 * (l * len(groups) + g)
+                wt = w[wi].contiguous()
+                dwt, db = ops.linear_bwd_w(AGG[l][r0:r1, :su * H], X[l][r0:r1], dz[r0:r1], True)
+                grads[wi], grads[wi + 1] = dwt, db
+                _mm_bwd_da(dz[r0:r1], wt, out=D[r0:r1, :(su + 1) * H])
+                ops.add_rows(e[r0:r1], D[r0:r1, su * H:(su + 1) * H])              # self block
+            # aggregate blocks: transposed gather over the virtual rows (row, slot) of D, on top of e
+            dxn = ops.csr_gather_sum_add(D.view(-1, H), ti["t_rowptr"], ti["t_col_s1"], e, e)
+            AGG[l] = None
+        return (dxn, None, None, None, None) + tuple(grads)
+
+
 class SmallKLinear(torch.autograd.Function):
     """pre_mp: out = feat @ wt + bias with tiny K (gnn_model.py:131); feat carries no gradient."""
 

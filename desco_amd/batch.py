@@ -53,9 +53,14 @@ class _TrainIndexMixin:
             n_seg_rows = num_count if self.slots == 4 else self.num_rows
             seg_id = ops.segment_ids(seg_ptr, n_seg_rows)
             dev = self.vrowptr.device
+            S = self.slots
             self._train_index = {
                 "t_rowptr": t_rowptr, "t_col": t_col, "seg_id": seg_id,
                 "ident_ptr": torch.arange(n_seg_rows + 1, device=dev, dtype=torch.int32),
+                # the same transposed index for gradient rows laid out [row][S + 1 blocks of 64] (S relation
+                # slots + the self block, one GEMM output of the fused training trunk): virtual row
+                # k S + s -> k (S + 1) + s
+                "t_col_s1": (t_col + torch.div(t_col, S, rounding_mode="floor")).to(torch.int32),
             }
         return self._train_index
 

@@ -43,12 +43,14 @@ __device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f
 // continue W sources at a time.  vcol must be readable at index 0 even when there is no edge.
 __device__ __attribute__((aligned(16))) float gather_zero_row[64];
 
-template <int S>
+// ADD (S = 1 only): out[row] = extra[row] + sum (out rows ldo apart; extra may alias out row for row)
+template <int S, bool ADD = false>
 __global__ __launch_bounds__(256) void csr_gather_sum_v2_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const int32_t* __restrict__ vrowptr,
                                                                 const int32_t* __restrict__ vcol,
                                                                 int64_t num_rows,
-                                                                float* __restrict__ out) {
+                                                                float* out, const float* extra = nullptr,
+                                                                int64_t ld_extra = 0, int64_t ldo = 64) {
   constexpr int W = 8 / S;
   const int lane = threadIdx.x & 63, l16 = lane & 15;
   const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
@@ -108,10 +110,36 @@ __global__ __launch_bounds__(256) void csr_gather_sum_v2_kernel(const float* __r
     }
   }
   if (live) {
+    if constexpr (ADD) {
+      const float4 b = *reinterpret_cast<const float4*>(extra + row * ld_extra + 4 * l16);
+      acc[0].x += b.x;
+      acc[0].y += b.y;
+      acc[0].z += b.z;
+      acc[0].w += b.w;
+      *reinterpret_cast<float4*>(out + row * ldo + 4 * l16) = acc[0];
+    } else {
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-      *reinterpret_cast<float4*>(out + (row * S + s) * 64 + 4 * l16) = acc[s];
+      for (int s = 0; s < S; ++s)
+        *reinterpret_cast<float4*>(out + (row * S + s) * 64 + 4 * l16) = acc[s];
+    }
   }
+}
+
+// dst[i, 0:64 j] += src[i, 0:64 j]   (row strides ldd / lds; 16 lanes x float4 per 64 columns)
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int64_t ldd,
+                                                       const float* __restrict__ src, int64_t lds,
+                                                       int64_t num_rows, int chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = i / chunks;
+  if (row >= num_rows) return;
+  const int c = (int)(i % chunks) * 4;
+  float4 a = *reinterpret_cast<const float4*>(dst + row * ldd + c);
+  const float4 b = *reinterpret_cast<const float4*>(src + row * lds + c);
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+  *reinterpret_cast<float4*>(dst + row * ldd + c) = a;
 }
 
 // global_add_pool over contiguous segments (+ one extra row per segment, added last to mirror the
@@ -513,6 +541,36 @@ extern "C" int desco_csr_gather_sum_f32(const float* x, int64_t ldx, const int32
     hipLaunchKernelGGL(csr_gather_sum_v2_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx,
                        vrowptr, vcol, num_rows, out);
   return launch_status("desco_csr_gather_sum_f32");
+}
+
+extern "C" int desco_csr_gather_sum_add_f32(const float* x, int64_t ldx, const int32_t* rowptr,
+                                            const int32_t* col, int64_t num_rows, const float* extra,
+                                            int64_t ld_extra, float* out, int64_t ldo,
+                                            desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (!x || !rowptr || !col || !extra || !out || num_rows < 0 || ldx % 4 || ld_extra % 4 || ldo % 4 ||
+      !al16(x) || !al16(extra) || !al16(out))
+    return fail(DESCO_EINVAL, "desco_csr_gather_sum_add_f32: bad argument");
+  const int64_t blocks = (num_rows + 15) / 16;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_csr_gather_sum_add_f32: too many rows");
+  hipLaunchKernelGGL((csr_gather_sum_v2_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, rowptr, col, num_rows, out, extra, ld_extra, ldo);
+  return launch_status("desco_csr_gather_sum_add_f32");
+}
+
+extern "C" int desco_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t num_rows,
+                                  int ncols, desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (!dst || !src || num_rows < 0 || ncols <= 0 || ncols % 4 || ldd % 4 || lds % 4 || !al16(dst) || !al16(src))
+    return fail(DESCO_EINVAL, "desco_add_rows_f32: bad argument");
+  const int chunks = ncols / 4;
+  const int64_t blocks = (num_rows * chunks + 255) / 256;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_add_rows_f32: too many rows");
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, ldd,
+                     src, lds, num_rows, chunks);
+  return launch_status("desco_add_rows_f32");
 }
 
 extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,

@@ -47,6 +47,10 @@ FUSED_POOLING = True
 # set-up).
 RESIDENT_SHMP = False
 RESIDENT_MIN_ROWS = 48
+# Training: the SHMP layer loop + anchor + pooling as ONE autograd node whose forward and backward are C-ABI
+# launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
+# --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
+FUSED_TRAIN_TRUNK = True
 _RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
@@ -610,6 +614,16 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     if feat is None:
         feat = torch.zeros((N, core.input_dim), device=dev)
     x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *pk["pre"][t]) for t, r0, r1, _ in groups], 0)
+    if FUSED_TRAIN_TRUNK and not drop:
+        # the whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk)
+        has_anchor = isinstance(batch, NeighborhoodBatch)
+        flat = list(pk["anchor"]) if has_anchor else []
+        for l in range(core.layer_num):
+            for t, *_ in groups:
+                e = pk["layers"][l][t]
+                flat += [e["wt"], e["b"]]
+        pooled = AG.ShmpTrunk.apply(x, batch, groups, core.layer_num, has_anchor, *flat)
+        return _post_mp_train(AG, pk, gnn, pooled, drop)
     X = [x]
     for l in range(core.layer_num):
         agg = AG.GatherSum.apply(X[-1], batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col"], N, S)
@@ -632,6 +646,11 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     else:
         pooled = torch.cat([AG.SegmentSum.apply(xl, seg_ptr, ti["seg_id"], ti["ident_ptr"], None)
                             for xl in X], dim=1)
+    return _post_mp_train(AG, pk, gnn, pooled, drop)
+
+
+def _post_mp_train(AG, pk, gnn, pooled, drop):
+    import torch.nn.functional as F
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
     if drop:                                                               # post_mp.1 (gnn_model.py:46)
         h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_NONE, 0.0)

@@ -138,6 +138,34 @@ def csr_gather_sum(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, n
     return out
 
 
+def csr_gather_sum_add(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, extra: torch.Tensor,
+                       out: torch.Tensor) -> torch.Tensor:
+    """out[j] = extra[j] + sum over row j of x[col[e]]  ([rows, 64]; extra may be out): the transposed gather
+    of the training backward accumulating onto an existing gradient."""
+    n = out.shape[0]
+    xp, ldx = _rows(x, "x")
+    ep, lde = _rows(extra, "extra")
+    op, ldo = _rows(out, "out")
+    assert x.shape[1] == 64 and out.shape[1] == 64 and extra.shape == out.shape
+    with _Timed("csr_gather_sum_kernel", float(col.numel()) * 64, 256.0 * (x.shape[0] + 2 * n) + 4.0 * (col.numel() + n)):
+        if col.numel() == 0:
+            col = torch.zeros(1, device=x.device, dtype=torch.int32)
+        _lib.check(_lib.lib().desco_csr_gather_sum_add_f32(xp, ldx, _dev(rowptr, "rowptr", torch.int32),
+                                                          _dev(col, "col", torch.int32), n, ep, lde, op, ldo,
+                                                          _stream()), "csr_gather_sum_add")
+    return out
+
+
+def add_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst += src for 2-D fp32 views with unit inner stride (row strides free)."""
+    assert dst.shape == src.shape and dst.shape[1] % 4 == 0
+    dp, ldd = _rows(dst, "dst")
+    sp, lds = _rows(src, "src")
+    with _Timed("add_rows_kernel", float(dst.numel()), 12.0 * dst.numel()):
+        _lib.check(_lib.lib().desco_add_rows_f32(dp, ldd, sp, lds, dst.shape[0], dst.shape[1], _stream()), "add_rows")
+    return dst
+
+
 def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None,
          a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
          s: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,

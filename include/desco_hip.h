@@ -391,6 +391,19 @@ int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, const float* w,
  * transposed index).  All reductions are deterministic (workspace partials, fixed order).
  * ------------------------------------------------------------------------------------------ */
 
+/* Building blocks of the fused training trunk (desco_amd/autograd.py::ShmpTrunk: the whole
+ * BaseGNNCore.forward SAGE loop + anchor + pooling as ONE autograd node, its backward running the chain rule
+ * on preallocated buffers -- lightning_model.py:228-254 via loss.backward()):
+ *  desco_csr_gather_sum_add_f32: out[j, 0:64] = extra[j, 0:64] + sum_{e in [rowptr[j], rowptr[j+1])} x[col[e], 0:64]
+ *    (one slot; out rows ldo apart, extra rows ld_extra apart, extra may be out): the transposed gather of the
+ *    backward pass accumulating onto the gradient a row already has from its other consumers;
+ *  desco_add_rows_f32: dst[i, 0:ncols] += src[i, 0:ncols]  (ncols % 4 == 0, 16-byte aligned rows). */
+int desco_csr_gather_sum_add_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                                 int64_t num_rows, const float* extra, int64_t ld_extra, float* out,
+                                 int64_t ldo, desco_stream_t stream);
+int desco_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t num_rows, int ncols,
+                       desco_stream_t stream);
+
 /* bytes of workspace desco_gemm_tn_f32 needs for this shape (and the number of M slabs it uses) */
 size_t desco_gemm_tn_workspace(int64_t m, int k, int n, int* splits_out);
 
