@@ -67,6 +67,7 @@ SIGNATURES = {
     "desco_segment_ids": (c_int, [vp, i64, vp, vp]),
     "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp]),
     "desco_csr_gather_sum_add_f32": (c_int, [vp, i64, vp, vp, i64, vp, i64, vp, i64, vp]),
+    "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]),
     "desco_add_rows_f32": (c_int, [vp, i64, vp, i64, i64, i32, vp]),
     "desco_gemm_tn_workspace": (ctypes.c_size_t, [i64, i32, i32, POINTER(c_int)]),
     "desco_gemm_tn_f32": (c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, vp]),

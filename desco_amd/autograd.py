@@ -114,26 +114,26 @@ def _mm_bwd_da(dz, wt, out=None):
 class ShmpTrunk(torch.autograd.Function):
     """BaseGNNCore.forward's SAGE loop (gnn_model.py:253-277) + anchor_mlp on the canonical rows (:69-73) +
     global_add_pool per layer block (:88-89, 107) as ONE autograd node: pooled [B, 64 (L+1)] from x0 [N, 64]
-    and the folded per-layer weights.  Forward and backward are C-ABI launches on buffers this node owns --
-    no torch.cat / slice / accumulate kernels between them (the per-op autograd wiring of round 2 spent as
-    much GPU time in ~900 torch glue launches per step as in the 216 kernels that do the work).
+    and the folded weights STACKED over the layers.  Forward and backward are C-ABI launches on buffers this
+    node owns -- no torch.cat / slice / accumulate kernels between them (the per-op autograd wiring of round 2
+    spent as much GPU time in ~900 torch glue launches per step as in the 216 kernels that do the work).
 
-    args: x0, batch (NeighborhoodBatch / QueryBatch), groups [(type, r0, r1, su)], num_layers, has_anchor,
-          then tensors: [anchor wt (K-major [P, P]), anchor bias] if has_anchor, then per layer and group
-          (wt [(su+1) 64, 64], bias [64]).
+    args: x0, batch (NeighborhoodBatch / QueryBatch), groups [(type, r0, r1, su)], has_anchor, then tensors:
+          [anchor wt (K-major [P, P]), anchor bias] if has_anchor, then per group Wt [L, (su+1) 64, 64] and
+          bias [L, 64] (gnn_model.pack_shmp_stacked).
     Gradient of a row of X_l = pooling broadcast + (canonical rows) its column block of d(anchor operand) +
     self block + transposed gather of the aggregate blocks of layer l: assembled in one buffer per layer."""
 
     @staticmethod
-    def forward(ctx, x0, batch, groups, num_layers, has_anchor, *w):
-        ti = batch.train_index()
+    def forward(ctx, x0, batch, groups, has_anchor, *w):
         N, S = batch.num_rows, batch.slots
         dev = x0.device
         H = 64
         k = 2 if has_anchor else 0
         aw, ab = (w[0], w[1]) if has_anchor else (None, None)
-        lw = [[(w[k + 2 * (l * len(groups) + g)], w[k + 2 * (l * len(groups) + g) + 1])
-               for g in range(len(groups))] for l in range(num_layers)]
+        Wt = [w[k + 2 * g].contiguous() for g in range(len(groups))]
+        Bs = [w[k + 2 * g + 1].contiguous() for g in range(len(groups))]
+        num_layers = Wt[0].shape[0]
         Nc = groups[0][2] if has_anchor else N
         seg_ptr = batch.count_ptr if has_anchor else batch.graph_ptr
         B = batch.num_graphs
@@ -142,9 +142,9 @@ class ShmpTrunk(torch.autograd.Function):
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
             xn = torch.empty((N, H), device=dev)
-            for (t, r0, r1, su), (wt, b) in zip(groups, lw[l]):
+            for g, (t, r0, r1, su) in enumerate(groups):
                 if r1 > r0:
-                    _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], wt.contiguous(), b, ops.ACT_RELU, 0.0, out=xn[r0:r1])
+                    _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], Wt[g][l], Bs[g][l], ops.ACT_RELU, 0.0, out=xn[r0:r1])
             AGG.append(agg)
             X.append(xn)
         pooled = torch.empty((B, P), device=dev)
@@ -157,7 +157,7 @@ class ShmpTrunk(torch.autograd.Function):
         for l, xl in enumerate(X):
             ops.segment_sum(xl[:Nc], seg_ptr, B, extra=None if anch is None else anch[:, l * H:(l + 1) * H],
                             out=pooled[:, l * H:(l + 1) * H])
-        ctx.batch, ctx.groups, ctx.num_layers, ctx.has_anchor = batch, groups, num_layers, has_anchor
+        ctx.batch, ctx.groups, ctx.has_anchor = batch, groups, has_anchor
         ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
         ctx.save_for_backward(*w)
         return pooled
@@ -165,16 +165,21 @@ class ShmpTrunk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled):
         w = ctx.saved_tensors
-        batch, groups, L, has_anchor = ctx.batch, ctx.groups, ctx.num_layers, ctx.has_anchor
+        batch, groups, has_anchor = ctx.batch, ctx.groups, ctx.has_anchor
         X, AGG = ctx.X, ctx.AGG
         ti = batch.train_index()
         N, S = batch.num_rows, batch.slots
         H = 64
         dev = dpooled.device
         k = 2 if has_anchor else 0
+        Wt = [w[k + 2 * g].contiguous() for g in range(len(groups))]
+        L = Wt[0].shape[0]
         Nc = groups[0][2] if has_anchor else N
         dpooled = dpooled.contiguous()
         grads = [None] * len(w)
+        for g in range(len(groups)):        # stacked gradients, filled layer by layer
+            grads[k + 2 * g] = torch.empty_like(Wt[g])
+            grads[k + 2 * g + 1] = torch.empty((L, H), device=dev)
         dcanon = None
         if has_anchor:
             aw, canon, anch = w[0], ctx.canon, ctx.anch
@@ -182,32 +187,38 @@ class ShmpTrunk(torch.autograd.Function):
             grads[0], grads[1] = ops.linear_bwd_w(canon, None, dza, True)
             dcanon = _mm_bwd_da(dza, aw.contiguous())                             # [B, P]
 
-        def seed(l):
-            """gradient of X_l from the pooling (count rows) and from the anchor operand (canonical rows)"""
-            e = torch.empty((N, H), device=dev)
-            ops.csr_gather_sum(dpooled[:, l * H:(l + 1) * H], ti["ident_ptr"], ti["seg_id"], Nc, 1, out=e[:Nc])
-            if has_anchor:
-                e[Nc:] = dcanon[:, l * H:(l + 1) * H]
-            return e
+        su_of = [su for _, _, _, su in groups]
+        off_count = su_of[0] * H                       # column of the self block in a row of D, per row type
+        off_canon = su_of[1] * H if has_anchor else 0
 
-        dxn = seed(L)
+        def dx(l, d_rows, mask):
+            """gradient w.r.t. the rows of X_l: seed (pooling broadcast; canonical rows: anchor operand) + self
+            block + transposed gather of the slot blocks of d_rows, times relu'(X_l) (one launch)"""
+            return ops.shmp_bwd_dx(d_rows, ti["t_rowptr"], ti["t_col_s1"], Nc, off_count, off_canon,
+                                   dpooled[:, l * H:(l + 1) * H], ti["seg_id"],
+                                   None if dcanon is None else dcanon[:, l * H:(l + 1) * H], mask)
+
+        # dZ of the last layer: its rows feed only the pooling / the anchor operand (one zero row stands in for D:
+        # row stride 0, no transposed edges)
+        zero_d = torch.zeros((1, (S + 1) * H), device=dev).expand(N, -1)
+        empty_ptr = torch.zeros(N + 1, device=dev, dtype=torch.int32)
+        dz = ops.shmp_bwd_dx(zero_d, empty_ptr, ti["t_col_s1"], Nc, off_count, off_canon,
+                             dpooled[:, L * H:(L + 1) * H], ti["seg_id"],
+                             None if dcanon is None else dcanon[:, L * H:(L + 1) * H], X[L])
         D = torch.empty((N, (S + 1) * H), device=dev)
         for l in range(L - 1, -1, -1):
-            dz = ops.act_grad(dxn, X[l + 1], ops.ACT_RELU, 0.0)
-            e = seed(l)
             for g, (t, r0, r1, su) in enumerate(groups):
                 if r1 <= r0:
+                    grads[k + 2 * g][l].zero_()
+                    grads[k + 2 * g + 1][l].zero_()
                     continue
-                wi = k + 2 * (l * len(groups) + g)
-                wt = w[wi].contiguous()
-                dwt, db = ops.linear_bwd_w(AGG[l][r0:r1, :su * H], X[l][r0:r1], dz[r0:r1], True)
-                grads[wi], grads[wi + 1] = dwt, db
-                _mm_bwd_da(dz[r0:r1], wt, out=D[r0:r1, :(su + 1) * H])
-                ops.add_rows(e[r0:r1], D[r0:r1, su * H:(su + 1) * H])              # self block
-            # aggregate blocks: transposed gather over the virtual rows (row, slot) of D, on top of e
-            dxn = ops.csr_gather_sum_add(D.view(-1, H), ti["t_rowptr"], ti["t_col_s1"], e, e)
+                ops.linear_bwd_w(AGG[l][r0:r1, :su * H], X[l][r0:r1], dz[r0:r1], True,
+                                 dwt=grads[k + 2 * g][l], dbias=grads[k + 2 * g + 1][l])
+                _mm_bwd_da(dz[r0:r1], Wt[g][l], out=D[r0:r1, :(su + 1) * H])
+            dz = dx(l, D, X[l] if l > 0 else None)        # (l == 0: the gradient of x0 itself)
             AGG[l] = None
-        return (dxn, None, None, None, None) + tuple(grads)
+        dxn = dz
+        return (dxn, None, None, None) + tuple(grads)
 
 
 class SmallKLinear(torch.autograd.Function):

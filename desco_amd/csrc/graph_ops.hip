@@ -125,6 +125,74 @@ __global__ __launch_bounds__(256) void csr_gather_sum_v2_kernel(const float* __r
   }
 }
 
+// Backward of one SHMP layer w.r.t. its input rows (training trunk): for row i of X_l
+//   out[i] = mask_i * ( seed_i + D[i, self block] + sum_{v in T(i)} Dv[v] )
+// seed_i = dpool[seg_id[i]] for count rows (broadcast of the pooled gradient), dcanon[i - Nc] for canonical rows;
+// D = dZ Wt^T [N, (S+1) 64] (slot blocks + self block; the self block sits at column self_off of the row's type);
+// Dv = D viewed as virtual rows of 64; T(i) = the virtual rows that gathered row i (transposed index);
+// mask = relu'(X_l[i]) (NULL for the input layer, whose rows come out of a Linear).  16 lanes x float4 per row,
+// eight virtual rows in flight per lane group.
+__global__ __launch_bounds__(256) void shmp_bwd_dx_kernel(const float* __restrict__ D, int64_t ldd,
+                                                          const int32_t* __restrict__ t_rowptr,
+                                                          const int32_t* __restrict__ t_col, int64_t num_rows,
+                                                          int64_t num_count, int off_count, int off_canon,
+                                                          const float* __restrict__ dpool, int64_t ld_pool,
+                                                          const int32_t* __restrict__ seg_id,
+                                                          const float* __restrict__ dcanon, int64_t ld_canon,
+                                                          const float* __restrict__ relu_src,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
+  const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool live = row_raw < num_rows;
+  const int64_t row = live ? row_raw : num_rows - 1;
+  const float* dv = D + 4 * l16;
+  const float* zr = gather_zero_row + 4 * l16;
+  int e = t_rowptr[row];
+  const int n = t_rowptr[row + 1];
+  const bool is_count = row < num_count;
+  float4 acc;
+  if (is_count)
+    acc = *reinterpret_cast<const float4*>(dpool + (int64_t)seg_id[row] * ld_pool + 4 * l16);
+  else if (dcanon)
+    acc = *reinterpret_cast<const float4*>(dcanon + (row - num_count) * ld_canon + 4 * l16);
+  else
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float4 sb = *reinterpret_cast<const float4*>(D + row * ldd + (is_count ? off_count : off_canon) + 4 * l16);
+    acc.x += sb.x;
+    acc.y += sb.y;
+    acc.z += sb.z;
+    acc.w += sb.w;
+  }
+  while (__any(e < n)) {
+    float4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = e + k < n;
+      const int j = t_col[ok ? e + k : (n > 0 ? n - 1 : 0)];
+      t[k] = *reinterpret_cast<const float4*>(ok ? dv + (int64_t)j * 64 : zr);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc.x += t[k].x;
+      acc.y += t[k].y;
+      acc.z += t[k].z;
+      acc.w += t[k].w;
+    }
+    e += 8;
+  }
+  if (live) {
+    if (relu_src) {
+      const float4 c = *reinterpret_cast<const float4*>(relu_src + row * 64 + 4 * l16);
+      acc.x = c.x > 0.f ? acc.x : 0.f;
+      acc.y = c.y > 0.f ? acc.y : 0.f;
+      acc.z = c.z > 0.f ? acc.z : 0.f;
+      acc.w = c.w > 0.f ? acc.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + row * 64 + 4 * l16) = acc;
+  }
+}
+
 // dst[i, 0:64 j] += src[i, 0:64 j]   (row strides ldd / lds; 16 lanes x float4 per 64 columns)
 __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int64_t ldd,
                                                        const float* __restrict__ src, int64_t lds,
@@ -557,6 +625,26 @@ extern "C" int desco_csr_gather_sum_add_f32(const float* x, int64_t ldx, const i
   hipLaunchKernelGGL((csr_gather_sum_v2_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, rowptr, col, num_rows, out, extra, ld_extra, ldo);
   return launch_status("desco_csr_gather_sum_add_f32");
+}
+
+extern "C" int desco_shmp_bwd_dx_f32(const float* d, int64_t ldd, const int32_t* t_rowptr, const int32_t* t_col,
+                                     int64_t num_rows, int64_t num_count, int self_off_count,
+                                     int self_off_canon, const float* dpool, int64_t ld_pool,
+                                     const int32_t* seg_id, const float* dcanon, int64_t ld_canon,
+                                     const float* relu_src, float* out, desco_stream_t stream) {
+  if (num_rows == 0) return 0;
+  auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (!d || !t_rowptr || !t_col || !dpool || !seg_id || !out || num_rows < 0 || num_count < 0 ||
+      num_count > num_rows || ldd % 4 || ld_pool % 4 ||
+      (dcanon && ld_canon % 4) || self_off_count % 4 || self_off_canon % 4 || !al16(d) || !al16(dpool) ||
+      !al16(out) || (dcanon && !al16(dcanon)) || (relu_src && !al16(relu_src)))
+    return fail(DESCO_EINVAL, "desco_shmp_bwd_dx_f32: bad argument");
+  const int64_t blocks = (num_rows + 15) / 16;
+  if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_shmp_bwd_dx_f32: too many rows");
+  hipLaunchKernelGGL(shmp_bwd_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d, ldd,
+                     t_rowptr, t_col, num_rows, num_count, self_off_count, self_off_canon, dpool, ld_pool,
+                     seg_id, dcanon, ld_canon, relu_src, out);
+  return launch_status("desco_shmp_bwd_dx_f32");
 }
 
 extern "C" int desco_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t num_rows,

@@ -589,15 +589,37 @@ def _shmp_pooled(gnn: BaseGNN, batch, allow_resident: bool = True) -> torch.Tens
     return pooled
 
 
+def pack_shmp_stacked(gnn: BaseGNN) -> dict:
+    """The folding of pack_shmp -- (U_n W_s)^T per slot, U_x^T, U_n sum_s b_s + c -- for the fused
+    training trunk, differentiable and STACKED over the layers: per node type (Wt [L, (S_t+1) 64, 64],
+    bias [L, 64]) from a dozen batched torch ops.  (pack_shmp's per-(layer, type) entries cost ~100 small
+    differentiable select / cat / add ops per step, and their backward as many zero-fills, copies and full-size
+    accumulations: half of the replayed step's GPU time in round 2.)"""
+    core = gnn.gnn_core
+    L = core.layer_num
+    out = {}
+    for t in core.node_types:
+        keys = core.slot_keys(t)
+        uniq = list(dict.fromkeys(keys))                 # one bias per edge TYPE (use_tconv=False ties two slots)
+        U = torch.stack([core.updates[l][t].weight for l in range(L)])                   # [L, 64, 128]
+        c = torch.stack([core.updates[l][t].bias for l in range(L)])                     # [L, 64]
+        Un, Ux = U[:, :, :H], U[:, :, H:]
+        W = torch.stack([core.convs[l][k].lin.weight for l in range(L) for k in keys]).view(L, len(keys), H, H)
+        bs = torch.stack([core.convs[l][k].lin.bias for l in range(L) for k in uniq]).view(L, len(uniq), H).sum(1)
+        folded = torch.matmul(Un.unsqueeze(1), W).transpose(-1, -2)                       # (U_n W_s)^T
+        Wt = torch.cat([folded, Ux.transpose(-1, -2).unsqueeze(1)], dim=1).reshape(L, (len(keys) + 1) * H, H)
+        fb = torch.matmul(Un, bs.unsqueeze(-1)).squeeze(-1) + c
+        out[t] = (Wt, fb)
+    return out
+
+
 def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     """Differentiable twin of ``shmp_forward`` (same math, un-fused kernels, autograd Functions from
     desco_amd.autograd; every forward and backward op is a C-ABI kernel launch)."""
     from . import autograd as AG
-    pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
     core = gnn.gnn_core
     dev = batch.vrowptr.device
     N, S = batch.num_rows, batch.slots
-    ti = batch.train_index()
     import torch.nn.functional as F
     # --neigh_dropout > 0 (default 0.0, config.py:251): F.dropout after every layer's relu and the
     # nn.Dropout of post_mp.1, as the reference applies them in training mode
@@ -613,17 +635,21 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     feat = batch.node_feature
     if feat is None:
         feat = torch.zeros((N, core.input_dim), device=dev)
-    x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *pk["pre"][t]) for t, r0, r1, _ in groups], 0)
-    if FUSED_TRAIN_TRUNK and not drop:
-        # the whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk)
+    if FUSED_TRAIN_TRUNK and not drop and all(len(core.slot_keys(t)) == su for t, _, _, su in groups):
+        # the whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk) on weights folded
+        # in stacked form
+        x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *_lin_t(core.pre_mp[0][t])) for t, r0, r1, _ in groups], 0)
         has_anchor = isinstance(batch, NeighborhoodBatch)
-        flat = list(pk["anchor"]) if has_anchor else []
-        for l in range(core.layer_num):
-            for t, *_ in groups:
-                e = pk["layers"][l][t]
-                flat += [e["wt"], e["b"]]
-        pooled = AG.ShmpTrunk.apply(x, batch, groups, core.layer_num, has_anchor, *flat)
-        return _post_mp_train(AG, pk, gnn, pooled, drop)
+        st = pack_shmp_stacked(gnn)
+        flat = list(_lin_t(gnn.anchor_mlp[0])) if has_anchor else []
+        for t, *_ in groups:
+            flat += list(st[t])
+        pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, *flat)
+        post = {"post": [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]}
+        return _post_mp_train(AG, post, gnn, pooled, drop)
+    pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
+    ti = batch.train_index()
+    x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *pk["pre"][t]) for t, r0, r1, _ in groups], 0)
     X = [x]
     for l in range(core.layer_num):
         agg = AG.GatherSum.apply(X[-1], batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col"], N, S)

@@ -156,6 +156,28 @@ def csr_gather_sum_add(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor,
     return out
 
 
+def shmp_bwd_dx(d: torch.Tensor, t_rowptr: torch.Tensor, t_col: torch.Tensor, num_count: int, off_count: int,
+                off_canon: int, dpool: torch.Tensor, seg_id: torch.Tensor, dcanon: Optional[torch.Tensor],
+                relu_src: Optional[torch.Tensor]) -> torch.Tensor:
+    """Input-row gradient of one SHMP layer of the training trunk (desco_shmp_bwd_dx_f32): seed (pooling
+    broadcast / anchor operand) + self block + transposed gather of the slot blocks, masked by relu'."""
+    n = d.shape[0]
+    out = torch.empty((n, 64), device=d.device, dtype=torch.float32)
+    dp, ldd = _rows(d, "d")
+    pp, ldp = _rows(dpool, "dpool")
+    cp_, ldc = (None, 0) if dcanon is None else _rows(dcanon, "dcanon")
+    rs = None if relu_src is None else _dev(relu_src, "relu_src")
+    assert relu_src is None or (relu_src.is_contiguous() and tuple(relu_src.shape) == (n, 64))
+    with _Timed("shmp_bwd_dx_kernel", float(t_col.numel()) * 64, 256.0 * (3 * n) + 4.0 * (t_col.numel() + 2 * n) +
+                256.0 * t_col.numel() / 4):
+        tc = t_col if t_col.numel() else torch.zeros(1, device=d.device, dtype=torch.int32)
+        _lib.check(_lib.lib().desco_shmp_bwd_dx_f32(dp, ldd, _dev(t_rowptr, "t_rowptr", torch.int32),
+                                                   _dev(tc, "t_col", torch.int32), n, int(num_count), int(off_count),
+                                                   int(off_canon), pp, ldp, _dev(seg_id, "seg_id", torch.int32),
+                                                   cp_, ldc, rs, _dev(out, "out"), _stream()), "shmp_bwd_dx")
+    return out
+
+
 def add_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """dst += src for 2-D fp32 views with unit inner stride (row strides free)."""
     assert dst.shape == src.shape and dst.shape[1] % 4 == 0
@@ -691,14 +713,21 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
-def linear_bwd_w(a1: torch.Tensor, a2: Optional[torch.Tensor], dz: torch.Tensor, want_bias: bool):
+def linear_bwd_w(a1: torch.Tensor, a2: Optional[torch.Tensor], dz: torch.Tensor, want_bias: bool,
+                 dwt: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None):
     """(dwt [(k1+k2), n], dbias [n] or None) of c = act([a1 | a2] @ wt + bias) given dz: weight and
-    bias gradient in two launches (desco_linear_bwd_w_f32)."""
+    bias gradient in two launches (desco_linear_bwd_w_f32); ``dwt`` / ``dbias``: contiguous outputs to fill."""
     m, k1 = a1.shape
     k2 = 0 if a2 is None else a2.shape[1]
     n = dz.shape[1]
-    dwt = torch.empty((k1 + k2, n), device=dz.device, dtype=torch.float32)
-    dbias = torch.empty((n,), device=dz.device, dtype=torch.float32) if want_bias else None
+    if dwt is None:
+        dwt = torch.empty((k1 + k2, n), device=dz.device, dtype=torch.float32)
+    assert dwt.is_contiguous() and tuple(dwt.shape) == (k1 + k2, n)
+    if want_bias and dbias is None:
+        dbias = torch.empty((n,), device=dz.device, dtype=torch.float32)
+    if not want_bias:
+        dbias = None
+    assert dbias is None or (dbias.is_contiguous() and dbias.numel() == n)
     a1p, lda1 = _rows(a1, "a1")
     a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
     zp, ldz = _rows(dz, "dz")

@@ -403,6 +403,18 @@ int desco_csr_gather_sum_add_f32(const float* x, int64_t ldx, const int32_t* row
                                  int64_t ldo, desco_stream_t stream);
 int desco_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t num_rows, int ncols,
                        desco_stream_t stream);
+/* The input-row gradient of one SHMP layer of the training trunk in one launch:
+ *   out[i, 0:64] = mask_i * ( seed_i + d[i, self_off .. +63] + sum_{v in [t_rowptr[i], t_rowptr[i+1])} dv[t_col[v]] )
+ * d = dZ Wt^T [num_rows, ldd] (relation-slot blocks, then the self block at column self_off_count for rows
+ * < num_count, self_off_canon for the others), dv = d viewed as rows of 64 floats (t_col indexes them: the
+ * transposed index over (row, slot) virtual rows with ldd / 64 blocks per row); seed_i = dpool[seg_id[i]] (the
+ * pooling's broadcast gradient, rows ld_pool apart) for i < num_count, dcanon[i - num_count] (NULL: 0) otherwise;
+ * mask = (relu_src[i] > 0) elementwise, or 1 when relu_src is NULL.  Replaces a seed build, two adds, the
+ * transposed gather and the activation gradient (five launches) of the per-op wiring. */
+int desco_shmp_bwd_dx_f32(const float* d, int64_t ldd, const int32_t* t_rowptr, const int32_t* t_col,
+                          int64_t num_rows, int64_t num_count, int self_off_count, int self_off_canon,
+                          const float* dpool, int64_t ld_pool, const int32_t* seg_id, const float* dcanon,
+                          int64_t ld_canon, const float* relu_src, float* out, desco_stream_t stream);
 
 /* bytes of workspace desco_gemm_tn_f32 needs for this shape (and the number of M slabs it uses) */
 size_t desco_gemm_tn_workspace(int64_t m, int k, int n, int* splits_out);
