@@ -53,6 +53,7 @@ SIGNATURES = {
                                       vp, i64, i64, vp]),
     "desco_round_bf16_f32": (c_int, [vp, i64, vp, vp]),
     "desco_segment_sum_f32": (c_int, [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
+    "desco_segment_sum_layers_f32": (c_int, [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
     "desco_count_head_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, f32, i32, vp, i64, i64, i32, vp]),
     "desco_scatter_rows_f32": (c_int, [vp, i64, vp, i64, i32, vp, i64, vp]),
     "desco_gossip_layer0_f32": (c_int, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

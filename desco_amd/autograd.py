@@ -139,9 +139,10 @@ class ShmpTrunk(torch.autograd.Function):
         B = batch.num_graphs
         P = H * (num_layers + 1)
         X, AGG = [x0.contiguous()], []
+        xall = torch.empty((num_layers, N, H), device=dev)        # X_1 .. X_L in one buffer (pooled in one launch)
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
-            xn = torch.empty((N, H), device=dev)
+            xn = xall[l]
             for g, (t, r0, r1, su) in enumerate(groups):
                 if r1 > r0:
                     _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], Wt[g][l], Bs[g][l], ops.ACT_RELU, 0.0, out=xn[r0:r1])
@@ -154,9 +155,8 @@ class ShmpTrunk(torch.autograd.Function):
             for l, xl in enumerate(X):
                 canon[:, l * H:(l + 1) * H] = xl[Nc:]
             anch = _mm_fwd(canon, None, aw.contiguous(), ab, ops.ACT_LEAKY, 0.1)
-        for l, xl in enumerate(X):
-            ops.segment_sum(xl[:Nc], seg_ptr, B, extra=None if anch is None else anch[:, l * H:(l + 1) * H],
-                            out=pooled[:, l * H:(l + 1) * H])
+        ops.segment_sum(X[0][:Nc], seg_ptr, B, extra=None if anch is None else anch[:, :H], out=pooled[:, :H])
+        ops.segment_sum_layers(xall, Nc, seg_ptr, B, None if anch is None else anch[:, H:], pooled[:, H:])
         ctx.batch, ctx.groups, ctx.has_anchor = batch, groups, has_anchor
         ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
         ctx.save_for_backward(*w)

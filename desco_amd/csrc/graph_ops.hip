@@ -255,7 +255,12 @@ __global__ __launch_bounds__(256) void segment_sum64_kernel(const float* __restr
                                                             int64_t num_seg,
                                                             const float* __restrict__ extra,
                                                             int64_t ld_extra, float* __restrict__ out,
-                                                            int64_t ldo) {
+                                                            int64_t ldo, int64_t layer_stride = 0) {
+  // blockIdx.y = layer (desco_segment_sum_layers_f32): x advances by layer_stride floats, extra and out by one
+  // 64-column block per layer
+  x += (int64_t)blockIdx.y * layer_stride;
+  out += (int64_t)blockIdx.y * 64;
+  if (extra) extra += (int64_t)blockIdx.y * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * 4 + (lane >> 4);
   const bool live = b < num_seg;
@@ -683,6 +688,21 @@ extern "C" int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols,
   hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      x, ldx, ncols, nch, seg_ptr, num_seg, extra, ld_extra, out, ldo);
   return launch_status("desco_segment_sum_f32");
+}
+
+extern "C" int desco_segment_sum_layers_f32(const float* x, int64_t ldx, int64_t layer_stride, int num_layers,
+                                           const int32_t* seg_ptr, int64_t num_seg, const float* extra,
+                                           int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream) {
+  if (num_seg == 0 || num_layers == 0) return 0;
+  auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
+  if (!x || !seg_ptr || !out || num_seg < 0 || num_layers < 0 || num_layers > 65535 || ldx % 4 || ldo % 4 ||
+      layer_stride % 4 || !al16(x) || !al16(out) || (extra && (ld_extra % 4 || !al16(extra))))
+    return fail(DESCO_EINVAL, "desco_segment_sum_layers_f32: bad argument");
+  const int64_t blocks64 = (num_seg + 15) / 16;
+  if (!grid_ok(blocks64)) return fail(DESCO_EINVAL, "desco_segment_sum_layers_f32: too many segments");
+  hipLaunchKernelGGL(segment_sum64_kernel, dim3((unsigned)blocks64, (unsigned)num_layers), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, seg_ptr, num_seg, extra, ld_extra, out, ldo, layer_stride);
+  return launch_status("desco_segment_sum_layers_f32");
 }
 
 extern "C" int desco_pool_reduce_f32(const float* part, const uint32_t* pool_bits,

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(const float* __res
 __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
     const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias) {
+  // direct_dwt != NULL (one slab): the block's tile IS the result -- written to dwt / dbias, no reduce launch
   __shared__ float lds[2 * TMC * 64];
   float* As = lds;              // [32 m][64 k]
   float* Bs = lds + TMC * 64;   // [32 m][64 n]
@@ -99,7 +100,11 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
-      partial[((int64_t)blockIdx.z * rows + K) * N + n0 + tid] = t;
+      if (direct_dwt) {
+        if (direct_dbias) direct_dbias[n0 + tid] = t;
+      } else {
+        partial[((int64_t)blockIdx.z * rows + K) * N + n0 + tid] = t;
+      }
     }
     return;
   }
@@ -130,12 +135,13 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     for (int mm = 0; mm < TMC / 2; ++mm)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * mm * 64], bs[2 * mm * 64], acc, 0, 0, 0);
   }
-  float* out = partial + ((int64_t)blockIdx.z * rows + k0) * N + n0;
+  float* out = direct_dwt ? direct_dwt + (int64_t)k0 * lddw + n0 : partial + ((int64_t)blockIdx.z * rows + k0) * N + n0;
+  const int64_t ldout = direct_dwt ? lddw : N;
   const int col = wc * 32 + (lane & 31);
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    out[(int64_t)row * N + col] = acc[reg];
+    out[(int64_t)row * ldout + col] = acc[reg];
   }
 }
 
@@ -369,8 +375,14 @@ extern "C" int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, con
   slab = (slab + TMC - 1) / TMC * TMC;
   if (slab < TMC) slab = TMC;
   hipStream_t st = (hipStream_t)stream;
+  if (splits == 1) {      // small M (canonical rows, query graphs, post MLP): one launch, results in place
+    hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(k / TK + 1, n / TN, 1), dim3(256), 0, st, a1, lda1, k1,
+                       a2, lda2, dz, lddz, m, k, n, slab, workspace, dwt, lddw, dbias);
+    return launch_status("desco_linear_bwd_w_f32");
+  }
   hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(k / TK + 1, n / TN, splits), dim3(256), 0, st, a1,
-                     lda1, k1, a2, lda2, dz, lddz, m, k, n, slab, workspace);
+                     lda1, k1, a2, lda2, dz, lddz, m, k, n, slab, workspace, (float*)nullptr, (int64_t)0,
+                     (float*)nullptr);
   const int64_t count = (int64_t)(k + 1) * n;
   hipLaunchKernelGGL(linear_bwd_w_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                      workspace, k, n, splits, dwt, lddw, dbias);

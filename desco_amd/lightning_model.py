@@ -121,6 +121,10 @@ class _LightningLike(nn.Module):
         self._qemb_cache = None
 
 
+# training: run the query model's trunk on a second HIP stream beside the target batch's (train_forward)
+OVERLAP_QUERY_TRUNK = True
+
+
 class NeighborhoodCountingModel(_LightningLike):
     def __init__(self, input_dim, hidden_dim, args, **kwargs):
         super().__init__()
@@ -248,8 +252,23 @@ class NeighborhoodCountingModel(_LightningLike):
         batch = batch.to(self.device)
         if batch.y is None:
             raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
-        emb_q = self.emb_model_query(self._queries())
-        emb_t = self.emb_model(batch)
+        if OVERLAP_QUERY_TRUNK and self.device.type == "cuda":
+            # the query model's trunk is ~100 launches on 135 rows: forward (and, through autograd, backward) on a
+            # second stream, beside the target batch's launches instead of in front of them (also inside a hipGraph
+            # capture: the side stream forks from and joins the capturing stream)
+            cur = torch.cuda.current_stream(self.device)
+            side = self.__dict__.get("_query_stream")
+            if side is None or side.device != self.device:
+                side = self.__dict__["_query_stream"] = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                emb_q = self.emb_model_query(self._queries())
+            emb_t = self.emb_model(batch)
+            cur.wait_stream(side)
+            emb_q.record_stream(cur)
+        else:
+            emb_q = self.emb_model_query(self._queries())
+            emb_t = self.emb_model(batch)
         W1, b1 = self.count_model[0].weight, self.count_model[0].bias
         T = AG.Linear.apply(emb_t, None, W1[:, :H].t(), None, ops.ACT_NONE, 0.0)
         Qh = AG.Linear.apply(emb_q, None, W1[:, H:].t(), b1, ops.ACT_NONE, 0.0)

@@ -557,6 +557,21 @@ def segment_sum(x: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int,
     return out
 
 
+def segment_sum_layers(xall: torch.Tensor, num_rows: int, seg_ptr: torch.Tensor, num_seg: int,
+                       extra: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """out[b, 64 l : 64 l + 64] = sum over segment b of xall[l, r, :] (r < num_rows) + extra[b, 64 l : ...] for every
+    layer l of ``xall`` [Lx, N, 64] in one launch (``out`` / ``extra``: [num_seg, >= 64 Lx] views)."""
+    Lx, N, H = xall.shape
+    assert H == 64 and xall.is_contiguous() and num_rows <= N
+    op, ldo = _rows(out, "out")
+    ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
+    with _Timed("segment_sum_kernel", float(num_rows) * 64 * Lx, 4.0 * Lx * (num_rows * 64 + 2 * num_seg * 64)):
+        _lib.check(_lib.lib().desco_segment_sum_layers_f32(_dev(xall, "xall"), 64, N * 64, Lx,
+                                                          _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, ep, lde,
+                                                          op, ldo, _stream()), "segment_sum_layers")
+    return out
+
+
 def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2, slope: float,
                exp2_minus_1: bool) -> torch.Tensor:
     """[B,Q] logits (or 2**logit - 1) of the separable count head (lightning_model.py:176-221).

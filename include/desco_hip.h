@@ -322,6 +322,12 @@ int desco_segment_sum_f32(const float* x, int64_t ldx, int ncols, const int32_t*
                           int64_t num_seg, const float* extra, int64_t ld_extra, float* out,
                           int64_t ldo, desco_stream_t stream);
 
+/* The same for num_layers feature blocks in one launch (training trunk: X_1 .. X_L live in one buffer):
+ * out[b, 64 l .. 64 l + 63] = sum_{r in segment b} x[l * layer_stride + r * ldx + 0..63] + extra[b, 64 l ..] */
+int desco_segment_sum_layers_f32(const float* x, int64_t ldx, int64_t layer_stride, int num_layers,
+                                 const int32_t* seg_ptr, int64_t num_seg, const float* extra,
+                                 int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream);
+
 /* K12/K13  count head (lightning_model.py:176-193, 210-221) in separable form:
  * logit[b,q] = sum_c w2[c] * leaky(T[b,c] + Qh[q,c]) + b2;  out = exp2 ? 2^logit - 1 : logit
  * T: [B, hid] (target half of count_model.0), Qh: [Q, hid] (query half + bias);
