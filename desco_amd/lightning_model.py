@@ -252,7 +252,11 @@ class NeighborhoodCountingModel(_LightningLike):
         batch = batch.to(self.device)
         if batch.y is None:
             raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
-        if OVERLAP_QUERY_TRUNK and self.device.type == "cuda":
+        from . import distributed as D
+        # (single process only: under DDP the gradient buckets are all-reduced from autograd hooks, which would run
+        #  on the side stream for the query model's parameters while other gradients of the same bucket are still
+        #  being written on the main stream)
+        if OVERLAP_QUERY_TRUNK and self.device.type == "cuda" and D.world_size() == 1:
             # the query model's trunk is ~100 launches on 135 rows: forward (and, through autograd, backward) on a
             # second stream, beside the target batch's launches instead of in front of them (also inside a hipGraph
             # capture: the side stream forks from and joins the capturing stream)
