@@ -244,3 +244,70 @@ def test_pool_index_slots_are_consistent_between_kernel_and_reduce():
                     k = bin(int(bits[t]) & ((1 << first) - 1)).count("1")
                     tot += part[slot[t] + k]
                 assert abs(tot - vals[r0:r1].sum()) < 1e-9
+
+
+# ---- round 3: host pieces of the resident kernel's plan, partition select, stacked weight folding ----------
+def _golden_partition():
+    from desco_amd.graphs import GraphSet
+    from desco_amd.partition import build_partition
+    from helpers import golden_graphs
+    return build_partition(GraphSet.from_edge_lists(golden_graphs()), 4)
+
+
+def test_partition_select_equals_slice_and_keeps_neighborhoods_intact():
+    part = _golden_partition()
+    a, b = part.slice(10, 40), part.select(np.arange(10, 40))
+    for f in ("count_ptr", "vrowptr", "vcol", "count_orig"):
+        assert (getattr(a, f) == getattr(b, f)).all(), f
+    idx = np.array([0, 3, 7, 8, 100, 200, part.num_neigh - 1])
+    c = part.select(idx)
+    assert c.num_neigh == len(idx) and (c.neigh_index == part.neigh_index[idx]).all()
+    for i, bi in enumerate(idx):                       # every selected neighborhood is the same self-contained block
+        one, two = part.slice(int(bi), int(bi) + 1), c.slice(i, i + 1)
+        assert (one.vrowptr == two.vrowptr).all() and (one.vcol == two.vcol).all()
+
+
+def test_resident_plan_packs_every_eligible_neighborhood_once_within_the_limits():
+    from desco_amd import ops
+    part = _golden_partition()
+    rows_max, edges_max, nb_max = ops.resident_limits()
+    n = np.diff(part.count_ptr.astype(np.int64))
+    v = part.vrowptr.astype(np.int64)
+    cp = part.count_ptr.astype(np.int64)
+    kr = part.num_count + np.arange(part.num_neigh)
+    e = (v[4 * cp[1:]] - v[4 * cp[:-1]]) + (v[4 * kr + 4] - v[4 * kr])
+    for min_rows in (1, 12):
+        elig, plist = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count, min_rows)
+        assert (elig == ((n >= min_rows) & (n <= rows_max) & (e <= edges_max))).all()   # a per-neighborhood rule
+        used = plist[plist >= 0]
+        assert len(used) == len(np.unique(used)) == int(elig.sum()) and elig[used].all()
+        assert plist.shape[1] == nb_max
+        for row in plist:
+            m = row[row >= 0]
+            assert len(m) >= 1 and (row[:len(m)] >= 0).all()                  # slots are filled from the front
+            assert ((n[m] + 15) // 16).sum() * 16 <= rows_max and e[m].sum() <= edges_max
+    # the choice does not depend on what else is in the block
+    sub = part.select(np.arange(0, part.num_neigh, 2))
+    elig2, _ = ops.resident_plan(sub.count_ptr, sub.vrowptr, sub.num_count, 12)
+    elig1, _ = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count, 12)
+    assert (elig2 == elig1[::2]).all()
+
+
+@pytest.mark.parametrize("use_tconv", [True, False])
+def test_stacked_weight_folding_equals_the_per_layer_folding(use_tconv):
+    """gnn_model.pack_shmp_stacked (training trunk) == gnn_model.pack_shmp per (layer, type), on CPU tensors."""
+    import torch
+    import desco_amd.gnn_model as GM
+    from desco_amd.lightning_model import NeighborhoodCountingModel
+    from helpers import neigh_args
+    torch.manual_seed(3)
+    nm = NeighborhoodCountingModel(1, 64, neigh_args(use_tconv=use_tconv)).to_hetero_old(use_tconv, use_tconv)
+    for gnn in (nm.emb_model, nm.emb_model_query):
+        with torch.no_grad():
+            pk = GM.pack_shmp(gnn, bf16_planes=False)
+            st = GM.pack_shmp_stacked(gnn)
+        for t in gnn.gnn_core.node_types:
+            Wt, fb = st[t]
+            for l in range(gnn.gnn_core.layer_num):
+                torch.testing.assert_close(Wt[l], pk["layers"][l][t]["wt"], rtol=1e-6, atol=1e-6)
+                torch.testing.assert_close(fb[l], pk["layers"][l][t]["b"], rtol=1e-6, atol=1e-6)
