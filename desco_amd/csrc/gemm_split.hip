@@ -42,6 +42,15 @@ struct GemmSplitArgs {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
+#ifndef GS_ABL
+#define GS_ABL 0
+#endif
+#if GS_ABL == 1      // no split arithmetic (timing only)
+#define GS_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
+#else
+#define GS_SPLIT(a_, b_, h_, m_, l_) split2_bf16x3(a_, b_, h_, m_, l_)
+#endif
+
 constexpr int SBK = 32, SST = 32;              // SST: plane row stride in bf16 (64 B, no padding)
 // 16-byte chunk c (0..3) of plane row r sits at chunk c ^ ((r >> 3) & 3): conflict-free for the fragment
 // reads (ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}: their rows differ in r & 3 or in
@@ -55,7 +64,7 @@ __device__ __forceinline__ int gs_chunk(const int row, const int c) { return ((c
 // in flight too: one chunk of MFMAs (2 304 cycles) does not cover an HBM round trip under load, two do
 // (144 -> 156 TF/s fp32-equivalent on the 576^2 anchor GEMM).
 template <int WN, int NP, int BM>
-__global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
+__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
   constexpr int NT = 2 * BM;                   // threads
   constexpr int BN = 64 * WN, BPLANE = BN * SST, APLANE = BM * SST;
   constexpr int AR = BM / 4;                   // A staging: row step between a thread's 4 rows
@@ -77,7 +86,11 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = g.k1 + g.k2;
+#if GS_ABL == 8
+  const int nchunks = g.m < 0 ? K / SBK : 0;
+#else
   const int nchunks = K / SBK;
+#endif
 
   // staging maps: A BM rows x 8 float4 -> 4 per thread; W planes BN rows x 4 uint4 -> BJ per plane
   const int arow = tid >> 3, ac4 = tid & 7;
@@ -136,8 +149,8 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
     short* d_ = Ap + (row_)*SST + gs_chunk((row_), ac4 >> 1) + 4 * (ac4 & 1);                 \
     if constexpr (NP == 3) {                                                                  \
       uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                                  \
-      split2_bf16x3(v_.x, v_.y, h0_, m0_, l0_);                                               \
-      split2_bf16x3(v_.z, v_.w, h1_, m1_, l1_);                                               \
+      GS_SPLIT(v_.x, v_.y, h0_, m0_, l0_);                                                    \
+      GS_SPLIT(v_.z, v_.w, h1_, m1_, l1_);                                                    \
       *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                                   \
       *reinterpret_cast<uint2*>(d_ + APLANE) = make_uint2(m0_, m1_);                          \
       *reinterpret_cast<uint2*>(d_ + 2 * APLANE) = make_uint2(l0_, l1_);                      \
@@ -176,19 +189,34 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
   DESCO_LOAD_W(0)
   DESCO_LOAD_A(rn, (nchunks > 1 ? 1 : 0) * SBK)
   for (int ch = 0; ch < nchunks; ++ch) {
+#if GS_ABL != 2
     if (ch > 0) __syncthreads();          // previous chunk's fragments have been read
+#endif
+#if GS_ABL == 4 || GS_ABL == 9
+    if (ch == 0)
+#endif
     DESCO_STORE_CHUNK()
+#if GS_ABL != 4 && GS_ABL != 9
     __syncthreads();
+#endif
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
     const int chnn = ch + 2 < nchunks ? ch + 2 : chn;
     ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;
+#if GS_ABL != 4 && GS_ABL != 5 && GS_ABL != 9
     DESCO_LOAD_W(chn * SBK)                // in flight under the MFMAs
+#endif
+#if GS_ABL != 4 && GS_ABL != 6 && GS_ABL != 9
     DESCO_LOAD_A(rn, chnn * SBK)           // two chunks ahead (HBM latency)
+#endif
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
     // (row + 32 i / 32 j keeps (row >> 3) & 3, so one swizzle per lane serves every tile)
     const int fsw = (lane >> 3) & 3, fh = lane >> 5;
     const short* ap = Ap + (wr * 64 + (lane & 31)) * SST;
     const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST;
+#if GS_ABL == 3 || (GS_ABL >= 5 && GS_ABL < 9)
+    if (g.m < 0)
+#endif
+    {
 #pragma unroll
     for (int s = 0; s < SBK / 16; ++s) {
       bf16x8 ah[2], am[2], al[2];
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1][j], 0, 0, 0);
       }
     }
+    }
   }
 #undef DESCO_LOAD_A
 #undef DESCO_LOAD_W
@@ -232,33 +261,66 @@ __global__ __launch_bounds__(2 * BM) void gemm_split_kernel(GemmSplitArgs g, int
 #undef DESCO_STORE_CHUNK
 #undef DESCO_STORE_WJ
 
-  // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), i.e. a
+  // lane holds single columns: stored as they sit, a wave instruction writes 2 x 128 B and the 96 of them
+  // per wave made the stores (not the MFMAs) the longest part of the anchor GEMM (no-MFMA build 3.7 ms with
+  // and 1.75 ms without them, of 4.8).  So each 32-row half of the wave tile goes through a wave-private
+  // [32][32 WN] fp32 image in the (now idle) staging LDS and leaves as 16 bytes per lane: one instruction
+  // covers 1 KB of whole 128-B lines.
+  __syncthreads();                       // every wave is done with the last chunk's fragments
+  constexpr int EW = 32 * WN;            // floats per staged row
+  float* st = reinterpret_cast<float*>(lds) + wave * (32 * EW);
   const int col = lane & 31;
+  const bool wide = ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0) && ((g.ldc & 3) == 0);
 #pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int gcol = n0 + wc * 32 * WN + 32 * j + col;
-    float wsv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
-    const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
+  for (int i = 0; i < 2; ++i) {
+    const int64_t grow0 = m0 + wr * 64 + 32 * i;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < WN; ++j) {
+      const int gcol = n0 + wc * EW + 32 * j + col;
+      float wsv[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
+      const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int row = wr * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const int64_t grow = m0 + row;
-        if (grow < g.m) {
-          float v = acc[i][j][reg];
-          if (g.bias) {
-            if (g.bias_rows == 1)
-              v += b_single;
-            else
-              v += g.bias[(grow % g.bias_rows) * g.n + gcol];
-          }
-          for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
-          g.c[grow * g.ldc + gcol] = apply_act(v, g.act, g.slope);
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int64_t grow = grow0 + row < g.m ? grow0 + row : g.m - 1;
+        float v = acc[i][j][reg];
+        if (g.bias) {
+          if (g.bias_rows == 1)
+            v += b_single;
+          else
+            v += g.bias[(grow % g.bias_rows) * g.n + gcol];
+        }
+        for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
+        st[row * EW + 32 * j + col] = apply_act(v, g.act, g.slope);
+      }
+    }
+    __syncthreads();
+    float* crow = g.c + n0 + wc * EW;
+#pragma unroll
+    for (int p = 0; p < 4 * WN; ++p) {
+      const int idx = lane + 64 * p;               // float4 index in the image: row idx / (8 WN)
+      const int row = idx / (8 * WN), c4 = idx % (8 * WN);
+      const float4 v = *reinterpret_cast<const float4*>(st + 4 * idx);
+      const int64_t grow = grow0 + row;
+#if GS_ABL == 9
+      if (grow < 0) {
+#else
+      if (grow < g.m) {
+#endif
+        float* o = crow + grow * g.ldc + 4 * c4;
+        if (wide) {
+          __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(o));
+        } else {
+          o[0] = v.x;
+          o[1] = v.y;
+          o[2] = v.z;
+          o[3] = v.w;
         }
       }
     }
+    if (i == 0) __syncthreads();
   }
 }
 
@@ -288,7 +350,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 template <int WN, int NP, int BM>
 static int launch_gemm_split_bm(const GemmSplitArgs& g, hipStream_t stream) {
   constexpr int BN = 64 * WN;
-  constexpr size_t lds_bytes = (size_t)(NP * BM * SST + NP * BN * SST) * sizeof(short);
+  constexpr size_t stage_bytes = (size_t)(NP * BM * SST + NP * BN * SST) * sizeof(short);
+  constexpr size_t epi_bytes = (size_t)(BM / 32) * 32 * 32 * WN * sizeof(float);   // one [32][32 WN] image per wave
+  constexpr size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<WN, NP, BM>),
