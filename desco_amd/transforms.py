@@ -3,7 +3,8 @@
 In the reference these are per-item PyG transforms executed in DataLoader workers on every
 ``__getitem__`` (workload.py:443-449).  Here the work is done once, in bulk, by the native
 partition builder (triangle split) or is implicit in the batch containers (zero features), so the
-classes are thin markers that the Workload inspects."""
+classes are thin markers that the Workload inspects; any OTHER transform / pre_transform / pre_filter callable is refused
+by the datasets (workload._check_transforms) instead of being ignored."""
 from __future__ import annotations
 
 from .batch import tconv_split  # noqa: F401  (exported: query-graph triangle split)

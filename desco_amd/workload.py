@@ -27,6 +27,20 @@ def _as_graphset(dataset) -> GraphSet:
     return GraphSet.from_networkx(list(dataset))
 
 
+def _check_transforms(who, transform, pre_transform, pre_filter):
+    """The reference runs ``transform`` per item in DataLoader workers (workload.py:443-449) and ``pre_transform`` /
+    ``pre_filter`` once over the PyG data list (:84-85, 287-288).  The native pipeline has no per-item PyG objects to
+    hand to a callable: the two transforms main.py uses are built in (transforms.py markers), anything else would be
+    silently ignored -- so it is refused."""
+    from .transforms import ToTconvHetero, ZeroNodeFeat
+    if transform is not None and not isinstance(transform, (ToTconvHetero, ZeroNodeFeat)):
+        raise NotImplementedError(
+            f"{who}: transform={type(transform).__name__} is not executed by the native pipeline (supported: None, "
+            "ToTconvHetero, ZeroNodeFeat -- both are built into the partition builder / batch containers)")
+    if pre_transform is not None or pre_filter is not None:
+        raise NotImplementedError(f"{who}: pre_transform / pre_filter callables are not supported (no PyG data list)")
+
+
 class NeighborhoodDataset:
     """One canonical neighborhood per node with >= 1 edge in it (workload.py:153-324)."""
 
@@ -37,6 +51,7 @@ class NeighborhoodDataset:
             raise NotImplementedError("hetero_graph=False (ablation) is outside the hot path")
         if dataset is None and nx_targets is None:
             raise AttributeError("must create Neighborhood dataset with a dataset")
+        _check_transforms("NeighborhoodDataset", transform, pre_transform, pre_filter)
         self.dataset = _as_graphset(dataset if dataset is not None else nx_targets)
         self.depth_neigh, self.root, self.transform = depth_neigh, root, transform
         self.quirk_batch = quirk_batch
@@ -110,6 +125,7 @@ class GossipDataset:
 
     def __init__(self, dataset, root=None, transform=None, pre_transform=None, pre_filter=None,
                  hetero_graph=True):
+        _check_transforms("GossipDataset", transform, pre_transform, pre_filter)
         self.dataset = _as_graphset(dataset)
         self.root = root
         self.x: Optional[torch.Tensor] = None
@@ -176,6 +192,7 @@ class Workload:
     def generate_pipeline_datasets(self, depth_neigh, neighborhood_transform=None,
                                    gossip_transform=None, pre_transform=None, pre_filter=None,
                                    quirk_batch: int = 0):                         # :422-471
+        _check_transforms("Workload.generate_pipeline_datasets", None, pre_transform, pre_filter)
         self.neighborhood_dataset = NeighborhoodDataset(
             depth_neigh=depth_neigh,
             root=os.path.join(self.root, "NeighborhoodDataset") if self.root else None,

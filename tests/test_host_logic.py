@@ -133,6 +133,25 @@ def test_workload_bookkeeping(tmp_path):
     assert torch.equal(nd.y, truth[torch.from_numpy(nd.nx_neighs_indicator)])
 
 
+def test_unsupported_transforms_are_refused_not_ignored(tmp_path):
+    """A per-item PyG transform the native pipeline cannot run (workload.py:443-449 runs it in DataLoader workers) must
+    raise; the two transforms main.py passes are accepted."""
+    from desco_amd.graphs import GraphSet
+    from desco_amd.transforms import ToTconvHetero, ZeroNodeFeat
+    from desco_amd.workload import GossipDataset, NeighborhoodDataset, Workload
+    gs = GraphSet.from_edge_lists([(4, [(0, 1), (1, 2), (2, 3), (3, 0)])])
+    w = Workload(gs, str(tmp_path))
+    w.generate_pipeline_datasets(depth_neigh=4, neighborhood_transform=ToTconvHetero(), gossip_transform=ZeroNodeFeat())
+    with pytest.raises(NotImplementedError, match="transform=function"):
+        w.generate_pipeline_datasets(depth_neigh=4, neighborhood_transform=lambda d: d)
+    with pytest.raises(NotImplementedError, match="pre_transform"):
+        w.generate_pipeline_datasets(depth_neigh=4, pre_transform=lambda d: d)
+    with pytest.raises(NotImplementedError, match="pre_transform / pre_filter"):
+        NeighborhoodDataset(4, None, dataset=gs, pre_filter=lambda d: True)
+    with pytest.raises(NotImplementedError, match="GossipDataset"):
+        GossipDataset(gs, transform=object())
+
+
 def test_syn_edgelist_text_format_round_trip(tmp_path):
     """The reference's synthetic-dataset text files (data.py:644-750): global ids, per-graph edge
     counts; local ids = order of first appearance (from_networkx of add_edges_from)."""
