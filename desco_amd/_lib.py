@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_resident.sh)
 LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -29,6 +29,7 @@ SIGNATURES = {
     "desco_partition_sizes": (c_int, [vp, POINTER(i64), POINTER(i64), POINTER(i64), POINTER(i64)]),
     "desco_partition_export": (c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "desco_partition_free": (None, [vp]),
+    "desco_partition_degree_sort": (c_int, [vp, i64, vp, vp, vp, vp, vp, vp, i32]),
     "desco_canonical_counts": (c_int, [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
     "desco_canonical_class_table": (c_int, [vp, vp, vp, i32, vp, vp]),
     "desco_canonical_counts_dev": (c_int, [vp, i64, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp]),

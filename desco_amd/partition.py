@@ -104,6 +104,25 @@ class NeighborhoodPartition:
             count_orig=self.count_orig[rows_old], vrowptr=vr2.astype(np.int32), vcol=col_new.astype(np.int32),
             depth=self.depth, quirk_batch=self.quirk_batch)
 
+    def degree_sorted(self, num_threads: int = 0) -> "NeighborhoodPartition":
+        """The same block with the count rows of every neighborhood re-ordered by decreasing / increasing (alternating
+        between consecutive neighborhoods) number of count -> count sources (``desco_partition_degree_sort``): fewer
+        gather steps per 16-row tile of the layer kernel on dense shapes.  Row order inside a neighborhood is a
+        convention of this repo; per-neighborhood results only change by fp32 summation order."""
+        if self.num_count == 0:
+            return self
+        cp = np.ascontiguousarray(self.count_ptr, dtype=np.int32)
+        vr = np.ascontiguousarray(self.vrowptr, dtype=np.int32)
+        vc = np.ascontiguousarray(self.vcol, dtype=np.int32)
+        co = np.ascontiguousarray(self.count_orig, dtype=np.int32)
+        co2, vr2, vc2 = np.empty_like(co), np.empty_like(vr), np.empty_like(vc)
+        _lib.check(_lib.lib().desco_partition_degree_sort(
+            cp.ctypes.data, self.num_neigh, vr.ctypes.data, vc.ctypes.data, co.ctypes.data, co2.ctypes.data,
+            vr2.ctypes.data, vc2.ctypes.data, num_threads), "desco_partition_degree_sort")
+        return NeighborhoodPartition(
+            neigh_index=self.neigh_index, indicator=self.indicator, count_ptr=self.count_ptr, count_orig=co2,
+            vrowptr=vr2, vcol=vc2, depth=self.depth, quirk_batch=self.quirk_batch)
+
     # ---- PyG-convention view (tests / interop) ---------------------------------------------
     def edge_index_dict(self) -> Dict[Tuple[str, str, str], np.ndarray]:
         """The six typed ``edge_index`` arrays of the collated HeteroData batch (PyG convention:

@@ -39,8 +39,12 @@ class InferencePipeline:
                  partition: Optional[NeighborhoodPartition] = None,
                  partition_backend: str = "device", rank: Optional[int] = None,
                  world: Optional[int] = None, graph_replay_rows: int = 400_000,
-                 chunks: Optional[int] = None):
-        """``rank`` / ``world`` (default: the initialised torch.distributed group): this process
+                 chunks: Optional[int] = None, degree_sort: Optional[bool] = None):
+        """``degree_sort`` (default on; ``DESCO_DEGREE_SORT=0`` turns it off for A/B runs): the count rows of every
+        neighborhood of a block are re-ordered by their number of count -> count sources
+        (``NeighborhoodPartition.degree_sorted``), which saves gather steps in the layer kernel on dense shapes; the
+        order inside a neighborhood is not observable in any result except through fp32 summation order.
+        ``rank`` / ``world`` (default: the initialised torch.distributed group): this process
         keeps the ``rank``-th of ``world`` contiguous, cost-balanced graph ranges
         (distributed.shard_graphs) with all their neighborhoods -- no data-path collective; the
         results of all ranks are assembled in dataset order by ``gather()``.
@@ -130,8 +134,14 @@ class InferencePipeline:
                 a, b = int(ngp[ga]), int(ngp[gb])
                 if b > a:
                     cuts += [a + c for c in _split_by_budget(rows_per_neigh[a:b], max_neigh_rows)[1:]]
-        self.neigh_batches = [NeighborhoodBatch(part.slice(b0, b1), device)
-                              for b0, b1 in zip(cuts[:-1], cuts[1:]) if b1 > b0]
+        import os as _os
+        if degree_sort is None:
+            degree_sort = _os.environ.get("DESCO_DEGREE_SORT", "1") != "0"
+        self.degree_sort = bool(degree_sort)
+        self.neigh_batches = [
+            NeighborhoodBatch(part.slice(b0, b1).degree_sorted(num_threads) if self.degree_sort else part.slice(b0, b1),
+                              device)
+            for b0, b1 in zip(cuts[:-1], cuts[1:]) if b1 > b0]
         # neighborhood b -> node row of the gossip x matrix (apply_neighborhood_count)
         rows = graphs.graph_ptr[part.neigh_index[:, 0]] + part.neigh_index[:, 1]
         self.scatter_index = torch.from_numpy(rows.astype(np.int32)).to(device)

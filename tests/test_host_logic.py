@@ -286,6 +286,62 @@ def test_partition_select_equals_slice_and_keeps_neighborhoods_intact():
         assert (one.vrowptr == two.vrowptr).all() and (one.vcol == two.vcol).all()
 
 
+def _degree_sorted_numpy(part):
+    """numpy restatement of desco_partition_degree_sort (the checker of the C++ entry point)."""
+    from desco_amd.partition import NeighborhoodPartition
+    Nc, B = part.num_count, part.num_neigh
+    v = part.vrowptr.astype(np.int64)
+    deg4 = np.diff(v)[:4 * Nc].reshape(Nc, 4)
+    ps = 1 if deg4[:, 1].sum() >= deg4[:, 0].sum() else 0
+    seg = np.repeat(np.arange(B, dtype=np.int64), np.diff(part.count_ptr.astype(np.int64)))
+    sign = np.where(seg % 2 == 1, 1, -1)
+    key = sign * ((deg4[:, ps].astype(np.int64) << 32) + deg4[:, 1 - ps])
+    order = np.lexsort((np.arange(Nc), key, seg))            # stable: ties keep the old order
+    new_of_old = np.empty(Nc, np.int64)
+    new_of_old[order] = np.arange(Nc)
+    four = np.arange(4, dtype=np.int64)
+    vr_old = np.concatenate([(order[:, None] * 4 + four).ravel(), np.arange(4 * Nc, 4 * (Nc + B), dtype=np.int64)])
+    deg = v[vr_old + 1] - v[vr_old]
+    vr2 = np.concatenate([[0], np.cumsum(deg)])
+    e_old = np.repeat(v[vr_old] - vr2[:-1], deg) + np.arange(int(vr2[-1]), dtype=np.int64)
+    col_old = part.vcol[e_old].astype(np.int64)
+    col_new = np.where(col_old < Nc, new_of_old[np.minimum(col_old, Nc - 1)], col_old)
+    vrow_of_e = np.repeat(np.arange(len(deg), dtype=np.int64), deg)
+    col_new = np.sort(vrow_of_e * (Nc + B) + col_new) % (Nc + B)
+    return NeighborhoodPartition(part.neigh_index, part.indicator, part.count_ptr, part.count_orig[order],
+                                 vr2.astype(np.int32), col_new.astype(np.int32), part.depth, part.quirk_batch)
+
+
+def _typed_edges_in_original_ids(p):
+    Nc, B = p.num_count, p.num_neigh
+    v = p.vrowptr.astype(np.int64)
+    vrow = np.repeat(np.arange(4 * (Nc + B)), np.diff(v))
+    dst, slot, src = vrow // 4, vrow % 4, p.vcol.astype(np.int64)
+    seg = np.repeat(np.arange(B), np.diff(p.count_ptr))
+    node = lambda r: np.where(r < Nc, p.count_orig[np.minimum(r, Nc - 1)], -1)        # -1 = the canonical row
+    nb = lambda r: np.where(r < Nc, seg[np.minimum(r, Nc - 1)], r - Nc)
+    assert (nb(dst) == nb(src)).all()
+    return set(zip(nb(dst).tolist(), node(dst).tolist(), node(src).tolist(), slot.tolist()))
+
+
+def test_degree_sorted_rows_keep_every_neighborhood_intact():
+    """desco_partition_degree_sort: same typed edge sets in original node ids, sources ascending inside a slot, rows
+    monotone in the sort key with the direction alternating between neighborhoods, and equal to the numpy restatement."""
+    from desco_amd import synthetic
+    from desco_amd.partition import build_partition
+    for part in (_golden_partition(), build_partition(synthetic.syn_1827_shaped(40), 4),
+                 build_partition(synthetic.msrc_imdb_mixed(6, 10), 4)):
+        got, want = part.degree_sorted(), _degree_sorted_numpy(part)
+        for f in ("count_ptr", "vrowptr", "vcol", "count_orig"):
+            assert (getattr(got, f) == getattr(want, f)).all(), f
+        assert _typed_edges_in_original_ids(got) == _typed_edges_in_original_ids(part)
+        v = got.vrowptr.astype(np.int64)
+        assert all((np.diff(got.vcol[v[i]:v[i + 1]]) > 0).all() for i in range(len(v) - 1))
+        assert (got.degree_sorted().vcol == got.vcol).all()               # idempotent (stable sort)
+    empty = part.slice(0, 0)
+    assert empty.degree_sorted().num_count == 0
+
+
 def test_resident_plan_packs_every_eligible_neighborhood_once_within_the_limits():
     from desco_amd import ops
     part = _golden_partition()

@@ -601,6 +601,45 @@ def test_heavy_tailed_shapes(setup, workload):
     assert float((ggot - gref).abs().max()) <= 1e-4 * max(1.0, float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("workload", ["syn_1827", "msrc_imdb", "cox2"])
+def test_degree_sorted_rows_give_the_same_counts(setup, workload):
+    """``NeighborhoodPartition.degree_sorted`` (default in InferencePipeline) only renames the count rows inside every
+    neighborhood: neighborhood logits against the oracle on the ORIGINAL order (same gate as the unsorted path) and the
+    whole pipeline with and without the sort (log space, as the shard-invariance test)."""
+    from desco_amd import synthetic
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm, qids, queries = setup
+    full = {"syn_1827": lambda: synthetic.syn_1827_shaped(60), "msrc_imdb": lambda: synthetic.msrc_imdb_mixed(3, 6),
+            "cox2": lambda: synthetic.cox2_shaped(12)}[workload]()
+    sizes = np.diff(full.graph_ptr)
+    keep = sorted(int(g) for g in np.argsort(sizes)[::-1] if sizes[g] <= 200)[:6]
+    graphs = [full.edge_lists()[g] for g in keep]
+    gs = GraphSet.from_edge_lists(graphs)
+    part = build_partition(gs, 4)
+    srt = part.degree_sorted()
+    assert (srt.count_orig != part.count_orig).any() or workload == "cox2"
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs), OP.query_batch(queries),
+                                    emulate_quirk=False)
+    with torch.no_grad():
+        got = nm._logits(NeighborhoodBatch(srt, DEV), exp2=False)
+        plain = nm._logits(NeighborhoodBatch(part, DEV), exp2=False)
+    report(f"{workload} degree-sorted neigh_logits", got, ref)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got.cpu() - ref).abs().max()) <= 1e-4 * scale
+    assert float((got - plain).abs().max()) <= 1e-4 * scale
+    nm2, gm2 = make_models(seed=0, gains=(0.8, 1.2))      # dense shapes: 2**logit must stay finite
+    nm2, gm2 = nm2.to(DEV), gm2.to(DEV)
+    nm2.set_queries(qids)
+    a = InferencePipeline(nm2, gm2, gs, depth=4, device=DEV, degree_sort=True).run()
+    b = InferencePipeline(nm2, gm2, gs, depth=4, device=DEV, degree_sort=False).run()
+    lg = lambda c: torch.sign(c) * torch.log2(1.0 + c.abs().double())          # noqa: E731
+    for key in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
+        dev = float(((lg(a[key]) - lg(b[key])).abs() / (1.0 + lg(b[key]).abs())).max())
+        print(f"[property] {workload} {key}: sorted vs unsorted rows, worst log2-space deviation {dev:.2e}")
+        assert torch.isfinite(a[key]).all() and dev < 1e-4, (key, dev)
+
+
 def test_degenerate_inputs(setup):
     """Edge cases: graphs without edges (no neighborhoods at all), single-node graphs, one edge."""
     from desco_amd.pipeline import InferencePipeline
