@@ -67,7 +67,8 @@ SIGNATURES = {
                                          i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]),
     "desco_vcsr_transpose_sym": (c_int, [vp, vp, i64, i32, i64, vp, vp, vp]),
     "desco_segment_ids": (c_int, [vp, i64, vp, vp]),
-    "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp]),
+    "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp, vp]),
+    "desco_gossip_tile_order": (c_int, [vp, i64, vp, vp]),
     "desco_csr_gather_sum_add_f32": (c_int, [vp, i64, vp, vp, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]),
     "desco_add_rows_f32": (c_int, [vp, i64, vp, i64, i64, i32, vp]),

@@ -268,6 +268,16 @@ class GossipBatch:
         self.graph_ptr = _i32(graphs.graph_ptr, device)
         self.x = None if x is None else x.to(device).float().contiguous()
         self.y = None if y is None else y.to(device)
+        self._tile_perm = None
+
+    @property
+    def tile_perm(self):
+        """Degree-balanced row order of the fused gossip kernel's neighbour-sum phase per 128-node tile
+        (ops.gossip_tile_order): a function of the CSR alone, computed on first use."""
+        if self._tile_perm is None and self.device.type == "cuda":
+            from . import ops
+            self._tile_perm = ops.gossip_tile_order(self.rowptr, self.num_nodes)
+        return self._tile_perm
 
     def to(self, device):
         if _norm_device(device) == self.device:

@@ -44,7 +44,7 @@ constexpr int PCAP = 1216;         // neighbour records prefetched (up to three 
 constexpr int ECAP = 1216;         // neighbour records staged per pass (aliases weight buffer 1: 20 B each)
 constexpr int CST = 832;           // u, d1, tp, b3 (64 each), b5, w7 (256 each), zp_q (64)
 constexpr size_t GOSSIP_LDS_BYTES = (size_t)2 * 3 * PLN * 2 + (size_t)2 * 3 * WPLN * 2 + GT * 16 +
-                                    132 * 4 + CST * 4 + 2 * GT * 4;
+                                    132 * 4 + CST * 4 + 2 * GT * 4 + GT;
 static_assert(ECAP * 20 <= 3 * WPLN * 2, "neighbour staging must fit in one weight buffer");
 static_assert(GOSSIP_LDS_BYTES <= 160 * 1024, "gossip_fused: LDS budget exceeded");
 
@@ -72,6 +72,7 @@ struct GossipFusedArgs {
   const float* w7;          // [256]
   float b7;
   float* out;               // [N,Q]
+  const uint8_t* tperm;     // [tiles*128] phase-1 slot -> row of the tile (desco_gossip_tile_order), or null
 };
 
 // scalars pre-pass: one wave per node, lane = query
@@ -115,6 +116,39 @@ __global__ __launch_bounds__(256) void gossip_scalars_kernel(const float* __rest
   if (lane < Q)
     scal[i * Q + lane] = make_float4(a * flo + (1.f - a) * fhi, a * slo + (1.f - a) * shi,
                                      b * flo + (1.f - b) * fhi, x[i * ldx + q]);
+}
+
+// Phase-1 work order of a 128-node tile (desco_gossip_tile_order): in phase 1 of the fused kernel a half wave walks the
+// neighbour list of one row, the two halves of a wave run in lock step (iterations = the longer list of the pair), a
+// wave takes 8 pairs one after the other and the phase ends at a block barrier (time = the slowest wave).  With rows in
+// node order that is 1.3-1.8x the balanced time (tools note in DESIGN.md section 8).  Here the tile's rows are sorted by
+// degree, consecutive rows form a pair, and the pairs are dealt to the 8 waves in snake order; perm[16 w + 2 i + h] =
+// the row that wave w handles as pair i, half h.  One block of 128 threads per tile, bitonic sort in LDS.
+__global__ __launch_bounds__(128) void gossip_tile_order_kernel(const int32_t* __restrict__ rowptr, int64_t num_nodes,
+                                                                uint8_t* __restrict__ perm) {
+  __shared__ uint32_t key[128];
+  const int t = threadIdx.x;
+  const int64_t node = (int64_t)blockIdx.x * 128 + t;
+  const uint32_t deg = node < num_nodes ? (uint32_t)(rowptr[node + 1] - rowptr[node]) : 0u;
+  key[t] = ((0xffffffu - (deg < 0xffffffu ? deg : 0xffffffu)) << 8) | (uint32_t)t;   // ascending = high degree first
+  __syncthreads();
+  for (int k = 2; k <= 128; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = t ^ j;
+      if (o > t) {
+        const uint32_t a = key[t], b = key[o];
+        const bool up = (t & k) == 0;
+        if ((a > b) == up) {
+          key[t] = b;
+          key[o] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int pair = t >> 1, grp = pair >> 3, slot = pair & 7;
+  const int w = (grp & 1) ? 7 - slot : slot;                  // snake: the 8 heaviest pairs go to waves 0..7, the next 8 to 7..0
+  perm[(int64_t)blockIdx.x * 128 + 16 * w + 2 * grp + (t & 1)] = (uint8_t)(key[t] & 0xffu);
 }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -247,6 +281,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   int* rp = reinterpret_cast<int*>(srow + GT);                // rowptr[n0 .. n0+128]
   float* cst = reinterpret_cast<float*>(rp + 132);            // bias vectors (see CST)
   float* red = cst + CST;                                     // [2][128] head partials
+  uint8_t* tperm = reinterpret_cast<uint8_t*>(red + 2 * GT);  // [128] phase-1 slot -> row
   int* ecol = reinterpret_cast<int*>(WB1);                    // [ECAP]
   float4* escal = reinterpret_cast<float4*>(ecol + ECAP);     // [ECAP]
 
@@ -278,6 +313,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   // item is done: a tile does not start with three dependent global-memory latencies.
   float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow, n_scal2 = n_srow, n_scal3 = n_srow;
   int n_rp = 0, n_col = 0, n_col2 = 0, n_col3 = 0, n_ebeg = 0, n_cnt = 0;
+  uint32_t n_perm = 0x03020100u + 0x04040404u * (uint32_t)(tid & 31);   // identity slots 4 tid .. 4 tid + 3
   float n_zp = 0.f, n_gq = 0.f;            // the next item's per-query vectors (this lane's slice)
   float2 n_pc = make_float2(0.f, 0.f), n_zc = n_pc;
   const int f0 = 2 * (lane & 31);          // phase-1 lane map: features (f0, f0+1)
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     const int nr_ = (int)((g.num_nodes - t0_) < GT ? (g.num_nodes - t0_) : GT);            \
     if (tid < GT) n_srow = g.scal[(t0_ + (tid < nr_ ? tid : nr_ - 1)) * Q + q_];           \
     if (tid <= GT) n_rp = g.rowptr[t0_ + (tid < nr_ ? tid : nr_)];                         \
+    if (g.tperm && tid < GT / 4) n_perm = reinterpret_cast<const uint32_t*>(g.tperm + ((it_) / Q) * GT)[tid]; \
     n_ebeg = g.rowptr[t0_];                                                                \
     n_cnt = g.rowptr[t0_ + nr_] - n_ebeg;                                                  \
     n_cnt = n_cnt < PCAP ? n_cnt : PCAP;                                                   \
@@ -323,6 +360,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     const int q = (int)(item % Q);
     if (tid < GT) srow[tid] = n_srow;
     if (tid <= GT) rp[tid] = n_rp;
+    if (tid < GT / 4) reinterpret_cast<uint32_t*>(tperm)[tid] = n_perm;
     if (tid < n_cnt) {
       ecol[tid] = n_col;
       escal[tid] = n_scal;
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
       for (;;) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int row = wave * 16 + 2 * i + half1;
+          const int row = tperm[wave * 16 + 2 * i + half1];
           const int node = (int)n0 + row;
           int lo = rp[row] - base, hi = rp[row + 1] - base;
           lo = lo < 0 ? 0 : lo;
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int row = wave * 16 + 2 * i + half1;
+        const int row = tperm[wave * 16 + 2 * i + half1];
         const float4 si = srow[row];
         float hx = si.x * pc.x + si.y * rc.x + si.w * tc.x + zc.x;
         float hy = si.x * pc.y + si.y * rc.y + si.w * tc.y + zc.y;
@@ -541,6 +579,17 @@ extern "C" int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32
   return launch_status("desco_gossip_scalars_f32");
 }
 
+extern "C" int desco_gossip_tile_order(const int32_t* rowptr, int64_t num_nodes, uint8_t* perm,
+                                       desco_stream_t stream) {
+  if (num_nodes == 0) return 0;
+  if (!rowptr || !perm || num_nodes < 0) return fail(DESCO_EINVAL, "desco_gossip_tile_order: bad argument");
+  const int64_t tiles = (num_nodes + GT - 1) / GT;
+  if (tiles > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_tile_order: too many nodes");
+  hipLaunchKernelGGL(gossip_tile_order_kernel, dim3((unsigned)tiles), dim3(128), 0, (hipStream_t)stream, rowptr,
+                     num_nodes, perm);
+  return launch_status("desco_gossip_tile_order");
+}
+
 extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
                                       int64_t num_nodes, int num_q, const float* g1, const float* p,
                                       const float* z, const float* zp, const float* r,
@@ -548,14 +597,16 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                                       const float* d1, const int16_t* w1_planes,
                                       const int16_t* wp_planes, const int16_t* w3_planes,
                                       const float* b3, const int16_t* w5_planes, const float* b5,
-                                      const float* w7, float b7, float* out, desco_stream_t stream) {
+                                      const float* w7, float b7, float* out, const uint8_t* tile_perm,
+                                      desco_stream_t stream) {
   if (num_nodes == 0) return 0;
   auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
   auto mis8 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 7) != 0; };
   if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !w1_planes ||
       !wp_planes || !w3_planes || !b3 || !w5_planes || !b5 || !w7 || !out || num_nodes < 0 ||
       num_q < 1 || num_q > 65535 || mis16(scal4) || mis16(w1_planes) || mis16(wp_planes) ||
-      mis16(w3_planes) || mis16(w5_planes) || mis8(p) || mis8(z) || mis8(r) || mis8(t))
+      mis16(w3_planes) || mis16(w5_planes) || mis8(p) || mis8(z) || mis8(r) || mis8(t) ||
+      (reinterpret_cast<uintptr_t>(tile_perm) & 3))
     return fail(DESCO_EINVAL, "desco_gossip_fused_f32: bad argument");
   const int64_t bx = (num_nodes + GT - 1) / GT;
   if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f32: too many nodes");
@@ -563,7 +614,7 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                     zp, r, t, u, tp, d1,
                     reinterpret_cast<const short*>(w1_planes), reinterpret_cast<const short*>(wp_planes),
                     reinterpret_cast<const short*>(w3_planes), b3,
-                    reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out};
+                    reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out, tile_perm};
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_fused_kernel),

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,6 +53,9 @@ RESIDENT_MIN_ROWS = 48
 # launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
 # --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
 FUSED_TRAIN_TRUNK = True
+# degree-balanced row order inside the fused gossip kernel's 128-node tiles (desco_gossip_tile_order); results are
+# bit-identical with and without it
+GOSSIP_TILE_ORDER = os.environ.get("DESCO_GOSSIP_TILE_ORDER", "1") != "0"
 _RELEASED = object()        # placeholder of a layer's rows that shmp_forward has released
 
 TARGET_NODE_TYPES = ["count", "canonical"]
@@ -776,7 +781,8 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
                  # the fused kernel takes n-major ([out, in]) weight blocks
                  "w1s": pk["fused_w1s"], "wps": pk["fused_wps"], "w3s": pk["fused_w3s"], "b3": b3,
                  "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
-            outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v))
+            outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v,
+                                         tile_perm=batch.tile_perm if GOSSIP_TILE_ORDER else None))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0

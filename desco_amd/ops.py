@@ -669,10 +669,24 @@ def gossip_scalars(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, g0,
 GOSSIP_FUSED_FLOPS_PER_ROW = 2.0 * 64 * (128 + 128 + 64) + 2.0 * 64 * 256
 
 
+def gossip_tile_order(rowptr: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """uint8 [ceil(N/128)*128]: per 128-node tile the degree-balanced row order of the fused kernel's neighbour-sum
+    phase (desco_gossip_tile_order); depends on the CSR only, so a batch computes it once."""
+    tiles = (num_nodes + 127) // 128
+    perm = torch.empty((tiles * 128,), device=rowptr.device, dtype=torch.uint8)
+    if num_nodes:
+        _lib.check(_lib.lib().desco_gossip_tile_order(_dev(rowptr, "rowptr", torch.int32), num_nodes,
+                                                      _dev(perm, "perm", torch.uint8), _stream()),
+                   "gossip_tile_order")
+    return perm
+
+
 def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
-                 num_q: int, v: dict) -> torch.Tensor:
+                 num_q: int, v: dict, tile_perm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One on-chip pass per (128-node tile, query): returns pred [N, Q] (see desco_hip.h)."""
     out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
+    if tile_perm is not None and tile_perm.numel() < ((num_nodes + 127) // 128) * 128:
+        raise ValueError("gossip_fused: tile_perm is shorter than the tiles of this batch")
     L = _lib.lib()
     names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1s", "wps", "w3s", "b3", "w5s", "b5", "w7")
     ptrs = []
@@ -685,7 +699,9 @@ def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, nu
                 rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
         _lib.check(L.desco_gossip_fused_f32(_dev(scal, "scal"), _dev(rowptr, "rowptr", torch.int32),
                                             _dev(col, "col", torch.int32), num_nodes, num_q, *ptrs,
-                                            float(v["b7"]), _dev(out, "out"), _stream()),
+                                            float(v["b7"]), _dev(out, "out"),
+                                            None if tile_perm is None else _dev(tile_perm, "tile_perm", torch.uint8),
+                                            _stream()),
                    "gossip_fused")
     return out
 

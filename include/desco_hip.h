@@ -393,7 +393,13 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
                            const int16_t* w1_planes, const int16_t* wp_planes,
                            const int16_t* w3_planes, const float* b3, const int16_t* w5_planes,
                            const float* b5, const float* w7, float b7, float* out,
-                           desco_stream_t stream);
+                           const uint8_t* tile_perm, desco_stream_t stream);
+/* tile_perm (optional, 4-byte aligned, [ceil(num_nodes/128)*128] bytes from desco_gossip_tile_order): the order in
+ * which the 8 waves of a block walk the rows of a 128-node tile in the neighbour-sum phase -- rows sorted by degree,
+ * paired, pairs dealt to the waves in snake order (a half wave per row, the two halves of a wave in lock step, a block
+ * barrier at the end: with rows in node order the phase takes 1.3-1.8x its balanced time).  NULL = node order.
+ * The result does not depend on it bit for bit (every row's sum keeps its own CSR order). */
+int desco_gossip_tile_order(const int32_t* rowptr, int64_t num_nodes, uint8_t* tile_perm, desco_stream_t stream);
 
 /* K21 tail: out[r] = add[r] + sum_c y[r,c]*w[c] + b   (post_mp.7 with output_dim 1, then
  * pred = neigh_pred + gossip_pred, lightning_model.py:622-625) */

@@ -267,6 +267,41 @@ def test_fused_gossip_equals_unfused_incl_hubs(setup):
     torch.testing.assert_close(fused - batch.x, unfused - batch.x, rtol=1e-4, atol=2e-4)
 
 
+def test_gossip_tile_order_is_a_permutation_and_changes_no_bit(setup):
+    """desco_gossip_tile_order: every 128-node tile gets a permutation of 0..127 (real rows sorted by degree, pairs dealt
+    to the 8 waves in snake order), and the fused kernel's result does not depend on it bit for bit (a row's neighbour
+    sum keeps its own CSR order) -- on a set with hub rows, a ragged last tile and isolated nodes."""
+    import desco_amd.gnn_model as GM
+    from desco_amd import ops
+    nm, gm, qids, queries = setup
+    rng = np.random.default_rng(9)
+    hub_n = 700
+    hub = (hub_n, [(3, v) for v in range(hub_n) if v != 3] + [(v, v + 1) for v in range(20, 300)])
+    graphs = golden_graphs(max_n=60)[:8] + [hub, (5, [(0, 1)])] + golden_graphs(max_n=60)[8:12]
+    gs = GraphSet.from_edge_lists(graphs)
+    batch = GossipBatch(gs, DEV, x=torch.from_numpy(rng.gamma(1.0, 4.0, size=(gs.num_nodes, len(queries)))).float())
+    perm = batch.tile_perm.cpu().numpy().astype(np.int64).reshape(-1, 128)
+    assert perm.shape[0] == (gs.num_nodes + 127) // 128 and gs.num_nodes % 128 != 0
+    assert (np.sort(perm, axis=1) == np.arange(128)).all()
+    deg = np.zeros(perm.shape[0] * 128, np.int64)
+    deg[:gs.num_nodes] = np.diff(gs.rowptr)
+    for t in range(perm.shape[0]):
+        d = deg[128 * t + perm[t]].reshape(8, 8, 2)            # [wave][pair][half]
+        pair_cost = d.max(2)                                    # lock-stepped halves
+        order = np.concatenate([pair_cost[:, g] if g % 2 == 0 else pair_cost[::-1, g] for g in range(8)])
+        assert (np.diff(order) <= 0).all(), "pairs must be dealt in snake order of decreasing cost"
+        assert (d[:, :, 0] >= d[:, :, 1]).all()
+    gm.set_query_emb(nm.get_query_emb())
+    try:
+        GM.GOSSIP_TILE_ORDER = True
+        a = gm.graph_to_count(batch)
+        GM.GOSSIP_TILE_ORDER = False
+        b = gm.graph_to_count(batch)
+    finally:
+        GM.GOSSIP_TILE_ORDER = True
+    assert torch.equal(a, b)
+
+
 def test_unfused_shmp_equals_fused(setup):
     import desco_amd.gnn_model as GM
     nm, *_ = setup
