@@ -316,6 +316,9 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // source-row addresses then need a shift instead of a 64-bit multiply per gathered row, and the stores
 // of a tile are one address with immediate offsets
 // POOL: fused pooling epilogue (instantiated for the count-row launches only)
+#ifdef SH16_TAIL     // tail probe (tools/debug): per block its start and the end of its last wave, 100 MHz ticks
+__device__ unsigned long long sh16_tail[1024][2];
+#endif
 template <int NW, int KB, int ST, bool LD64, bool POOL>
 __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const int32_t* __restrict__ rowptr_s,
                                                               const uint32_t* __restrict__ pool_bits_s,
@@ -350,6 +353,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   }
   if (tid < 64) biasL[tid] = g.bias ? g.bias[tid] : 0.f;
   if (tid == 0) *next_sub = 0;
+#ifdef SH16_TAIL
+  if (tid == 0) sh16_tail[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();
 
   const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
@@ -657,6 +663,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_ROW
     if (!has_next) break;
   }
+#ifdef SH16_TAIL
+  if (lane == 0) atomicMax(&sh16_tail[blockIdx.x & 1023][1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 
@@ -751,3 +760,14 @@ bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
 }
 
 }  // namespace desco
+
+#ifdef SH16_TAIL
+extern "C" int desco_debug_sh16_tail(unsigned long long* out, int reset) {
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(desco::sh16_tail), sizeof(unsigned long long) * 2048);
+  if (reset) {
+    static unsigned long long z[2048];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(desco::sh16_tail), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
