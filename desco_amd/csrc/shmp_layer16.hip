@@ -253,11 +253,16 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // rows are 64 B with no padding: the 16-byte chunk k/8 of row r sits at chunk (k/8) ^ (-(r/4) & 3), which
 // makes both this write (ds_write_b64) and the fragment read conflict-free (ds_read_b128 is served in
 // the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: tools/micro/lds_banks.py)
+#if defined(SH16_ABL) && SH16_ABL == 2
+#define DESCO_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
+#else
+#define DESCO_SPLIT(a_, b_, h_, m_, l_) split2_bf16x3(a_, b_, h_, m_, l_)
+#endif
 #define DESCO_PUT_X6(av_, it_)                                                  \
   {                                                                             \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                      \
-    split2_bf16x3(av_.x, av_.y, h0_, m0_, l0_);                                   \
-    split2_bf16x3(av_.z, av_.w, h1_, m1_, l1_);                                   \
+    DESCO_SPLIT(av_.x, av_.y, h0_, m0_, l0_);                                     \
+    DESCO_SPLIT(av_.z, av_.w, h1_, m1_, l1_);                                     \
     short* d_ = Ap + ((it_) * 8 + g8) * APS +                                   \
                 ((((l8 >> 1) ^ (0 - ((it_) * 2 + (g8 >> 2)))) & 3) << 3) + 4 * (l8 & 1); \
     *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                       \
@@ -267,7 +272,14 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // 24 bf16 MFMAs (6-product split) of v_mfma_f32_16x16x32_bf16 on the staged half (32 k) of block b_: lane
 // (r = lane&15, q = lane>>4) holds A[row r][k = 8 q + 0..7] and B[k = 8 q + 0..7][col 16 t + r] of every
 // plane, t = 0..3 (the four 16-column tiles of the 64 outputs)
+#ifndef SH16_ABL
+#define SH16_ABL 0
+#endif
+#if SH16_ABL == 1        // timing-only builds (tools/debug/ab_libs.sh): 1 no MFMA, 2 no split arithmetic, 3 no output stores
+#define DESCO_M16(a_, b_, c_) { asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_)); }
+#else
 #define DESCO_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
+#endif
 #define DESCO_MFMA_HALF_X6(b_, h_)                                                                \
   {                                                                                               \
     const short* ap_ = Ap + (lane & 15) * APS + ((((lane >> 4) ^ (0 - (lane >> 2))) & 3) << 3);   \
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     }
     const int nru = __builtin_amdgcn_readfirstlane(nr_out);
 #define DESCO_ROW(r_) ((r_) < 4 ? q0[(r_) & 3] : (r_) < 8 ? q1[(r_) & 3] : (r_) < 12 ? q2[(r_) & 3] : q3[(r_) & 3])
-    if (!POOL || g.out) {
+    if ((!POOL || g.out) && !(SH16_ABL == 3 && g.row0 >= 0)) {
       float* ob = g.out + grow_out * LDO + lane;               // LD64: row r at the immediate offset 256 r
       if (nru == 16) {
 #pragma unroll
