@@ -297,6 +297,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define GF_RELU(v_) ((v_) > 0.f ? (v_) : 0.f)
 #define GF_LEAKY01(v_) ((v_) > 0.f ? (v_) : 0.1f * (v_))
 
+#ifdef GF_TAIL      // tail probe (tools/debug): per block its start and end, 100 MHz ticks
+__device__ unsigned long long gf_tail[1024][2];
+#endif
 __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
   short* I0 = reinterpret_cast<short*>(gf_lds);          // h1, later y1
@@ -322,6 +325,9 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
   int64_t item = blockIdx.x;
   if (item >= nitems) return;
+#ifdef GF_TAIL
+  if (threadIdx.x == 0) gf_tail[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (int i = tid; i < 64; i += GNT) {
     cst[i] = g.u[i];
@@ -572,6 +578,9 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     item = next;
     __syncthreads();            // srow / rp / red / weight buffers are free again
   }
+#ifdef GF_TAIL
+  if (threadIdx.x == 0) gf_tail[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #undef GF_STAGE1
 #undef GF_STAGE2
 #undef GF_STAGE3
@@ -667,3 +676,14 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                      a, bx);
   return launch_status("desco_gossip_fused_f32");
 }
+
+#ifdef GF_TAIL
+extern "C" int desco_debug_gf_tail(unsigned long long* out, int reset) {
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(desco::gf_tail), sizeof(unsigned long long) * 2048);
+  if (reset) {
+    static unsigned long long z[2048];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(desco::gf_tail), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
