@@ -68,3 +68,52 @@ def report(name, got, ref):
     print(f"[parity] {name}: max|d|={d.max().item():.3e} max rel={rel.max().item():.3e} "
           f"ref max={ref.abs().max().item():.3e}")
     return d.max().item()
+
+
+def random_family_graphs(seed, count):
+    """Graph families the fixtures do not hold: stars, wheels, paths, cycles, cliques with tails, grids, barbells, random
+    trees, G(n,p) at three densities, graphs with isolated nodes and with several components."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        kind = i % 11
+        n = int(rng.integers(4, 40))
+        e = set()
+        add = lambda a, b: e.add((min(a, b), max(a, b))) if a != b else None       # noqa: E731
+        if kind == 0:                                   # star (hub row)
+            c = int(rng.integers(n))
+            [add(c, v) for v in range(n)]
+        elif kind == 1:                                 # wheel
+            [add(0, v) for v in range(1, n)]
+            [add(v, v % (n - 1) + 1) for v in range(1, n)]
+        elif kind == 2:                                 # path
+            [add(v, v + 1) for v in range(n - 1)]
+        elif kind == 3:                                 # cycle + chords
+            [add(v, (v + 1) % n) for v in range(n)]
+            [add(int(rng.integers(n)), int(rng.integers(n))) for _ in range(n // 4)]
+        elif kind == 4:                                 # clique with a tail (all-triangle edges + tride edges)
+            k = min(n, int(rng.integers(4, 9)))
+            [add(a, b) for a in range(k) for b in range(a + 1, k)]
+            [add(v, v + 1) for v in range(k - 1, n - 1)]
+        elif kind == 5:                                 # grid
+            w = max(2, int(np.sqrt(n)))
+            n = w * w
+            [add(r * w + c, r * w + c + 1) for r in range(w) for c in range(w - 1)]
+            [add(r * w + c, (r + 1) * w + c) for r in range(w - 1) for c in range(w)]
+        elif kind == 6:                                 # barbell
+            k = max(3, n // 3)
+            n = 2 * k + 2
+            [add(a, b) for a in range(k) for b in range(a + 1, k)]
+            [add(k + 2 + a, k + 2 + b) for a in range(k) for b in range(a + 1, k)]
+            add(k - 1, k), add(k, k + 1), add(k + 1, k + 2)
+        elif kind == 7:                                 # random tree, random labels
+            [add(v, int(rng.integers(v))) for v in range(1, n)]
+        else:                                           # G(n, p), p = 0.08 / 0.2 / 0.45; isolated nodes and components stay
+            p = (0.08, 0.2, 0.45)[kind - 8]
+            m = rng.random((n, n)) < p
+            [add(a, b) for a in range(n) for b in range(a + 1, n) if m[a, b]]
+        perm = rng.permutation(n)                       # canonical neighborhoods depend on the node ids: shuffle them
+        edges = sorted((int(min(perm[a], perm[b])), int(max(perm[a], perm[b]))) for a, b in e)
+        if edges:
+            out.append((n, edges))
+    return out

@@ -73,6 +73,19 @@ def test_selfloop_quirk_matches_pyg_semantics(partition_golden, qb):
     assert part.num_edges < full.num_edges
 
 
+@pytest.mark.parametrize("seed,depth", [(21, 4), (22, 2)])
+def test_random_graph_families_match_oracle(seed, depth):
+    """Stars, wheels, paths, cycles with chords, cliques with tails, grids, barbells, random trees and G(n,p) at three
+    densities with shuffled node ids: index, indicator and the six typed edge sets of the host builder equal the oracle's."""
+    from helpers import random_family_graphs
+    graphs = random_family_graphs(seed, 44)
+    part = build_partition(GraphSet.from_edge_lists(graphs), depth, num_threads=2)
+    idx, ind, neighs = OP.neighborhood_dataset(graphs, depth)
+    assert (part.neigh_index == idx).all() and (part.indicator == ind).all()
+    assert _typed_sets(part.edge_index_dict()) == _typed_sets(OP.neighborhood_batch(neighs)["edge_index"])
+    assert part.num_edges == 2 * sum(len(e) for _, e in neighs)
+
+
 def test_empty_and_edgeless_inputs():
     part = build_partition(GraphSet.from_edge_lists([]), 4)
     assert part.num_neigh == 0 and part.num_edges == 0

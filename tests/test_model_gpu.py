@@ -14,7 +14,7 @@ from desco_amd.partition import build_partition  # noqa: E402
 from oracle import model as OM  # noqa: E402
 from oracle import partition as OP  # noqa: E402
 
-from helpers import cpu_sd, golden_graphs, make_models, report, standard_queries  # noqa: E402
+from helpers import cpu_sd, golden_graphs, make_models, random_family_graphs, report, standard_queries  # noqa: E402
 
 DEV = "cuda"
 RTOL, ATOL = 1e-4, 1e-4
@@ -175,6 +175,35 @@ def test_full_size_dense_workloads_are_shard_invariant(workload):
         print(f"[property] {workload} {key}: whole vs two halves, worst log2-space deviation "
               f"{float(dev.max()):.2e} (relative {worst:.2e}); max |count| {float(ref.abs().max()):.3e}")
         assert worst < 1e-4, (key, worst)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_graph_families_pipeline_vs_oracle(seed):
+    """The whole two-stage pass on ~45 random graphs of eleven families (hub rows, all-triangle and no-triangle
+    neighborhoods, isolated nodes, several components, shuffled node ids) against the oracle: partition index / indicator
+    bit-exact, counts in log space within the suite's gate -- with the degree-sorted rows and the gossip tile order on
+    (the defaults)."""
+    from desco_amd.pipeline import InferencePipeline
+    nm, gm = make_models(seed=seed, gains=(0.8, 1.2))
+    qids, queries = standard_queries()
+    nm, gm = nm.to(DEV), gm.to(DEV)
+    nm.set_queries(qids)
+    graphs = random_family_graphs(seed, 48)
+    gs = GraphSet.from_edge_lists(graphs)
+    ref = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), graphs, queries, emulate_quirk=False)
+    pipe = InferencePipeline(nm, gm, gs, depth=4, device=DEV)
+    assert pipe.degree_sort
+    out = pipe.run()
+    assert (pipe.partition.neigh_index == ref["index"]).all()
+    assert (pipe.partition.indicator == ref["indicator"]).all()
+    print(f"[shape] {len(graphs)} graphs, {gs.num_nodes} nodes, {ref['neigh_count'].shape[0]} neighborhoods")
+    lg = lambda c: torch.sign(c) * torch.log2(1.0 + c.abs().double())          # noqa: E731
+    for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
+        got, want = out[k].cpu(), ref[k]
+        assert torch.isfinite(want).all() and torch.isfinite(got).all(), k
+        dev = float(((lg(got) - lg(want)).abs() / (1.0 + lg(want).abs())).max())
+        print(f"[parity] families seed {seed} {k}: worst log2-space deviation {dev:.2e}; max |count| {float(want.abs().max()):.3e}")
+        assert dev < 1e-4, (k, dev)
 
 
 def test_mutag_shaped_pipeline_vs_oracle(setup):

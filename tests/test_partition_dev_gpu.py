@@ -44,6 +44,13 @@ def test_synthetic_shapes_bit_exact(workload, count):
     assert torch.equal(b.vrowptr.cpu(), torch.from_numpy(host.vrowptr))
 
 
+@pytest.mark.parametrize("seed,depth", [(31, 4), (32, 3)])
+def test_random_graph_families_bit_exact(seed, depth):
+    from helpers import random_family_graphs
+    gs = GraphSet.from_edge_lists(random_family_graphs(seed, 66))
+    _same(build_partition_device(gs, depth), build_partition(gs, depth))
+
+
 def test_edge_cases():
     # isolated nodes, a single edge, a triangle, a star with a hub of degree 70 (> one wave of lanes)
     graphs = [(3, []), (2, [(0, 1)]), (3, [(0, 1), (1, 2), (0, 2)]),
