@@ -32,6 +32,18 @@ def test_counts_size2_and_6_vs_bruteforce():
     assert got.long().tolist() == want.tolist()
 
 
+def test_random_graph_families_vs_bruteforce():
+    """The 29 standard queries on small graphs of eleven families (stars, wheels, grids, barbells, cliques with tails,
+    trees, G(n,p), ... with shuffled ids): the host enumerator equals the brute-force definition, node by node."""
+    from helpers import random_family_graphs, standard_queries
+    _, queries = standard_queries()
+    graphs = [g for g in random_family_graphs(41, 120) if g[0] <= 13][:22]
+    assert len(graphs) >= 15
+    got = canonical_counts(GraphSet.from_edge_lists(graphs), queries, backend="host").long()
+    want = np.concatenate([OP.canonical_counts_bruteforce(n, e, queries) for n, e in graphs])
+    assert want.sum() > 500 and got.tolist() == want.tolist()
+
+
 def test_workload_compute_groundtruth(tmp_path):
     from desco_amd.data import STANDARD_QUERY_IDS
     from desco_amd.workload import Workload

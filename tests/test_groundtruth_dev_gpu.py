@@ -59,6 +59,19 @@ def test_device_counts_equal_host_enumerator(case):
     assert torch.equal(canonical_counts(gs, queries, backend="auto"), host)     # auto -> device on this box
 
 
+def test_random_graph_families_device_vs_host_and_bruteforce():
+    from helpers import random_family_graphs
+    _, queries = standard_queries()
+    graphs = random_family_graphs(43, 90)
+    gs = GraphSet.from_edge_lists(graphs)
+    dev = canonical_counts_device(gs, queries).cpu()
+    assert dev.tolist() == canonical_counts(gs, queries, backend="host").long().tolist()
+    small = [g for g in graphs if g[0] <= 12][:10]
+    got = canonical_counts_device(GraphSet.from_edge_lists(small), queries).cpu()
+    want = np.concatenate([OP.canonical_counts_bruteforce(n, e, queries) for n, e in small])
+    assert got.tolist() == want.tolist()
+
+
 def test_device_path_rejections_and_fallback():
     g = GraphSet.from_edge_lists([(6, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)])])
     six = [(6, [(i, i + 1) for i in range(5)])]
