@@ -384,6 +384,60 @@ def test_neighborhood_training_loss_and_gradients(setup):
     print(f"[parity] worst relative gradient error over {len(sd)} tensors: {worst:.3e}")
 
 
+def test_training_gradients_on_random_graph_families():
+    """The same loss / gradient parity on the random graph families (hub rows, all-triangle and no-triangle
+    neighborhoods, single-count-node neighborhoods): loss and every parameter gradient of the neighborhood model, then of
+    the gossip model, vs torch autograd through the oracle."""
+    qids, queries = standard_queries()
+    nm, gm = make_models(seed=3, gains=(0.8, 1.2))
+    nm, gm = nm.to(DEV), gm.to(DEV)
+    nm.set_queries(qids)
+    graphs = random_family_graphs(51, 33)
+    gs = GraphSet.from_edge_lists(graphs)
+    part = build_partition(gs, 4)
+    g = torch.Generator().manual_seed(6)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) ** 3 * 30)
+    nm.zero_grad()
+    loss = nm.train_forward(NeighborhoodBatch(part, DEV, y=y), 0)
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in nm.state_dict().items()}
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref_loss = OM.neighborhood_loss(sd, OP.neighborhood_batch(neighs), OP.query_batch(queries), y, emulate_quirk=False)
+    ref_loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-4, atol=1e-5)
+    worst = 0.0
+    for name, p in nm.named_parameters():
+        ref = sd[name].grad
+        if ref is None:
+            continue
+        err = float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-8)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    print(f"[parity] families: {part.num_neigh} neighborhoods, neighborhood-model worst relative gradient error {worst:.3e}")
+    # gossip stage
+    x = torch.rand(gs.num_nodes, len(queries), generator=g) * 15
+    yn = torch.floor(torch.rand(gs.num_nodes, len(queries), generator=g) * 20)
+    qemb = nm.get_query_emb().detach()
+    gm.set_query_emb(qemb)
+    gm.zero_grad()
+    batch = GossipBatch(gs, DEV, x=x, y=yn)
+    gl = gm.train_forward(batch, 0)
+    gl.backward()
+    gsd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in gm.state_dict().items()}
+    rl = OM.gossip_loss(gsd, x, yn, batch.edge_index.numpy(), qemb.cpu(), 2)
+    rl.backward()
+    torch.testing.assert_close(gl.detach().cpu(), rl.detach(), rtol=1e-4, atol=1e-2)
+    worst = 0.0
+    for name, p in gm.named_parameters():
+        ref = gsd[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:   # pre_mp (detached input) and anchor_mlp
+            continue
+        err = float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-8)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    print(f"[parity] families: gossip-model worst relative gradient error {worst:.3e}")
+
+
 def test_neighborhood_adam_steps_reduce_loss(setup):
     nm0, gm, qids, queries = setup
     nm, _ = make_models(seed=1)
