@@ -40,6 +40,26 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.check(rc, "gemm")
 
 
+def test_new_entry_points_validate_their_arguments():
+    """Round-3 entry points: bad arguments come back as DESCO_EINVAL with a message (no launch, no crash)."""
+    L = _lib.lib()
+    cp = np.zeros(1, np.int32)
+    vr = np.zeros(1, np.int32)
+    assert L.desco_partition_degree_sort(None, 0, vr.ctypes.data, None, None, None, vr.ctypes.data, None, 0) == -1
+    assert b"desco_partition_degree_sort" in L.desco_last_error()
+    assert L.desco_partition_degree_sort(cp.ctypes.data, -1, vr.ctypes.data, None, None, cp.ctypes.data,
+                                         vr.ctypes.data, None, 0) == -1
+    # an empty block is fine (no rows, no edges)
+    out = np.zeros(1, np.int32)
+    assert L.desco_partition_degree_sort(cp.ctypes.data, 0, vr.ctypes.data, None, None, cp.ctypes.data,
+                                         out.ctypes.data, None, 1) == 0 and out[0] == 0
+    assert L.desco_gossip_tile_order(None, 5, None, None) == -1
+    assert b"desco_gossip_tile_order" in L.desco_last_error()
+    assert L.desco_gossip_tile_order(None, 0, None, None) == 0          # nothing to do
+    assert L.desco_gossip_fused_f32(*([None] * 3), 7, 29, *([None] * 16), 0.0, None, None, None) == -1
+    assert b"desco_gossip_fused_f32" in L.desco_last_error()
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from desco_amd import ops
