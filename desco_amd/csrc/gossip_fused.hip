@@ -30,6 +30,8 @@
 // as 2 x 2 tiles of v_mfma_f32_16x16x32_bf16 (a lane then owns two nodes and 2 x 4 features).
 // The next item's CSR slice and scalar records are prefetched through registers in three stages
 // under the current item's GEMMs.  Algebra: DESIGN.md 4.2.
+#include <atomic>
+
 #include "common_device.hpp"
 
 namespace desco {
@@ -44,7 +46,7 @@ constexpr int PCAP = 1216;         // neighbour records prefetched (up to three 
 constexpr int ECAP = 1216;         // neighbour records staged per pass (aliases weight buffer 1: 20 B each)
 constexpr int CST = 832;           // u, d1, tp, b3 (64 each), b5, w7 (256 each), zp_q (64)
 constexpr size_t GOSSIP_LDS_BYTES = (size_t)2 * 3 * PLN * 2 + (size_t)2 * 3 * WPLN * 2 + GT * 16 +
-                                    132 * 4 + CST * 4 + 2 * GT * 4 + GT;
+                                    132 * 4 + CST * 4 + 2 * GT * 4 + GT + 16;
 static_assert(ECAP * 20 <= 3 * WPLN * 2, "neighbour staging must fit in one weight buffer");
 static_assert(GOSSIP_LDS_BYTES <= 160 * 1024, "gossip_fused: LDS budget exceeded");
 
@@ -73,6 +75,7 @@ struct GossipFusedArgs {
   float b7;
   float* out;               // [N,Q]
   const uint8_t* tperm;     // [tiles*128] phase-1 slot -> row of the tile (desco_gossip_tile_order), or null
+  unsigned long long* queue;  // {next ticket, finished blocks} of this launch (see gf_queue)
 };
 
 // scalars pre-pass: one wave per node, lane = query
@@ -297,6 +300,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define GF_RELU(v_) ((v_) > 0.f ? (v_) : 0.f)
 #define GF_LEAKY01(v_) ((v_) > 0.f ? (v_) : 0.1f * (v_))
 
+// Work queue: a block's first item is its block index, every further one a ticket (grid + atomicAdd(queue[0], 1)): the
+// static map "item += grid" let the slowest block finish 2-5 % after the mean (profiles/r3_i_tail_probe_*.log).  The
+// counters are self-cleaning -- the block that finishes last zeroes them -- so a launch needs no memset and a captured
+// launch can be replayed; launches take the 64 slots in turn (at most 64 launches in flight per device).
+constexpr int GF_QSLOTS = 64;
+__device__ unsigned long long gf_queue[GF_QSLOTS][2];
 #ifdef GF_TAIL      // tail probe (tools/debug): per block its start and end, 100 MHz ticks
 __device__ unsigned long long gf_tail[1024][2];
 #endif
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   float* cst = reinterpret_cast<float*>(rp + 132);            // bias vectors (see CST)
   float* red = cst + CST;                                     // [2][128] head partials
   uint8_t* tperm = reinterpret_cast<uint8_t*>(red + 2 * GT);  // [128] phase-1 slot -> row
+  unsigned long long* tick = reinterpret_cast<unsigned long long*>(tperm + GT);   // the item after the current one
   int* ecol = reinterpret_cast<int*>(WB1);                    // [ECAP]
   float4* escal = reinterpret_cast<float4*>(ecol + ECAP);     // [ECAP]
 
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     if (tid + 2 * GNT < n_cnt) n_scal3 = g.scal[(int64_t)n_col3 * Q + (int)((it_) % Q)];     \
   }
 
+  if (tid == 0) *tick = gridDim.x + atomicAdd(g.queue, 1ull);
   GF_STAGE1(item)
   GF_STAGE2()
   GF_STAGE3(item)
@@ -411,10 +422,12 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     const int cnt0 = n_cnt;
     const int64_t n0 = (item / Q) * GT;
     const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
-    const int64_t next = item + gridDim.x;
-    const bool has_next = next < nitems;
     GF_WSTORE(WB0)                         // block 0 (W1, k 0..63: multiplies hh)
     __syncthreads();
+    const int64_t next = (int64_t)*tick;   // (written before the previous barrier)
+    const bool has_next = next < nitems;
+    unsigned long long tk = 0;             // ticket of the item after `next`: in flight until the end of this item
+    if (tid == 0 && has_next) tk = gridDim.x + atomicAdd(g.queue, 1ull);
     if (has_next) GF_STAGE1(next)
     GF_WLOAD(g.w1s, 64, 128, 0, 64)        // block 1 in flight while the tile is being assembled
 
@@ -576,7 +589,12 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     if (tid < nrows) g.out[(n0 + tid) * Q + q] = red[tid] + red[GT + tid] + g.b7 + srow[tid].w;
     if (!has_next) break;
     item = next;
+    if (tid == 0) *tick = tk;
     __syncthreads();            // srow / rp / red / weight buffers are free again
+  }
+  if (tid == 0 && atomicAdd(g.queue + 1, 1ull) == gridDim.x - 1) {      // last block out: leave the slot clean
+    g.queue[0] = 0;
+    g.queue[1] = 0;
   }
 #ifdef GF_TAIL
   if (threadIdx.x == 0) gf_tail[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memrealtime();
@@ -655,7 +673,14 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
                     zp, r, t, u, tp, d1,
                     reinterpret_cast<const short*>(w1_planes), reinterpret_cast<const short*>(wp_planes),
                     reinterpret_cast<const short*>(w3_planes), b3,
-                    reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out, tile_perm};
+                    reinterpret_cast<const short*>(w5_planes), b5, w7, b7, out, tile_perm, nullptr};
+  {
+    static std::atomic<unsigned> seq{0};
+    unsigned long long* base = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(desco::gf_queue));
+    if (e != hipSuccess || !base) return fail((int)e, "desco_gossip_fused_f32: no work-queue symbol");
+    a.queue = base + 2 * (seq.fetch_add(1) % GF_QSLOTS);
+  }
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_fused_kernel),
