@@ -590,7 +590,12 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     if (!has_next) break;
     item = next;
     if (tid == 0) *tick = tk;
-    __syncthreads();            // srow / rp / red / weight buffers are free again
+    // No barrier here: what the next item's publish overwrites is either read by the SAME thread above (srow[tid]) or was
+    // last read before the barrier in front of block 8 (rp, tperm, the staging area in WB1, zp_q) or before the one above
+    // (WB0: block 8); red is not written again before ten more barriers, and the ticket is read behind the next one.
+#ifdef GF_END_BARRIER
+    __syncthreads();
+#endif
   }
   if (tid == 0 && atomicAdd(g.queue + 1, 1ull) == gridDim.x - 1) {      // last block out: leave the slot clean
     g.queue[0] = 0;
