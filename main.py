@@ -230,6 +230,8 @@ if __name__ == "__main__":
                         help="matrix-product precision of the training steps (bf16: BASELINE config 3)")
     parser.add_argument("--graph_capture", action="store_true",
                         help="replay each neighborhood training batch's step from a hipGraph after epoch 0")
+    parser.add_argument("--seed", type=int, default=None,
+                        help="seed of the model initialisation and the batch order (the reference seeds neither: runs differ)")
     args = parser.parse_args()
     gpus = args.gpu if isinstance(args.gpu, list) else [args.gpu]
     if len(gpus) > 1 and "WORLD_SIZE" not in os.environ:
@@ -239,6 +241,13 @@ if __name__ == "__main__":
         from desco_amd import distributed as D
         sys.exit(D.launch([os.path.abspath(__file__)] + sys.argv[1:], len(gpus), devices=gpus))
     print(args)
+    if args.seed is not None:
+        import random as _random
+        import numpy as _np
+        import torch as _torch
+        _random.seed(args.seed)
+        _np.random.seed(args.seed)
+        _torch.manual_seed(args.seed)
     args_neighborhood, args_gossip, args_opt = split_namespaces(args)
     args_opt.precision = args.precision          # this build's flags (not in the reference's groups)
     args_opt.graph_capture = args.graph_capture
