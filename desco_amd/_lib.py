@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_resident.sh)
 LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -53,6 +53,10 @@ SIGNATURES = {
     "desco_gemm_bf16_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
                                       vp, i64, i64, vp]),
     "desco_round_bf16_f32": (c_int, [vp, i64, vp, vp]),
+    "desco_gemm_f16x3_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, f32,
+                                     vp, i64, i64, vp, vp]),
+    "desco_row_scale_f16": (c_int, [vp, i64, i32, vp, i64, i32, i64, vp, vp]),
+    "desco_split_f16x2_f32": (c_int, [vp, i64, vp, vp, vp]),
     "desco_segment_sum_f32": (c_int, [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
     "desco_segment_sum_layers_f32": (c_int, [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
     "desco_count_head_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, f32, i32, vp, i64, i64, i32, vp]),
@@ -69,6 +73,8 @@ SIGNATURES = {
     "desco_segment_ids": (c_int, [vp, i64, vp, vp]),
     "desco_gossip_fused_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 16 + [f32, vp, vp, vp]),
     "desco_gossip_tile_order": (c_int, [vp, i64, vp, vp]),
+    "desco_gossip_f16_stream": (c_int, [vp, vp, vp, vp, vp, vp]),
+    "desco_gossip_fused_f16x3_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 14 + [f32, vp, vp, vp, vp]),
     "desco_csr_gather_sum_add_f32": (c_int, [vp, i64, vp, vp, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]),
     "desco_add_rows_f32": (c_int, [vp, i64, vp, i64, i64, i32, vp]),

@@ -269,6 +269,16 @@ class GossipBatch:
         self.x = None if x is None else x.to(device).float().contiguous()
         self.y = None if y is None else y.to(device)
         self._tile_perm = None
+        self._work_queue = None
+
+    @property
+    def work_queue(self):
+        """Two zeroed int64 words: the work-item tickets of this batch's fused gossip launches (the kernel leaves
+        them zero).  One per batch object: launches of one batch are stream-ordered; batches that run concurrently
+        (other streams, other graph replays) each have their own."""
+        if self._work_queue is None:
+            self._work_queue = torch.zeros(2, dtype=torch.int64, device=self.device)
+        return self._work_queue
 
     @property
     def tile_perm(self):

@@ -55,6 +55,33 @@ __device__ __forceinline__ uint32_t pack2_bf16_rne(const float f0, const float f
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, desco_bf2));
 }
 
+// ---- fp16 hi/lo split ("f16x3": three products hi*hi + hi*lo + lo*hi on v_mfma_f32_*_f16) -----------------------
+// x (already multiplied by a power-of-two scale that puts the largest element of its row / tile into [2^14, 2^15))
+// = hi + lo with hi = fp16_rne(x) and lo = fp16_rne(x - hi): 22 significand bits for every element within 2^-17 of
+// the maximum, an absolute error of 2^-40 of the maximum below that (lo goes subnormal and then to zero: gradual; the
+// MFMA honours fp16 subnormals, tools/micro/f16x3_probe.hip).  Three VALU per pair: v_cvt_pk_f16_f32 for the hi pair,
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 for the two residuals.  Packed as (f0 | f1 << 16) per plane.
+typedef _Float16 desco_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_f16x2(const float f0, const float f1, uint32_t& hi, uint32_t& lo) {
+  const desco_f2 f = {f0, f1};
+  const desco_h2 h = __builtin_convertvector(f, desco_h2);
+  const desco_h2 l = {(_Float16)(f0 - (float)h.x), (_Float16)(f1 - (float)h.y)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// the power of two s with s * mx in [2^14, 2^15) (mx >= 0; 1 for mx == 0): exponent bits only, no rounding anywhere.
+// mx = 1.m * 2^(eb-127)  ->  s = 2^(141 - eb)  (biased 268 - eb, clamped to a normal number)
+__device__ __forceinline__ float f16_scale_for(const float mx) {
+  const int eb = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  int sb = 268 - eb;
+  sb = sb > 253 ? 253 : sb;
+  return mx > 0.f ? __uint_as_float((uint32_t)sb << 23) : 1.f;
+}
+// 1 / s for a power of two s (exact)
+__device__ __forceinline__ float pow2_inverse(const float s) {
+  return __uint_as_float((254u << 23) - (__float_as_uint(s) & 0x7f800000u));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

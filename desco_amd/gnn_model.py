@@ -29,9 +29,16 @@ H = 64
 FUSED_SHMP_LAYER = True
 # scalars pre-pass + one on-chip kernel for the whole gossip network (False: 7 launches via HBM)
 FUSED_GOSSIP = True
+# the fused gossip pass in the three-product fp16 form (csrc/gossip_f16.hip); False: the six-product bf16 kernel
+# (csrc/gossip_fused.hip), kept as its cross-check
+GOSSIP_F16X3 = os.environ.get("DESCO_GOSSIP_F16X3", "1") != "0"
 # inference GEMMs (anchor, post MLP, head, canonical table) on the bf16 matrix pipe with fp32-level
 # accuracy (bf16x6 split, csrc/gemm_split.hip); False: v_mfma_f32_32x32x2_f32 (gemm_f32.hip)
 GEMM_BF16X6 = True
+# the large inference GEMM (anchor MLP) in the THREE-product fp16 hi/lo form (csrc/gemm_f16x3.hip): half the MFMAs and
+# two operand planes instead of three, power-of-two scales per weight matrix and per activation row; measured error
+# below the f32 MFMA's (tests/test_kernels_gpu.py::test_gemm_f16x3_is_fp32_accurate).  Needs GEMM_BF16X6.
+GEMM_F16X3 = os.environ.get("DESCO_GEMM_F16X3", "1") != "0"
 # True: the fused SHMP layer's MFMA blocks also run as the bf16x6 split (csrc/shmp_layer.hip, K <= 192)
 SHMP_BF16X6 = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
@@ -358,7 +365,8 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     if not (bf16_planes and GEMM_BF16X6):
         return pk
     # n-major ([out, in]) pre-split operands of the bf16x6 GEMM
-    pk["anchor_nk"] = (ops.split_bf16_planes(gnn.anchor_mlp[0].weight), gnn.anchor_mlp[0].bias.contiguous())
+    _split = ops.split_f16_planes if GEMM_F16X3 else ops.split_bf16_planes
+    pk["anchor_nk"] = (_split(gnn.anchor_mlp[0].weight), gnn.anchor_mlp[0].bias.contiguous())
     # (64-input layers run on the streaming row-wise kernel: planes per 64-column output block)
     pk["post_nk"] = [((ops.linear64_planes(gnn.post_mp[i].weight) if gnn.post_mp[i].in_features == 64
                        else ops.split_bf16_planes(gnn.post_mp[i].weight)),
@@ -383,6 +391,11 @@ def _post_mp(pk, pooled):
     return ops.gemm(h, w7, b7)
 
 
+def _gemm_planes(a, w, b, **kw):
+    """A GEMM on pre-split weight planes: f16x3 (ops.F16Planes) or bf16x6 (int16 [3, n, k])."""
+    return (ops.gemm_f16x3 if isinstance(w, ops.F16Planes) else ops.gemm_split)(a, w, b, **kw)
+
+
 def _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev):
     """[S+1, 64] coefficients of the closed-form first layer for destination type ``t`` (folded once per
     weight version): rows s < su = x0_src(s) W_s, unused slots zero, last row = x0_t W_self + bias."""
@@ -405,8 +418,9 @@ def _anchor_const_input(pk, gnn, canon):
     if "anchor_nk_const" not in pk:
         w, b = gnn.anchor_mlp[0].weight, gnn.anchor_mlp[0].bias
         x0 = pk["pre"]["canonical"][1]
-        pk["anchor_nk_const"] = (ops.split_bf16_planes(w[:, H:].contiguous()), (b + w[:, :H] @ x0).contiguous())
-    return ops.gemm_split(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1)
+        _split = ops.split_f16_planes if GEMM_F16X3 else ops.split_bf16_planes
+        pk["anchor_nk_const"] = (_split(w[:, H:].contiguous()), (b + w[:, :H] @ x0).contiguous())
+    return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1)
 
 
 def _resident_operands(pk, core, dev):
@@ -571,7 +585,7 @@ def _shmp_pooled(gnn: BaseGNN, batch, allow_resident: bool = True) -> torch.Tens
         if GEMM_BF16X6 and const_input and direct_canon and first == 1:
             anch = _anchor_const_input(pk, gnn, canon)
         elif GEMM_BF16X6:
-            anch = ops.gemm_split(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
+            anch = _gemm_planes(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
         else:
             anch = ops.gemm(canon, aw, ab, act=ops.ACT_LEAKY, slope=0.1)   # :69-73
         seg_ptr = batch.count_ptr
@@ -726,6 +740,9 @@ def pack_gossip(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     if bf16_planes:     # bf16 planes (hi, mid, lo) of the n-major matrices: the fused kernel's operands
         for k in ("fused_w1", "fused_wp", "fused_w3", "fused_w5"):
             pk[k + "s"] = ops.split_bf16_planes(pk[k])
+        # ... and the fp16 (hi, lo) weight stream of the three-product kernel
+        pk["wstream"], pk["winv"] = ops.gossip_f16_stream(*[ops.split_f16_planes(pk[k]) for k in
+                                                            ("fused_w1", "fused_wp", "fused_w3", "fused_w5")])
     pk["qcache"] = None
     return pk
 
@@ -781,8 +798,13 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
                  # the fused kernel takes n-major ([out, in]) weight blocks
                  "w1s": pk["fused_w1s"], "wps": pk["fused_wps"], "w3s": pk["fused_w3s"], "b3": b3,
                  "w5s": pk["fused_w5s"], "b5": b5, "w7": pk["w7"], "b7": pk["b7"]}
-            outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v,
-                                         tile_perm=batch.tile_perm if GOSSIP_TILE_ORDER else None))
+            tperm = batch.tile_perm if GOSSIP_TILE_ORDER else None
+            if GOSSIP_F16X3:
+                v["wstream"], v["winv"] = pk["wstream"], pk["winv"]
+                outs.append(ops.gossip_fused_f16(scal4, batch.rowptr, batch.col, N, q1 - q0, v, batch.work_queue,
+                                                 tile_perm=tperm))
+            else:
+                outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v, tile_perm=tperm))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     h1, scal = ops.gossip_layer0(x, batch.rowptr, batch.col, q["g0"], q["g1"], q["p"], q["r"],
                                  q["t"], q["z"])                                  # layer 0

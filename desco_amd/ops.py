@@ -472,6 +472,77 @@ def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+class F16Planes:
+    """Weight operand of the f16x3 kernels: (hi, lo) fp16 planes [2, *w.shape] of scale * w and the device pair
+    {scale, 1/scale} (one power of two per matrix), made once per weight version by ``split_f16_planes``."""
+    __slots__ = ("planes", "scale")
+
+    def __init__(self, planes, scale):
+        self.planes, self.scale = planes, scale
+
+    @property
+    def shape(self):
+        return self.planes.shape
+
+
+def split_f16_planes(w: torch.Tensor) -> F16Planes:
+    w = w.contiguous()
+    planes = torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.int16)
+    scale = torch.empty((2,), device=w.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.desco_split_f16x2_f32(_dev(w, "w"), w.numel(), _dev(planes, "planes", torch.int16),
+                                       _dev(scale, "scale"), _stream()), "split_f16x2")
+    return F16Planes(planes, scale)
+
+
+def row_scale_f16(a1: torch.Tensor, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[m] powers of two s_i with s_i * max_k |[a1 | a2][i, k]| in [2^14, 2^15) (1 for an all-zero row)."""
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    out = torch.empty((m,), device=a1.device, dtype=torch.float32)
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    with _Timed("row_scale_kernel", 0.0, 4.0 * m * (k1 + k2 + 1)):
+        _lib.check(_lib.lib().desco_row_scale_f16(a1p, lda1, k1, a2p, lda2, k2, m, _dev(out, "row_scale"),
+                                                  _stream()), "row_scale_f16")
+    return out
+
+
+def gemm_f16x3(a1: torch.Tensor, w, bias: Optional[torch.Tensor] = None,
+               a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
+               out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act([a1 | a2] @ w.T + bias) with fp32-level accuracy on the fp16 matrix pipe in three products
+    (csrc/gemm_f16x3.hip).  ``w``: ``split_f16_planes(weight)`` of torch's [n, k1+k2] weight (a float weight is
+    split on the fly, for tests); ``row_scale``: ``row_scale_f16(a1, a2)`` when the caller already has it."""
+    if not isinstance(w, F16Planes):
+        w = split_f16_planes(w)
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = w.planes.shape[1]
+    assert w.planes.dim() == 3 and w.planes.shape[0] == 2 and w.planes.shape[2] == k1 + k2
+    if out is None:
+        out = torch.empty((m, n), device=a1.device, dtype=torch.float32)
+    if m == 0:
+        return out
+    if row_scale is None:
+        row_scale = row_scale_f16(a1, a2)
+    a1p, lda1 = _rows(a1, "a1")
+    a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
+    op, ldo = _rows(out, "out")
+    bias_rows = 1
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_rows = 1 if bias.dim() == 1 else bias.shape[0]
+    L = _lib.lib()
+    kk = k1 + k2
+    with _Timed("gemm_f16x3_kernel", 2.0 * m * kk * n, 4.0 * (m * kk + kk * n + m * n), (m, kk, n)):
+        _lib.check(L.desco_gemm_f16x3_f32(a1p, lda1, k1, a2p, lda2, k2, _dev(w.planes, "w", torch.int16),
+                                          _dev(w.scale, "w_scale"), n, _opt(bias, "bias"), bias_rows, None, 0,
+                                          None, act, slope, op, ldo, m, _dev(row_scale, "row_scale"), _stream()),
+                   "gemm_f16x3")
+    return out
+
+
 def vcsr_transpose_sym(vrowptr: torch.Tensor, vcol: torch.Tensor, num_rows: int, slots: int,
                        num_count: Optional[int] = None):
     """(t_rowptr [num_rows+1], t_col [E]): the backward gather's index of a symmetric virtual-row
@@ -703,6 +774,48 @@ def gossip_fused(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, nu
                                             None if tile_perm is None else _dev(tile_perm, "tile_perm", torch.uint8),
                                             _stream()),
                    "gossip_fused")
+    return out
+
+
+def gossip_f16_stream(w1: F16Planes, wp: F16Planes, w3: F16Planes, w5: F16Planes):
+    """(wstream int16 [9, 2, 4096], winv float32 [4]): the nine 64x64 weight blocks of the fp16 gossip kernel in its
+    LDS image order (k slots of the register-fed blocks permuted, desco_gossip_f16_stream) and 1/scale per matrix."""
+    for name, w, shape in (("w1", w1, (2, 64, 128)), ("wp", wp, (2, 64, 128)), ("w3", w3, (2, 64, 64)),
+                           ("w5", w5, (2, 256, 64))):
+        if tuple(w.planes.shape) != shape:
+            raise ValueError(f"gossip_f16_stream: {name} planes must be {shape}, got {tuple(w.planes.shape)}")
+    stream = torch.empty((9, 2, 4096), device=w1.planes.device, dtype=torch.int16)
+    _lib.check(_lib.lib().desco_gossip_f16_stream(*[_dev(w.planes, "planes", torch.int16) for w in (w1, wp, w3, w5)],
+                                                  _dev(stream, "wstream", torch.int16), _stream()), "gossip_f16_stream")
+    winv = torch.stack([w.scale[1] for w in (w1, wp, w3, w5)]).contiguous()
+    return stream, winv
+
+
+def gossip_fused_f16(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
+                     num_q: int, v: dict, queue: torch.Tensor, tile_perm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One on-chip pass per (128-node tile, query) in the three-product fp16 form (csrc/gossip_f16.hip): returns
+    pred [N, Q].  ``queue``: two zeroed int64 words (see desco_hip.h)."""
+    out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
+    if tile_perm is not None and tile_perm.numel() < ((num_nodes + 127) // 128) * 128:
+        raise ValueError("gossip_fused_f16: tile_perm is shorter than the tiles of this batch")
+    if queue.dtype != torch.int64 or queue.numel() < 2:
+        raise ValueError("gossip_fused_f16: queue must hold two int64 words")
+    L = _lib.lib()
+    names = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "wstream", "winv", "b3", "b5", "w7")
+    ptrs = []
+    for n in names:
+        if not v[n].is_contiguous():
+            raise ValueError(f"gossip_fused_f16: operand {n} must be contiguous")
+        ptrs.append(_dev(v[n], n, torch.int16 if n == "wstream" else torch.float32))
+    rows = float(num_nodes) * num_q
+    with _Timed("gossip_fused_f16_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
+                rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
+        _lib.check(L.desco_gossip_fused_f16x3_f32(_dev(scal, "scal"), _dev(rowptr, "rowptr", torch.int32),
+                                                  _dev(col, "col", torch.int32), num_nodes, num_q, *ptrs,
+                                                  float(v["b7"]), _dev(out, "out"),
+                                                  None if tile_perm is None else _dev(tile_perm, "tile_perm", torch.uint8),
+                                                  _dev(queue, "queue", torch.int64), _stream()),
+                   "gossip_fused_f16")
     return out
 
 

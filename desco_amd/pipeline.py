@@ -168,6 +168,7 @@ class InferencePipeline:
             n0, n1 = int(self.graphs.graph_ptr[g0]), int(self.graphs.graph_ptr[g1])
             self.gossip_batches.append((n0, n1, GossipBatch(self.graphs.subset(g0, g1), self.device)))
             self.gossip_batches[-1][2].tile_perm        # built here, outside any stream capture
+            self.gossip_batches[-1][2].work_queue
         self.num_queries = Q
 
     # ---- hipGraph replay --------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DESCO_ABI_VERSION 3
+#define DESCO_ABI_VERSION 4
 #define DESCO_H 64
 
 #define DESCO_EINVAL (-1)
@@ -189,6 +189,23 @@ int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2
                           const float* s, int ns, const float* ws, int act, float slope, float* c,
                           int64_t ldc, int64_t m, desco_stream_t stream);
 int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco_stream_t stream);
+
+/* Same contract as desco_gemm_f32 on the fp16 matrix pipe with fp32-level accuracy in THREE products ("f16x3",
+ * csrc/gemm_f16x3.hip): operands are scaled by powers of two and split into two fp16 terms (hi = rne(s x),
+ * lo = rne(s x - hi): 22 significand bits); hi*hi + hi*lo + lo*hi accumulate in fp32 and the scales are undone in
+ * the epilogue (exact).  Measured error <= the f32 MFMA's (tools/micro/f16x3_probe.hip).
+ *   w_planes[2][n][k1+k2]: (hi, lo) fp16 bit patterns of scale * W, N-MAJOR, and w_scale[2] = {scale, 1/scale} on
+ *     the DEVICE, both produced once per weight version by desco_split_f16x2_f32 (one power of two per matrix:
+ *     largest |w| -> [2^14, 2^15));
+ *   row_scale[m]: one power of two per row of [A1 | A2] (largest |a| of the row -> [2^14, 2^15)), produced by
+ *     desco_row_scale_f16 on the same operands (or by the kernel that wrote A). */
+int desco_gemm_f16x3_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+                         const int16_t* w_planes, const float* w_scale, int n, const float* bias,
+                         int bias_rows, const float* s, int ns, const float* ws, int act, float slope,
+                         float* c, int64_t ldc, int64_t m, const float* row_scale, desco_stream_t stream);
+int desco_row_scale_f16(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+                        int64_t m, float* row_scale, desco_stream_t stream);
+int desco_split_f16x2_f32(const float* w, int64_t count, int16_t* planes, float* scale, desco_stream_t stream);
 
 /* bf16 training mode (BASELINE config 3): the same GEMM contract with ONE bf16 product per
  * multiply-add -- A is rounded to nearest-even bf16 inside the kernel, the N-MAJOR weight arrives
@@ -394,6 +411,22 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
                            const int16_t* w3_planes, const float* b3, const int16_t* w5_planes,
                            const float* b5, const float* w7, float b7, float* out,
                            const uint8_t* tile_perm, desco_stream_t stream);
+/* The same fused gossip pass in the THREE-product fp16 form (csrc/gossip_f16.hip; the product path since round 4):
+ * per-node power-of-two scales carry the range, a wave owns 16 nodes x all features so that h2, y1, y2 stay in
+ * registers between the GEMMs, weight blocks stream through a ring of four LDS buffers (5 barriers per item).
+ *   wstream [9][2][4096] fp16 + winv[4]: desco_gossip_f16_stream of the four desco_split_f16x2_f32 plane sets
+ *     (w1, wp [2][64][128]; w3 [2][64][64]; w5 [2][256][64]) and the 1/scale of each matrix, in that order;
+ *   queue: two zeroed 64-bit words owned by the caller (work-item tickets of this launch; the kernel leaves them
+ *     zero).  Launches that may run CONCURRENTLY (other streams, graph replays) need queues of their own; launches
+ *     on one stream can share one. */
+int desco_gossip_f16_stream(const int16_t* w1_planes, const int16_t* wp_planes, const int16_t* w3_planes,
+                            const int16_t* w5_planes, int16_t* wstream, desco_stream_t stream);
+int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
+                                 int64_t num_nodes, int num_q, const float* g1, const float* p,
+                                 const float* z, const float* zp, const float* r, const float* t,
+                                 const float* u, const float* tp, const float* d1, const int16_t* wstream,
+                                 const float* winv, const float* b3, const float* b5, const float* w7, float b7,
+                                 float* out, const uint8_t* tile_perm, uint64_t* queue, desco_stream_t stream);
 /* tile_perm (optional, 4-byte aligned, [ceil(num_nodes/128)*128] bytes from desco_gossip_tile_order): the order in
  * which the 8 waves of a block walk the rows of a 128-node tile in the neighbour-sum phase -- rows sorted by degree,
  * paired, pairs dealt to the waves in snake order (a half wave per row, the two halves of a wave in lock step, a block

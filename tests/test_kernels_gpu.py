@@ -434,3 +434,81 @@ def test_gemm_bf16x6_is_fp32_accurate(m, k1, k2, n):
     scale = ref.abs().max().item()
     print(f"[accuracy] m={m} k={k1}+{k2} n={n}: bf16x6 err {e_split:.2e}  f32-MFMA err {e_f32:.2e}  scale {scale:.1f}")
     assert e_split <= max(4 * e_f32, 2e-6 * scale)
+
+
+# ---- fp16 hi/lo three-product GEMM (csrc/gemm_f16x3.hip) ------------------------------------------------------------
+def _f16x3_case(m, k1, k2, n, row_mag, seed):
+    g = torch.Generator().manual_seed(seed)
+    a1 = torch.randn(m, k1, generator=g) * row_mag(m, g)
+    a2 = torch.randn(m, k2, generator=g) * row_mag(m, g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    bias = torch.randn(n, generator=g)
+    return a1, a2, w, bias
+
+
+def _f16x3_errors(a1, a2, w, bias):
+    A = a1 if a2 is None else torch.cat([a1, a2], 1)
+    lin = A.double() @ w.double().T
+    ref = torch.nn.functional.leaky_relu(lin + bias.double(), 0.1)
+    mag = A.double().abs() @ w.double().abs().T + bias.double().abs()      # the scale rounding errors live on
+    dev = lambda t: None if t is None else t.to(DEV)                     # noqa: E731
+    got = ops.gemm_f16x3(dev(a1), dev(w), dev(bias), a2=dev(a2), act=ops.ACT_LEAKY, slope=0.1)
+    f32 = ops.gemm(dev(a1), dev(w.t().contiguous()), dev(bias), a2=dev(a2), act=ops.ACT_LEAKY, slope=0.1)
+    x6 = ops.gemm_split(dev(a1), dev(w), dev(bias), a2=dev(a2), act=ops.ACT_LEAKY, slope=0.1)
+    rel = lambda t: ((t.cpu().double() - ref).abs() / mag.clamp_min(1e-300)).max().item()   # noqa: E731
+    return rel(got), rel(f32), rel(x6)
+
+
+@pytest.mark.parametrize("m,k1,k2,n", [(300, 576, 0, 576), (1000, 512, 0, 576), (257, 64, 64, 64), (129, 64, 0, 256),
+                                       (64, 32, 32, 128), (5, 96, 0, 192)])
+def test_gemm_f16x3_is_fp32_accurate(m, k1, k2, n):
+    """the three-product fp16 form must be as accurate as the f32 MFMA (error measured relative to
+    sum |a||w|, the scale fp32 rounding errors live on), on rows whose magnitudes span 30x."""
+    a1, a2, w, bias = _f16x3_case(m, k1, k2, n, lambda m_, g: torch.rand(m_, 1, generator=g) * 30, m + n)
+    e16, e32, e6 = _f16x3_errors(a1, a2, w, bias)
+    print(f"[accuracy] m={m} k={k1}+{k2} n={n}: f16x3 {e16:.2e}  f32-MFMA {e32:.2e}  bf16x6 {e6:.2e} (max err / sum|a||w|)")
+    assert e16 <= 2.0 * e32
+
+
+@pytest.mark.parametrize("kind", ["1e5", "1e-4", "rows_2^+-20", "inrow_2^-20", "zero_rows", "fp16_overflow_edge"])
+def test_gemm_f16x3_range(kind):
+    """fp16 has a 5-bit exponent: the per-row power-of-two scale must carry activations of any magnitude (the
+    range guard VERDICT r3 asks for is a scale here, not a fallback), tiny rows must not fall into the subnormal
+    hole, and an all-zero row must stay zero."""
+    m, k, n = 384, 128, 64
+    g = torch.Generator().manual_seed(7)
+    mags = {
+        "1e5": lambda m_, g_: torch.full((m_, 1), 1e5),
+        "1e-4": lambda m_, g_: torch.full((m_, 1), 1e-4),
+        "rows_2^+-20": lambda m_, g_: 2.0 ** torch.randint(-20, 21, (m_, 1), generator=g_).float(),
+        "inrow_2^-20": lambda m_, g_: torch.ones(m_, 1),
+        "zero_rows": lambda m_, g_: (torch.rand(m_, 1, generator=g_) > 0.5).float(),
+        "fp16_overflow_edge": lambda m_, g_: torch.full((m_, 1), 65504.0 * 3),
+    }
+    a1, a2, w, bias = _f16x3_case(m, k, 0, n, mags[kind], 11)
+    if kind == "inrow_2^-20":          # half of every row is 2^-20 of the other half
+        a1[:, ::2] *= 2.0 ** -20
+    e16, e32, e6 = _f16x3_errors(a1, a2, w, bias * 0)
+    print(f"[range] {kind}: f16x3 {e16:.2e}  f32-MFMA {e32:.2e}  bf16x6 {e6:.2e} (max err / sum|a||w|)")
+    assert e16 <= 2.0 * e32 + 1e-30
+    if kind == "zero_rows":
+        got = ops.gemm_f16x3(a1.to(DEV), w.to(DEV))
+        zero = (a1.abs().sum(1) == 0)
+        assert zero.any() and torch.all(got.cpu()[zero] == 0)
+
+
+def test_gemm_f16x3_weight_scale_and_planes():
+    """The planes are (hi, lo) of scale * w with ONE power of two per matrix; hi + lo reproduces the scaled weight
+    to 2^-22 and tiny weights next to large ones degrade gradually (subnormal lo), never to garbage."""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 96, generator=g) * 0.05
+    w[0, 0] = 3.0            # one large element sets the scale
+    w[1, :8] = 1e-7          # far below it
+    P = ops.split_f16_planes(w.to(DEV))
+    scale = P.scale.cpu()
+    assert scale[0] * scale[1] == 1.0 and 2 ** 14 <= scale[0] * 3.0 < 2 ** 15
+    assert float(np.log2(scale[0].item())).is_integer()
+    planes = P.planes.cpu().view(torch.float16).double()
+    rec = (planes[0] + planes[1]) / scale[0].double()
+    err = (rec - w.double()).abs()
+    assert bool((err <= torch.clamp(2.0 ** -22 * w.double().abs(), min=2.0 ** -25 / scale[0].item())).all())

@@ -42,6 +42,16 @@ def case(m, k, n, check, tag):
         ref = torch.nn.functional.leaky_relu(a[rows].double() @ wt.double() + b.double(), 0.1)
         msg += f" maxdiff {(out[rows].double() - ref).abs().max().item():.2e}"
     print(msg, flush=True)
+    # the three-product fp16 form (csrc/gemm_f16x3.hip): row-scale pre-pass + GEMM, and the GEMM alone
+    w16 = ops.split_f16_planes(wt.t().contiguous())
+    rs = ops.row_scale_f16(a)
+    ms_rs = timeit(lambda: ops.row_scale_f16(a))
+    ms16 = timeit(lambda: ops.gemm_f16x3(a, w16, b, act=ops.ACT_LEAKY, slope=0.1, out=out, row_scale=rs))
+    msg = (f"{tag} m={m} k={k} n={n}: f16x3 {ms16:.3f} ms + row scale {ms_rs:.3f} ms = {fl / (ms16 + ms_rs) / 1e9:.1f} TF/s "
+           f"fp32-equivalent ({3 * fl / ms16 / 1e9 / 2500:.3f} of 2.5 PF x3 for the GEMM alone)")
+    if check:
+        msg += f" maxdiff {(out[rows].double() - ref).abs().max().item():.2e}"
+    print(msg, flush=True)
 
 
 def main():
