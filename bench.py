@@ -43,6 +43,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (same guid
 # fp32-accurate kernels on the bf16 pipe ("bf16x6"): every algorithmic fp32 multiply-add is six bf16
 # MFMA products, so the speed of light of the ALGORITHM is the bf16 peak / 6 in fp32-equivalent flops
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# ... and on the fp16 pipe in THREE products ("f16x3", round 4: hi/lo fp16 split with power-of-two scales; the fp16
+# MFMA runs at the bf16 rate): the algorithm's speed of light is the fp16 peak / 3
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
 
 def gather_kernel() -> str:
@@ -56,6 +59,8 @@ def mfma_peak(kernel: str):
     """(peak TFLOP/s in algorithmic fp32 flops, pipe) for an MFMA-bound kernel, else None."""
     if kernel == "gemm_f32_kernel" or kernel.endswith(",f32>"):
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
+    if kernel in ("gemm_f16x3_kernel", "gossip_fused_f16_kernel") or kernel.endswith(",f16x3>"):
+        return PEAK_X3_TFLOPS, "fp16 MFMA x 3 products (f16x3, fp32-accurate)"
     if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>") or \
             kernel.startswith("shmp_layer16_kernel<"):
         return PEAK_X6_TFLOPS, "bf16 MFMA x 6 products (bf16x6, fp32-accurate)"
@@ -134,7 +139,7 @@ def host_cpu_info():
     return model, phys, logical
 
 
-def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0):
+def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0, workers=None):
     """The CPU oracle in the reference's form on a bounded sample of the same workload, on
     PRE-BUILT batches (canonical partition, triangle split and collate excluded, as on the GPU
     side -- SURVEY 8d), timed with k = 1 thread and with k = all physical cores."""
@@ -162,7 +167,21 @@ def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0):
         runs[k] = n / (time.perf_counter() - t0)
     best_k = max(runs, key=runs.get)
     torch.set_num_threads(max(1, min(8, phys)))
-    return {"value": runs[best_k], "unit": "graphs/s", "cores": best_k, "kind": "port",
+    value, cores, pp = runs[best_k], best_k, None
+    if workers:
+        # the honest all-core figure (SURVEY 8d "k = all physical host cores"): intra-op threading of thousands of
+        # tiny torch ops only adds synchronisation, so P single-threaded processes take disjoint shards of a sample
+        # sized for ~target_seconds / 2 of wall time at the 1-thread rate per process
+        P = len(workers)
+        n_pp = int(max(2 * P, min(64 * len(graphs_host), 0.5 * target_seconds * runs[1] * P)))
+        sample_pp = [graphs_host[i % len(graphs_host)] for i in range(n_pp)]
+        rate, wall, slowest, fastest = cpu_baseline_processes(workers, sd_n, sd_g, sample_pp, queries)
+        pp = {"value": rate, "processes": P, "threads_per_process": 1, "graphs": n_pp, "wall_s": wall,
+              "slowest_worker_s": slowest, "fastest_worker_s": fastest}
+        if rate > value:
+            value, cores = rate, P
+    return {"value": value, "unit": "graphs/s", "cores": cores, "kind": "port",
+            "value_process_parallel": None if pp is None else pp["value"], "process_parallel": pp,
             "value_1_thread": runs[1], "value_all_physical_cores": runs[phys], "physical_cores": phys,
             "logical_cores": logical, "cpu_model": model,
             "sample": f"{n} graphs cycling over the synthetic set; reference-form model (per-edge-type "
@@ -170,7 +189,100 @@ def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0):
                       f"batches 512/256, torch fp32) on PRE-BUILT collated batches: the oracle's Python "
                       f"canonical partition + triangle split + collate ({t_prep:.1f} s for the sample) is "
                       f"excluded, as the partition build is excluded from the GPU's timed region; "
-                      f"value = best of k=1 ({runs[1]:.1f}) and k={phys} physical cores ({runs[phys]:.1f})"}, ref, n
+                      f"value = best of one process with k=1 ({runs[1]:.1f}) / k={phys} threads ({runs[phys]:.1f}) and "
+                      f"P single-threaded processes over disjoint graph shards "
+                      f"({'not run' if pp is None else '%d processes: %.1f' % (pp['processes'], pp['value'])})"}, ref, n
+
+
+# ---- process-parallel CPU baseline: P single-threaded worker processes over disjoint graph shards ------------------
+def cpu_worker_main():
+    """``bench.py --cpu-worker``: one single-threaded CPU-oracle worker.  Protocol on stdin / stdout:
+    ``job <path> <index> <count>`` -> loads the job, pre-builds its shard's batches, answers ``ready``;
+    ``go`` -> runs the reference-form model over the shard, answers ``done <seconds>``."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch
+    torch.set_num_threads(1)
+    from oracle import model as OM
+    pre = sd_n = sd_g = None
+    for line in sys.stdin:
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "job":
+            job = torch.load(tok[1], weights_only=False)
+            i, cnt = int(tok[2]), int(tok[3])
+            n = len(job["graphs"])
+            lo, hi = (n * i) // cnt, (n * (i + 1)) // cnt
+            sd_n, sd_g = job["sd_n"], job["sd_g"]
+            pre = OM.prebuild_reference_inputs(job["graphs"][lo:hi], job["queries"]) if hi > lo else None
+            print("ready", flush=True)
+        elif tok[0] == "go":
+            t0 = time.perf_counter()
+            if pre is not None:
+                OM.run_reference_prebuilt(sd_n, sd_g, pre, emulate_quirk=False)
+            print(f"done {time.perf_counter() - t0:.6f}", flush=True)
+        elif tok[0] == "quit":
+            break
+    return 0
+
+
+def start_cpu_workers():
+    """Start the worker processes of the process-parallel CPU baseline.  Called at the very top of main(), BEFORE this
+    process touches the GPU (fresh children, one python each).  P = physical cores, bounded by free memory (a torch
+    import is ~0.4 GB per process)."""
+    _, phys, _ = host_cpu_info()
+    P = phys
+    try:
+        with open("/proc/meminfo") as f:
+            avail_kb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0]
+        P = max(1, min(P, int((avail_kb / 1e6 - 24.0) / 0.6)))
+    except Exception:
+        P = min(P, 16)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker"], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT) for _ in range(P)]
+    return procs
+
+
+def stop_cpu_workers(procs):
+    for p in procs or []:
+        try:
+            p.stdin.write("quit\n")
+            p.stdin.flush()
+            p.stdin.close()
+        except Exception:
+            pass
+    for p in procs or []:
+        try:
+            p.wait(timeout=20)
+        except Exception:
+            p.kill()
+
+
+def cpu_baseline_processes(procs, sd_n, sd_g, sample, queries):
+    """graphs/s of P single-threaded workers over disjoint contiguous shards of ``sample`` (wall clock from the common
+    start signal to the last worker's answer; the pre-build of each shard's batches is outside, as everywhere)."""
+    import tempfile
+    import torch
+    P = len(procs)
+    fd, path = tempfile.mkstemp(suffix=".pt", prefix="desco_cpu_job_")
+    os.close(fd)
+    try:
+        torch.save({"sd_n": sd_n, "sd_g": sd_g, "graphs": sample, "queries": queries}, path)
+        for i, p in enumerate(procs):
+            p.stdin.write(f"job {path} {i} {P}\n")
+            p.stdin.flush()
+        for p in procs:
+            assert p.stdout.readline().strip() == "ready", "cpu worker failed to load its shard"
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        per = [float(p.stdout.readline().split()[1]) for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    return len(sample) / wall, wall, max(per), min(per)
 
 
 def train_leg(device, batch_size=512, stride=4, precision="fp32"):
@@ -297,28 +409,18 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     }
 
 
-def nccl_selftest(args):
-    """--selftest-nccl: the RCCL path without an 8-GPU node.  With >= 2 visible devices, two ranks (one per
-    GPU, backend "nccl") run ONE real neighborhood training step each on their half of a union batch with the
-    gradient buckets all-reduced asynchronously from the autograd hooks (desco_amd.distributed.GradBuckets) and
-    compare the result with the single-process gradient of the union batch; prints one JSON line.  Skips
-    cleanly (status "skipped") on a 1-device box.  Reference: main.py:242-255."""
+def nccl_gradient_check(device):
+    """One REAL neighborhood training step per rank on its (unequal) share of a union batch, the gradient buckets
+    all-reduced asynchronously from the autograd hooks (desco_amd.distributed.GradBuckets), compared with the
+    single-process gradient of the union batch.  Runs inside an initialised process group of any size; returns the
+    record every rank agrees on.  Reference: main.py:242-255 (Lightning's ddp strategy)."""
     import torch
     from desco_amd import distributed as D
-    ndev = torch.cuda.device_count()
-    if "WORLD_SIZE" not in os.environ:
-        if ndev < 2:
-            print(json.dumps({"selftest": "nccl", "status": "skipped", "reason": f"{ndev} visible device(s); needs 2"}))
-            return 0
-        return D.launch([os.path.abspath(__file__), "--selftest-nccl"], 2, devices=[0, 1], timeout=600)
-    rank, world, _ = D.env_world()
-    device = D.local_device()
-    D.init_from_env(device, backend="nccl")
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from desco_amd import synthetic
     from desco_amd.batch import NeighborhoodBatch
     from desco_amd.data import STANDARD_QUERY_IDS
     from desco_amd.partition import build_partition
+    rank, world = D.rank(), D.world_size()
     nm, _ = build_models(device, gains=(0.8, 1.2))
     nm.set_queries(STANDARD_QUERY_IDS)
     gs = synthetic.syn_1827_shaped(60)
@@ -326,8 +428,9 @@ def nccl_selftest(args):
     B = min(part.num_neigh, 768)
     g = torch.Generator().manual_seed(4)
     y = torch.floor(torch.rand(B, len(STANDARD_QUERY_IDS), generator=g) ** 3 * 40)
-    cut = B // 2 + 37                                   # unequal halves: count-weighted mean loss
-    lo, hi = (0, cut) if rank == 0 else (cut, B)
+    # unequal contiguous shares (count-weighted mean loss): cuts at i*B/world shifted by 37 where that fits
+    cuts = [0] + [min(B, max(1, (i * B) // world + (37 if B // world > 74 else 0))) for i in range(1, world)] + [B]
+    lo, hi = cuts[rank], cuts[rank + 1]
     mine = NeighborhoodBatch(part.slice(lo, hi), device, y=y[lo:hi])
     params = [p for p in nm.parameters() if p.requires_grad]
     bk = D.GradBuckets(params, 4)
@@ -348,16 +451,34 @@ def nccl_selftest(args):
         worst = max(worst, float((gdist - ref).abs().max()) / den)
     t = torch.tensor([worst], device=device)
     D.all_reduce_(t, "max")
+    return {"status": "ok" if float(t) < 1e-4 else "FAILED", "world": world, "backend": torch.distributed.get_backend(),
+            "buckets": len(bk.buckets), "buckets_issued_from_hooks": issued,
+            "grad_bytes": sum(b.numel() for b in bk.buckets) * 4, "worst_rel_grad_diff_vs_union_batch": float(t)}
+
+
+def nccl_selftest(args):
+    """--selftest-nccl: the RCCL path without an 8-GPU node.  With >= 2 visible devices, two ranks (one per GPU, backend
+    "nccl") run ``nccl_gradient_check``; prints one JSON line.  Skips cleanly (status "skipped") on a 1-device box.
+    (With world > 1 and the nccl backend, the normal bench run performs the same check at start-up and reports it under
+    "collective".)"""
+    import torch
+    from desco_amd import distributed as D
+    ndev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ:
+        if ndev < 2:
+            print(json.dumps({"selftest": "nccl", "status": "skipped", "reason": f"{ndev} visible device(s); needs 2"}))
+            return 0
+        return D.launch([os.path.abspath(__file__), "--selftest-nccl"], 2, devices=[0, 1], timeout=600)
+    rank, world, _ = D.env_world()
+    device = D.local_device()
+    D.init_from_env(device, backend="nccl")
+    rec = nccl_gradient_check(device)
     if rank == 0:
-        ok = float(t) < 1e-4
-        print(json.dumps({"selftest": "nccl", "status": "ok" if ok else "FAILED", "world": world,
-                          "backend": torch.distributed.get_backend(), "buckets": len(bk.buckets),
-                          "buckets_issued_from_hooks": issued, "grad_bytes": sum(b.numel() for b in bk.buckets) * 4,
-                          "worst_rel_grad_diff_vs_union_batch": float(t)}))
+        print(json.dumps(dict({"selftest": "nccl"}, **rec)))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
-    return 0 if float(t) < 1e-4 else 1
+    return 0 if rec["status"] == "ok" else 1
 
 
 def main():
@@ -394,7 +515,10 @@ def main():
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--selftest-nccl", action="store_true",
                     help="2-rank RCCL gradient all-reduce check (needs 2 visible GPUs; skips otherwise)")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        sys.exit(cpu_worker_main())
     if args.selftest_nccl:
         sys.exit(nccl_selftest(args))
 
@@ -402,6 +526,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: start the N ranks ourselves, before any GPU call in this process
         sys.exit(D.launch([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    # the process-parallel CPU baseline's workers are started NOW, before this process touches the GPU
+    cpu_workers = None
+    if args.gpus == 1 and not args.no_cpu_baseline and "WORLD_SIZE" not in os.environ:
+        cpu_workers = start_cpu_workers()
 
     import torch
     rank, world, local_rank = D.env_world()
@@ -416,6 +545,18 @@ def main():
     device = D.local_device()
     D.init_from_env(device)
     assert D.world_size() == args.gpus, (D.world_size(), args.gpus)
+    # self-proof of the collective path: which backend is live and how many ranks it reaches
+    collective = None
+    if world > 1:
+        ones = torch.ones(1, device=torch.device("cpu") if share else device)
+        D.all_reduce_(ones, "sum")
+        collective = {"backend": torch.distributed.get_backend(), "ranks_seen": int(round(float(ones.item()))),
+                      "shared_gpu_test_mode": bool(share)}
+        assert collective["ranks_seen"] == world, collective
+        # the gradient all-reduce check on the live backend: always for nccl (RCCL, < 2 s); in the shared-GPU test mode
+        # (gloo, host-staged) only when asked, since the test-suite times these runs
+        if collective["backend"] == "nccl" or os.environ.get("DESCO_BENCH_GRAD_CHECK") == "1":
+            collective["grad_allreduce_selftest"] = nccl_gradient_check(device)
 
     from desco_amd import ops, synthetic
     from desco_amd.data import STANDARD_QUERY_IDS
@@ -530,8 +671,10 @@ def main():
         "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
-        "arithmetic": "fp32 in/out; matrix products as 6 bf16 MFMA products per multiply-add (3-way "
-                      "truncation split, fp32 accumulation): fp32-accurate, see DESIGN.md section 4",
+        "arithmetic": "fp32 in/out, fp32 accumulation; matrix products of the gossip stage and the anchor GEMM as 3 fp16 "
+                      "MFMA products per multiply-add (hi/lo split with power-of-two scales), of the SHMP layers and "
+                      "the small GEMMs as 6 bf16 products (3-way truncation split): both fp32-accurate, DESIGN.md "
+                      "section 4",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}-shaped synthetic ({base.num_graphs} graphs) x{args.replicas} "
@@ -586,7 +729,11 @@ def main():
                 roof = {"bound": "mfma", "achieved": ach, "peak": mp[0],
                         "unit": "TFLOP/s", "frac": ach / mp[0], "traffic": traffic(name),
                         "pipe": mp[1],
-                        "note": "achieved/peak in algorithmic fp32 flops; executed bf16 flops are 6x "
+                        "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                        "note": "achieved/peak in algorithmic fp32 flops; executed fp16 flops are 3x (frac = "
+                                "matrix-pipe utilisation); frac_of_f32_mfma_peak = against what the fp32 matrix "
+                                "pipe (157.3 TF/s) could do at best" if mp[0] == PEAK_X3_TFLOPS else
+                                "achieved/peak in algorithmic fp32 flops; executed bf16 flops are 6x "
                                 "(frac = matrix-pipe utilisation)" if mp[0] == PEAK_X6_TFLOPS else
                                 "fp32 matrix pipe"}
             else:
@@ -618,9 +765,10 @@ def main():
                 att = attainable_mfma()
                 if att:
                     # the shape the dominant kernel issues (gossip_fused: 16x16x32; the others: 32x32x16)
-                    shape = "v_mfma_f32_16x16x32_bf16" if name == "gossip_fused_kernel" else "v_mfma_f32_32x32x16_bf16"
-                    if shape in att and mp[0] == PEAK_X6_TFLOPS:
-                        pa = att[shape]["TFLOPs"] / 6.0
+                    shape = "v_mfma_f32_16x16x32_bf16" if name in ("gossip_fused_kernel", "gossip_fused_f16_kernel") \
+                        else "v_mfma_f32_32x32x16_bf16"      # (the fp16 MFMAs run at the bf16 rate of their shape)
+                    if shape in att and mp[0] in (PEAK_X6_TFLOPS, PEAK_X3_TFLOPS):
+                        pa = att[shape]["TFLOPs"] / (6.0 if mp[0] == PEAK_X6_TFLOPS else 3.0)
                         roof["attainable"] = {
                             "peak": pa, "frac": roof["achieved"] / pa, "mfma_shape": shape,
                             "measured": att,
@@ -667,7 +815,7 @@ def main():
             with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as f:
                 qj = json.load(f)
             queries = [(q["n"], [tuple(e) for e in q["edges"]]) for q in qj["queries"]]
-            cb, ref, n = cpu_baseline(nm, gm, base.edge_lists(), queries, args.cpu_seconds)
+            cb, ref, n = cpu_baseline(nm, gm, base.edge_lists(), queries, args.cpu_seconds, workers=cpu_workers)
             m = min(n, base.num_graphs)
             got = out["graph_gossip_count"][:m].cpu()
             want = ref["graph_gossip_count"][:m]
@@ -677,7 +825,10 @@ def main():
             cb["max_abs_count"] = want.abs().max().item()
             result["cpu_baseline"] = cb
             result["gpu_over_cpu"] = value / cb["value"]
+        if collective is not None:
+            result["collective"] = collective
         print(json.dumps(result))
+    stop_cpu_workers(cpu_workers)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_resident.sh)
+# DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_libs.sh)
 LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
 ABI_VERSION = 4
 
@@ -29,7 +29,7 @@ SIGNATURES = {
     "desco_partition_sizes": (c_int, [vp, POINTER(i64), POINTER(i64), POINTER(i64), POINTER(i64)]),
     "desco_partition_export": (c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "desco_partition_free": (None, [vp]),
-    "desco_partition_degree_sort": (c_int, [vp, i64, vp, vp, vp, vp, vp, vp, i32]),
+    "desco_partition_degree_sort": (c_int, [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32]),
     "desco_canonical_counts": (c_int, [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
     "desco_canonical_class_table": (c_int, [vp, vp, vp, i32, vp, vp]),
     "desco_canonical_counts_dev": (c_int, [vp, i64, i64, vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp]),
@@ -41,10 +41,6 @@ SIGNATURES = {
     "desco_linear64_bf16x6_f32": (c_int, [vp, i64, vp, i32, vp, i32, f32, vp, i64, i64, vp]),
     "desco_shmp_layer_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_layer_pool_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
-    "desco_shmp_resident_limits": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
-    "desco_resident_plan": (c_int, [vp, vp, i64, i64, i32, vp, vp, POINTER(i64)]),
-    "desco_shmp_resident_bf16x6_f32": (c_int, [vp, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i64, vp, i64,
-                                               vp, vp]),
     "desco_pool_reduce_f32": (c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]),
     "desco_shmp_pool_tile_rows": (c_int, []),
     "desco_degree_affine_f32": (c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i64, vp, i64, vp]),
@@ -119,8 +115,13 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.desco_abi_version() != ABI_VERSION:
-            raise DescoLibraryError("libdesco_hip.so ABI version mismatch; rebuild it")
+        ver = handle.desco_abi_version()
+        if ver == ABI_VERSION + 1000 and os.environ.get("DESCO_ALLOW_DEBUG_LIB") == "1":
+            pass        # a timing-only ablation / probe build (wrong results by design): developer tools only
+        elif ver != ABI_VERSION:
+            raise DescoLibraryError(
+                f"{LIB_PATH}: ABI version {ver}, expected {ABI_VERSION}" +
+                (" (a debug / ablation build; set DESCO_ALLOW_DEBUG_LIB=1 for tools/debug runs)" if ver >= 1000 else "; rebuild it"))
         _lib = handle
     return _lib
 

@@ -167,6 +167,11 @@ class ShmpTrunk(torch.autograd.Function):
         w = ctx.saved_tensors
         batch, groups, has_anchor = ctx.batch, ctx.groups, ctx.has_anchor
         X, AGG = ctx.X, ctx.AGG
+        if AGG is None or any(a is None for a in AGG):
+            # the per-layer aggregates are released as the backward consumes them (they are the largest saved
+            # tensors of the step); a second backward through the same node would otherwise die on a None
+            raise RuntimeError("ShmpTrunk.backward ran twice on the same forward (retain_graph=True is not supported: "
+                               "the saved aggregates are freed layer by layer); run the forward again")
         ti = batch.train_index()
         N, S = batch.num_rows, batch.slots
         H = 64

@@ -101,41 +101,6 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def _seg_ptr_device(self):
         return self.count_ptr
 
-    def resident_plan(self, min_count_rows: int = 1):
-        """Work list of the neighborhood-resident multi-layer kernel (desco_shmp_resident_bf16x6_f32),
-        built once per batch: bin-packed packs of the neighborhoods with at least ``min_count_rows``
-        count rows that fit the kernel's LDS limits, and the remaining neighborhoods (too small to be
-        worth aligning to 16-row tiles, or above the limits) as a self-contained sub-batch for the
-        layer-by-layer kernels.  Which path a neighborhood takes depends on the neighborhood alone."""
-        cache = self.__dict__.setdefault("_resident_plan", {})
-        if min_count_rows not in cache:
-            from . import ops
-            part = self.part
-            plan = {"num_packs": 0, "rest_index": None, "rest_batch": None}
-            if part.num_neigh > 0:
-                elig, plist = ops.resident_plan(part.count_ptr, part.vrowptr, part.num_count, min_count_rows)
-                if len(plist):
-                    cp = part.count_ptr.astype(np.int64)
-                    n = np.diff(cp)
-                    v = part.vrowptr.astype(np.int64)
-                    kr = part.num_count + np.arange(part.num_neigh)
-                    e = (v[4 * cp[1:]] - v[4 * cp[:-1]]) + (v[4 * kr + 4] - v[4 * kr])
-                    tiles = int(((n[elig] + 15) // 16).sum())
-                    rest = np.nonzero(~elig)[0]
-                    dev = self.device
-                    plan = {
-                        "num_packs": len(plist), "pack_list": _i32(plist, dev),
-                        "rows": int(n[elig].sum() + elig.sum()), "edges": int(e[elig].sum()),
-                        "neighborhoods": int(elig.sum()), "tile_rows": 16 * tiles + 16 * len(plist),
-                        "counter": torch.zeros(1, device=dev, dtype=torch.int32),
-                        "rest_index": None, "rest_batch": None,
-                    }
-                    if len(rest):
-                        plan["rest_index"] = torch.from_numpy(rest).to(dev)
-                        plan["rest_batch"] = NeighborhoodBatch(part.select(rest), dev, input_dim=self.input_dim)
-            cache[min_count_rows] = plan
-        return cache[min_count_rows]
-
     def pool_index(self, tile_rows: Optional[int] = None):
         """(pool_bits, pool_slot, num_slots) of the fused pooling (desco_shmp_layer_pool_bf16x6_f32):
         per wave tile (``tile_rows`` = 16 or 32 count rows; default: what the library's layer kernel

@@ -12,7 +12,13 @@ int fail(int code, const char* msg) {
 }
 }  // namespace desco
 
+// A library built with any timing-only ablation / probe switch (-DDESCO_DEBUG_ABLATION, required by the GF_ABL / GS_ABL /
+// SH16_ABL / *_TAIL switches) computes wrong results on purpose: it reports a version no product loader accepts.
+#if defined(DESCO_DEBUG_ABLATION) || defined(GF_TAIL) || defined(SH16_TAIL)
+extern "C" int desco_abi_version(void) { return DESCO_ABI_VERSION + 1000; }
+#else
 extern "C" int desco_abi_version(void) { return DESCO_ABI_VERSION; }
+#endif
 
 extern "C" int desco_device_count(void) {
   int n = 0;

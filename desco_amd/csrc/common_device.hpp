@@ -64,10 +64,11 @@ __device__ __forceinline__ uint32_t pack2_bf16_rne(const float f0, const float f
 typedef _Float16 desco_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_f16x2(const float f0, const float f1, uint32_t& hi, uint32_t& lo) {
   const desco_f2 f = {f0, f1};
-  const desco_h2 h = __builtin_convertvector(f, desco_h2);
-  const desco_h2 l = {(_Float16)(f0 - (float)h.x), (_Float16)(f1 - (float)h.y)};
-  hi = __builtin_bit_cast(uint32_t, h);
-  lo = __builtin_bit_cast(uint32_t, l);
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, desco_h2));          // v_cvt_pk_f16_f32
+  // lo = fp16(f - hi) straight from the packed hi halves (mixed-precision fma: f32 * 1.0 - f16 -> f16); hipcc's own
+  // lowering of the C expression is v_cvt_f32_f16 x 2 + v_pk_fma_f32 + v_cvt_pk_f16_f32 (4 instructions for these 2)
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(f0), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(f1), "v"(hi));
 }
 // the power of two s with s * mx in [2^14, 2^15) (mx >= 0; 1 for mx == 0): exponent bits only, no rounding anywhere.
 // mx = 1.m * 2^(eb-127)  ->  s = 2^(141 - eb)  (biased 268 - eb, clamped to a normal number)

@@ -45,6 +45,9 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 #ifndef GS_ABL
 #define GS_ABL 0
 #endif
+#if GS_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
+#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
+#endif
 #if GS_ABL == 1      // no split arithmetic (timing only)
 #define GS_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
 #else

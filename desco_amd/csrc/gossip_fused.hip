@@ -192,6 +192,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef GF_ABL
 #define GF_ABL 0
 #endif
+#if GF_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
+#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
+#endif
 #if GF_ABL == 1
 #define GF_M16(a_, b_, c_) { asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_)); }
 #else

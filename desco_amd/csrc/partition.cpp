@@ -356,13 +356,13 @@ extern "C" void desco_partition_free(desco_partition* p) { delete p; }
 // Row order inside a neighborhood is a convention of this library (the reference's own order is CPython set order,
 // DESIGN.md section 2) and no sum over a neighborhood depends on it.  The layer kernel takes, per 16-row wave tile and
 // gathered relation slot, as many two-source steps as the tile's highest-degree row needs: rows sorted by degree put
-// similar rows into one tile.  Key: the block's heavier count -> count slot first, then the other one; the direction
-// alternates from one neighborhood to the next, so a tile that spans a boundary joins the low ends (or the high ends)
-// of both.  Measured: shmp_layer16 -9 % on Syn_1827 shapes, -3 % on MSRC-21 + IMDB shapes, +-0 on COX2 shapes.
+// similar rows into one tile.  Key: the neighborhood's heavier count -> count slot first, then the other one; the
+// direction alternates with the parity of neigh_key (graph id + node id: consecutive neighborhoods of a graph alternate),
+// so a tile that spans a boundary joins the low ends (or the high ends) of both.  Measured: shmp_layer16 -9 % on Syn_1827 shapes, -3 % on MSRC-21 + IMDB shapes, +-0 on COX2 shapes.
 extern "C" int desco_partition_degree_sort(const int32_t* count_ptr, int64_t num_neigh, const int32_t* vrowptr,
                                            const int32_t* vcol, const int32_t* count_orig,
                                            int32_t* count_orig_out, int32_t* vrowptr_out, int32_t* vcol_out,
-                                           int num_threads) {
+                                           const int64_t* neigh_key, int num_threads) {
   if (!count_ptr || !vrowptr || num_neigh < 0 || !count_orig_out || !vrowptr_out)
     return desco::fail(DESCO_EINVAL, "desco_partition_degree_sort: bad argument");
   const int64_t B = num_neigh, Nc = count_ptr[B];
@@ -376,13 +376,6 @@ extern "C" int desco_partition_degree_sort(const int32_t* count_ptr, int64_t num
     const int nt = 1;
     (void)num_threads;
 #endif
-    int64_t tot0 = 0, tot1 = 0;
-#pragma omp parallel for num_threads(nt) reduction(+ : tot0, tot1) schedule(static)
-    for (int64_t r = 0; r < Nc; ++r) {
-      tot0 += vrowptr[4 * r + 1] - vrowptr[4 * r];
-      tot1 += vrowptr[4 * r + 2] - vrowptr[4 * r + 1];
-    }
-    const int ps = tot1 >= tot0 ? 1 : 0;           // primary slot
     std::vector<int32_t> order((size_t)Nc), new_of_old((size_t)Nc);
 #pragma omp parallel num_threads(nt)
     {
@@ -391,7 +384,17 @@ extern "C" int desco_partition_degree_sort(const int32_t* count_ptr, int64_t num
       for (int64_t b = 0; b < B; ++b) {
         const int64_t c0 = count_ptr[b], n = count_ptr[b + 1] - c0;
         key.resize((size_t)n);
-        const int64_t sign = (b & 1) ? 1 : -1;
+        // direction and primary slot are properties of the neighborhood alone (its key's parity -- the caller passes
+        // graph id + node id --, its own slot totals), so its row order -- hence its fp32 summation order -- does
+        // not depend on which block / shard it lands in
+        const int64_t sign = ((neigh_key ? neigh_key[b] : b) & 1) ? 1 : -1;
+        int64_t tot0 = 0, tot1 = 0;
+        for (int64_t i = 0; i < n; ++i) {
+          const int32_t* v = vrowptr + 4 * (c0 + i);
+          tot0 += v[1] - v[0];
+          tot1 += v[2] - v[1];
+        }
+        const int ps = tot1 >= tot0 ? 1 : 0;           // primary slot
         for (int64_t i = 0; i < n; ++i) {
           const int32_t* v = vrowptr + 4 * (c0 + i);
           const int64_t dp = v[ps + 1] - v[ps], dq = v[2 - ps] - v[1 - ps];

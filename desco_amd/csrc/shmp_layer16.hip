@@ -275,6 +275,9 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #ifndef SH16_ABL
 #define SH16_ABL 0
 #endif
+#if SH16_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
+#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
+#endif
 #if SH16_ABL == 1        // timing-only builds (tools/debug/ab_libs.sh): 1 no MFMA, 2 no split arithmetic, 3 no output stores
 #define DESCO_M16(a_, b_, c_) { asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_)); }
 #else

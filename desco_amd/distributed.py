@@ -208,6 +208,9 @@ def barrier():
         dist.barrier()
 
 
+_RANK0_FIRST_CALLS = 0
+
+
 def rank0_first(fn: Callable, key: str = "desco_rank0_done", timeout_s: float = 7 * 86400.0):
     """``fn()`` on rank 0 first, then on the other ranks (which then find rank 0's on-disk caches).
     The others wait on the process group's STORE, not in a collective: a store wait has its own
@@ -218,6 +221,11 @@ def rank0_first(fn: Callable, key: str = "desco_rank0_done", timeout_s: float = 
     if not is_initialized() or dist.get_world_size() == 1:
         return fn()
     store = dist.distributed_c10d._get_default_store()
+    # one key per CALL (every rank counts its calls identically): a second use in the same process group must not
+    # find the first call's "ok" / "fail" and run ahead of rank 0
+    global _RANK0_FIRST_CALLS
+    _RANK0_FIRST_CALLS += 1
+    key = f"{key}:{_RANK0_FIRST_CALLS}"
     if dist.get_rank() == 0:
         try:
             out = fn()
@@ -356,7 +364,12 @@ class GradBuckets:
     size is latency-bound, so a few large buckets beat per-tensor collectives.  Buckets are filled
     in REVERSE registration order (the order backward produces gradients: head first, layer 0
     last); a post-accumulate hook counts a bucket's gradients and issues its asynchronous
-    all-reduce the moment it is complete -- backward of the earlier layers overlaps it.
+    all-reduce the moment it is complete -- the rest of the backward overlaps it.  With the fused training
+    trunk (autograd.ShmpTrunk, default) the gradients of ALL SHMP-layer weights appear at once, at the end of the
+    trunk's backward, so only the head / post-MLP buckets overlap compute; the layer buckets (most of the 5.24 MB)
+    are issued behind the trunk.  At 5 MB per step against ~5 ms of kernels that exposes < 0.1 ms per step over
+    xGMI; per-op autograd (gnn_model.FUSED_TRAIN_TRUNK = False) restores the overlap at
+    1.5x the step time.
     ``finish()`` issues the buckets whose parameters received no gradient (the never-used
     query-side ``anchor_mlp``, SURVEY A10: DDP's find_unused_parameters semantics, they reduce
     zeros) and waits.  After the first step those parameters are moved into ONE last bucket, so that

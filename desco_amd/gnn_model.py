@@ -44,18 +44,6 @@ SHMP_BF16X6 = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
-# Neighborhood-resident multi-layer kernel (csrc/shmp_resident.hip): every SHMP layer of a pack of
-# neighborhoods in one launch with the node features in LDS.  When True, target batches with the constant
-# (all-zero) input send every neighborhood with at least RESIDENT_MIN_ROWS count rows that fits the
-# kernel's pack limits through it and the others (aligning a small neighborhood to 16-row tiles wastes too
-# much) through the layer-by-layer kernels; the rule looks at the neighborhood alone, so every shard /
-# block / rank takes the same path for it, and a packed neighborhood's result is bit-for-bit independent
-# of its placement.  OFF by default: measured end to end it is 5 % (Syn_1827 shapes) to 13 % (MSRC-21 +
-# IMDB shapes) SLOWER than the layer-by-layer kernels (the kernel's count
-# phase is VALU-issue-bound beside its MFMAs and 35 % of its time goes to barriers, epilogues and per-pack
-# set-up).
-RESIDENT_SHMP = False
-RESIDENT_MIN_ROWS = 48
 # Training: the SHMP layer loop + anchor + pooling as ONE autograd node whose forward and backward are C-ABI
 # launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
 # --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
@@ -423,69 +411,13 @@ def _anchor_const_input(pk, gnn, canon):
     return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1)
 
 
-def _resident_operands(pk, core, dev):
-    """Operands of desco_shmp_resident_bf16x6_f32, folded once per weight version: first-layer
-    coefficients [2][5][64], fragment stream [L-1][16][3][4][64][8], biases [L-1][2][64]."""
-    if "resident" not in pk:
-        x0 = {t: pk["pre"][t][1] for t in ("count", "canonical")}
-        src = lambda t, s: "count" if s < 2 else "canonical"              # noqa: E731
-        l0 = torch.stack([_first_layer_coef(pk, "count", 4, 4, x0, src, dev),
-                          _first_layer_coef(pk, "canonical", 2, 4, x0, src, dev)]).contiguous()
-        frags, biases = [], []
-        for l in range(1, core.layer_num):
-            ec, ek = pk["layers"][l]["count"], pk["layers"][l]["canonical"]
-            frags.append(ops.resident_fragments(ec["wt_tab"], ek["wt"], ec["wt_mfma"]))
-            biases.append(torch.stack([ec["b"], ek["b"]]))
-        pk["resident"] = (l0, torch.stack(frags).contiguous(), torch.stack(biases).contiguous())
-    return pk["resident"]
-
-
-def _use_resident(gnn: BaseGNN, batch) -> bool:
-    if not RESIDENT_SHMP or not isinstance(batch, NeighborhoodBatch):
-        return False
-    core = gnn.gnn_core
-    ok = (batch.node_feature is None and FUSED_SHMP_LAYER and SHMP_BF16X6 and GEMM_BF16X6
-          and core.layer_num >= 2 and "wt_tab" in gnn.packed()["layers"][0].get("count", {}))
-    return bool(ok) and batch.resident_plan(RESIDENT_MIN_ROWS)["num_packs"] > 0
-
-
-def _shmp_pooled_resident(gnn: BaseGNN, batch) -> torch.Tensor:
-    """pooled [B, 576] of BaseGNN.forward's hetero path (gnn_model.py:58-107) with ALL layers of the packed
-    neighborhoods in one launch (csrc/shmp_resident.hip); the other neighborhoods (small, or above the
-    kernel's pack limits) run through the layer-by-layer kernels as a sub-batch."""
-    pk = gnn.packed()
-    core = gnn.gnn_core
-    dev = batch.vrowptr.device
-    plan = batch.resident_plan(RESIDENT_MIN_ROWS)
-    l0, wfrag, bias = _resident_operands(pk, core, dev)
-    B = batch.num_graphs
-    P = H * (core.layer_num + 1)
-    pooled = torch.zeros((B, P), device=dev)
-    canon = torch.zeros((B, P), device=dev)
-    ops.shmp_resident(batch.count_ptr, batch.vrowptr, batch.vcol, batch.num_count, plan["pack_list"],
-                      l0, wfrag, bias, pooled, canon, plan["counter"],
-                      work=(plan["rows"], plan["edges"]))
-    anch = _anchor_const_input(pk, gnn, canon)                    # gnn_model.py:69-73 (x^0 block folded)
-    ck = ("pool0_coef", "count")
-    if ck not in pk:
-        pk[ck] = torch.stack([pk["pre"]["count"][1], torch.zeros(H, device=dev)]).contiguous()
-    # block 0: (count rows in the neighborhood) * x0 + anchored canonical row; blocks 1..: + anchored row
-    ops.degree_affine(batch.count_ptr, 0, B, 1, pk[ck], ops.ACT_NONE, 0.0, pooled[:, :H], extra=anch[:, :H])
-    pooled[:, H:] += anch[:, H:]
-    if plan["rest_batch"] is not None:
-        pooled[plan["rest_index"]] = _shmp_pooled(gnn, plan["rest_batch"], allow_resident=False)
-    return pooled
-
-
 def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     """BaseGNN.forward, hetero path (gnn_model.py:58-109) -> graph embeddings [B, 64]."""
     return _post_mp(gnn.packed(), _shmp_pooled(gnn, batch))                 # :108
 
 
-def _shmp_pooled(gnn: BaseGNN, batch, allow_resident: bool = True) -> torch.Tensor:
+def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     """The pooled embeddings [B, 64 (L+1)] of BaseGNN.forward before post_mp (gnn_model.py:58-107)."""
-    if allow_resident and _use_resident(gnn, batch):
-        return _shmp_pooled_resident(gnn, batch)
     pk = gnn.packed()
     core = gnn.gnn_core
     dev = batch.vrowptr.device

@@ -307,81 +307,6 @@ def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_
     return out
 
 
-# ---- neighborhood-resident multi-layer SHMP (csrc/shmp_resident.hip) ---------------------------------
-def resident_limits():
-    """(max count rows, max edges, max neighborhoods) of one pack of desco_shmp_resident_bf16x6_f32."""
-    import ctypes
-    a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _lib.check(_lib.lib().desco_shmp_resident_limits(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-    return a.value, b.value, c.value
-
-
-def resident_plan(count_ptr, vrowptr, num_count: int, min_count_rows: int = 1):
-    """Host side of the resident kernel's work list (desco_resident_plan): numpy int32 arrays in,
-    (eligible bool [B], pack_list int32 [P, 16] of neighborhood indices, -1 = unused slot) out."""
-    import ctypes
-    import numpy as np
-    cp = np.ascontiguousarray(count_ptr, dtype=np.int32)
-    vr = np.ascontiguousarray(vrowptr, dtype=np.int32)
-    B = len(cp) - 1
-    elig = np.zeros(max(B, 1), dtype=np.uint8)
-    plist = np.full((max(B, 1), 16), -1, dtype=np.int32)
-    npk = ctypes.c_int64()
-    _lib.check(_lib.lib().desco_resident_plan(cp.ctypes.data, vr.ctypes.data, B, int(num_count),
-                                              int(min_count_rows), elig.ctypes.data, plist.ctypes.data,
-                                              ctypes.byref(npk)),
-               "resident_plan")
-    return elig[:B].astype(bool), plist[:npk.value].copy()
-
-
-def _fragment_steps(planes: torch.Tensor, order) -> torch.Tensor:
-    """planes [3][N][K] int16 (n-major bf16 planes) -> MFMA B fragments of v_mfma_f32_16x16x32_bf16 for the
-    K-steps in ``order`` = [(j, kb, h), ...]: step -> [3 planes][4 col tiles][64 lanes][8], lane (n = lane & 15,
-    q = lane >> 4) holding W[k = 64 kb + 32 h + 8 q .. + 7][n = 64 j + 16 t + n]."""
-    P3, N, K = planes.shape
-    v = planes.view(3, N // 64, 4, 16, K // 64, 2, 4, 8)          # [p][j][t][n][kb][h][q][8]
-    steps = [v[:, j, :, :, kb, h].permute(0, 1, 3, 2, 4).reshape(3, 4, 64, 8) for j, kb, h in order]
-    return torch.stack(steps)
-
-
-def resident_fragments(wt_tab: torch.Tensor, wt_canon: torch.Tensor, wt_count: torch.Tensor) -> torch.Tensor:
-    """One layer's fragment stream [16][3][4][64][8] int16 of desco_shmp_resident_bf16x6_f32 from the folded
-    fp32 weights in K-major form: wt_tab [64, 128] (= [W_2 | W_3]), wt_canon [192, 64] (canonical
-    destinations: slot 0, slot 1, self), wt_count [192, 64] (count destinations)."""
-    tab = _fragment_steps(split_bf16_planes(wt_tab.t().contiguous()), [(0, 0, 0), (1, 0, 0), (0, 0, 1), (1, 0, 1)])
-    kbh = [(0, b, h) for b in range(3) for h in range(2)]
-    can = _fragment_steps(split_bf16_planes(wt_canon.t().contiguous()), kbh)
-    cnt = _fragment_steps(split_bf16_planes(wt_count.t().contiguous()), kbh)
-    return torch.cat([tab, can, cnt]).contiguous()
-
-
-def shmp_resident(count_ptr: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, num_count: int,
-                  pack_list: torch.Tensor, l0coef: torch.Tensor, wfrag: torch.Tensor,
-                  bias: torch.Tensor, pooled: torch.Tensor, canon: torch.Tensor, counter: torch.Tensor,
-                  work=None) -> None:
-    """All SHMP layers for the packs' neighborhoods in one launch (see desco_hip.h); ``work`` =
-    (rows, directed edges) of the packs for the launch profiler."""
-    P = pack_list.shape[0]
-    assert pack_list.dim() == 2 and pack_list.shape[1] == 16 and pack_list.is_contiguous()
-    nl = wfrag.shape[0]
-    assert wfrag.dtype == torch.int16 and wfrag.is_contiguous() and tuple(wfrag.shape[1:]) == (16, 3, 4, 64, 8)
-    assert l0coef.is_contiguous() and tuple(l0coef.shape) == (2, 5, 64)
-    assert bias.is_contiguous() and tuple(bias.shape) == (nl, 2, 64)
-    pp, ldp = _rows(pooled, "pooled")
-    cp_, ldc = _rows(canon, "canon")
-    rows, edges = work if work is not None else (0, 0)
-    fl = 2.0 * rows * 192 * 64 * nl
-    nb = 4.0 * (edges + 4 * rows)        # CSR once (+ 2 x 256 B per neighborhood and layer, negligible)
-    L = _lib.lib()
-    with _Timed("shmp_resident_kernel", fl, nb):
-        _lib.check(L.desco_shmp_resident_bf16x6_f32(
-            _dev(count_ptr, "count_ptr", torch.int32), _dev(vrowptr, "vrowptr", torch.int32),
-            _dev(vcol, "vcol", torch.int32), int(num_count), _dev(pack_list, "pack_list", torch.int32),
-            int(P), _dev(l0coef, "l0coef"),
-            _dev(wfrag, "wfrag", torch.int16), _dev(bias, "bias"), int(nl), pp, ldp, cp_, ldc,
-            _dev(counter, "counter", torch.int32), _stream()), "shmp_resident")
-
-
 def shmp_kernel_name(kb: int, st: int, x6: bool) -> str:
     """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
     the bf16x6 form unless DESCO_SHMP_ROWS=32) and its <weight blocks, table slots>."""

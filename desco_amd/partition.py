@@ -79,8 +79,7 @@ class NeighborhoodPartition:
 
     def select(self, idx) -> "NeighborhoodPartition":
         """The neighborhoods ``idx`` (ascending indices, any subset) as a self-contained block: what
-        ``slice`` does for a contiguous range.  Used to hand the few neighborhoods that exceed the
-        resident kernel's pack limits to the layer-by-layer kernels."""
+        ``slice`` does for a contiguous range."""
         idx = np.asarray(idx, dtype=np.int64)
         M = len(idx)
         cp, Nc = self.count_ptr.astype(np.int64), self.num_count
@@ -105,8 +104,8 @@ class NeighborhoodPartition:
             depth=self.depth, quirk_batch=self.quirk_batch)
 
     def degree_sorted(self, num_threads: int = 0) -> "NeighborhoodPartition":
-        """The same block with the count rows of every neighborhood re-ordered by decreasing / increasing (alternating
-        between consecutive neighborhoods) number of count -> count sources (``desco_partition_degree_sort``): fewer
+        """The same block with the count rows of every neighborhood re-ordered by decreasing / increasing (by the parity
+        of graph id + node id, so consecutive neighborhoods alternate) number of count -> count sources (``desco_partition_degree_sort``): fewer
         gather steps per 16-row tile of the layer kernel on dense shapes.  Row order inside a neighborhood is a
         convention of this repo; per-neighborhood results only change by fp32 summation order."""
         if self.num_count == 0:
@@ -116,9 +115,12 @@ class NeighborhoodPartition:
         vc = np.ascontiguousarray(self.vcol, dtype=np.int32)
         co = np.ascontiguousarray(self.count_orig, dtype=np.int32)
         co2, vr2, vc2 = np.empty_like(co), np.empty_like(vr), np.empty_like(vc)
+        # direction by a neighborhood-intrinsic key (graph id + node id): the same neighborhood gets the same row
+        # order -- the same fp32 summation order -- wherever the block cuts fall
+        nkey = np.ascontiguousarray(self.neigh_index[:, 0].astype(np.int64) + self.neigh_index[:, 1].astype(np.int64))
         _lib.check(_lib.lib().desco_partition_degree_sort(
             cp.ctypes.data, self.num_neigh, vr.ctypes.data, vc.ctypes.data, co.ctypes.data, co2.ctypes.data,
-            vr2.ctypes.data, vc2.ctypes.data, num_threads), "desco_partition_degree_sort")
+            vr2.ctypes.data, vc2.ctypes.data, nkey.ctypes.data, num_threads), "desco_partition_degree_sort")
         return NeighborhoodPartition(
             neigh_index=self.neigh_index, indicator=self.indicator, count_ptr=self.count_ptr, count_orig=co2,
             vrowptr=vr2, vcol=vc2, depth=self.depth, quirk_batch=self.quirk_batch)

@@ -80,14 +80,15 @@ int desco_partition_export(const desco_partition* p, int64_t* neigh_index, uint8
 void desco_partition_free(desco_partition* p);
 
 /* Optional re-ordering of a block's count rows (host arrays, same layout in and out): inside every neighborhood the
- * count rows are sorted by their number of count -> count sources (the block's heavier relation slot first, direction
- * alternating between consecutive neighborhoods), vcol is relabelled and kept ascending inside a slot, count_orig
+ * count rows are sorted by their number of count -> count sources (the neighborhood's heavier relation slot first,
+ * descending when neigh_key[b] is even, ascending when odd -- pass graph id + node id so that the order is a property
+ * of the neighborhood, not of its place in a block; NULL = the index b), vcol is relabelled and kept ascending inside a slot, count_orig
  * follows the rows; count_ptr, the canonical rows and every per-neighborhood quantity are unchanged.  Row order inside a
  * neighborhood is this library's convention (data.py:375-396 leaves it to CPython set order), and the fused layer kernel
  * needs as many gather steps per 16-row tile as the tile's highest-degree row: -9 % on Syn_1827 shapes. */
 int desco_partition_degree_sort(const int32_t* count_ptr, int64_t num_neigh, const int32_t* vrowptr,
                                 const int32_t* vcol, const int32_t* count_orig, int32_t* count_orig_out,
-                                int32_t* vrowptr_out, int32_t* vcol_out, int num_threads);
+                                int32_t* vrowptr_out, int32_t* vcol_out, const int64_t* neigh_key, int num_threads);
 
 /* ------------------------------------------------------------------------------------------
  * DEVICE: the same canonical-partition builder on the GPU (csrc/partition_dev.hip), one wavefront
@@ -270,46 +271,6 @@ int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, con
                           int64_t ld_extra, float* out, int64_t ldo, int tile_rows,
                           desco_stream_t stream);
 
-/* Neighborhood-resident multi-layer SHMP (csrc/shmp_resident.hip): ALL layers of BaseGNNCore.forward's
- * SAGE branch for the hetero count / canonical block (gnn_model.py:230-277, 372-404) in ONE launch, the
- * node features of a PACK of neighborhoods resident in LDS from the first layer to the last, plus the
- * global_add_pool of the count rows (gnn_model.py:88-89, 107).  Constant input only (the default
- * pipeline's all-zero node features, workload.py:431-440): the first layer is the closed degree-affine
- * form of desco_degree_affine_f32.
- *   packs: pack p = the neighborhoods pack_list[p][0..15] (indices into the 4-slot block count_ptr /
- *          vrowptr / vcol of desco_shmp_layer_*; -1 = unused slot), built by desco_resident_plan (bin
- *          packing towards full packs): <= 16 neighborhoods, <= 30 tiles of 16 count rows (every
- *          neighborhood starts a tile), <= desco_shmp_resident_limits edges; neighborhoods above the
- *          limits or with fewer than min_count_rows count rows (tile alignment wastes too much on
- *          them) are flagged eligible[b] = 0, belong to no pack and must go through the
- *          layer-by-layer entry points -- a per-neighborhood rule, so every shard decides alike.
- *          pack_list must hold 16 * num_neigh entries for the plan.
- *   l0coef [2][5][64]: first-layer coefficients, count rows (slots 0..3, constant) then canonical rows
- *          (slots 0, 1, two unused rows, constant): x1 = relu(const + sum_s deg_s coef_s).
- *   wfrag  [num_layers][16][3][4][64][8] bf16: the layers' weight planes as MFMA B fragments in
- *          consumption order -- per layer 4 K-steps of the canonical->count table weights ([W_2|W_3],
- *          order (h0,j0) (h0,j1) (h1,j0) (h1,j1)), 6 of the canonical-destination weights (slot 0,
- *          slot 1, self; two 32-deep halves each), 6 of the count-destination weights; step =
- *          [plane hi/mid/lo][16-column tile][lane][8]: lane (n = lane & 15, q = lane >> 4) holds
- *          W[k = 32 h + 8 q .. + 7][16 t + n]  (desco_amd.ops.resident_fragments builds it).
- *   bias   [num_layers][2][64]: folded bias of the count rows, of the canonical rows.
- *   pooled [B][ldp], canon [B][ldc]: column block l (64 floats at 64 l) receives, for l = 1 ..
- *          num_layers + 1, the sum of the neighborhood's count rows of x^l / its canonical row of x^l
- *          (block 0, the constant input layer, is left to the caller); rows of ineligible neighborhoods
- *          are not touched.  counter: one int32 of device scratch (pack hand-out).
- * Every sum has a fixed order that depends only on the neighborhood itself (tiles are aligned to
- * neighborhood starts; a row switches to the cooperative gather by its OWN degree): results do not
- * depend on which other neighborhoods share the launch, pack or shard. */
-int desco_shmp_resident_limits(int* max_count_rows, int* max_edges, int* max_neigh);
-int desco_resident_plan(const int32_t* count_ptr, const int32_t* vrowptr, int64_t num_neigh,
-                        int64_t num_count, int min_count_rows, uint8_t* eligible, int32_t* pack_list,
-                        int64_t* num_packs);
-int desco_shmp_resident_bf16x6_f32(const int32_t* count_ptr, const int32_t* vrowptr, const int32_t* vcol,
-                                   int64_t num_count, const int32_t* pack_list, int num_packs,
-                                   const float* l0coef, const int16_t* wfrag,
-                                   const float* bias, int num_layers, float* pooled, int64_t ldp,
-                                   float* canon, int64_t ldc, int32_t* counter, desco_stream_t stream);
-
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);
  * w_planes[num_blocks][3][64 n][64 k] = desco_split_bf16x3_f32 of every 64-row block of the
@@ -399,7 +360,11 @@ int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, const int32_t
  *      desco_split_bf16x3_f32: w*_planes[3][out][in].  All GEMMs run as the fp32-accurate
  *      6-product bf16 split of desco_gemm_bf16x6_f32.  p, z, r, t must be 8-byte aligned.
  * Replaces BaseGNN.forward (gossip) for every query: gnn_model.py:58-103, 230-260, 303-350 and the
- * loop of lightning_model.py:613-628; equals layer0 + gather + 4 GEMMs + rowdot of the unfused path. */
+ * loop of lightning_model.py:613-628; equals layer0 + gather + 4 GEMMs + rowdot of the unfused path.
+ * desco_gossip_fused_f32 (the six-product bf16 form; since round 4 the cross-check of desco_gossip_fused_f16x3_f32)
+ * draws its work items from a process-wide ring of 64 ticket slots taken in launch order: launches must be issued
+ * from ONE stream at a time and captured launches must not be replayed concurrently with other launches of it (the
+ * fp16 entry point takes a caller-owned queue instead). */
 int desco_gossip_scalars_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                              int64_t num_nodes, int num_q, const float* g0, const float* g1,
                              float* scal4, desco_stream_t stream);

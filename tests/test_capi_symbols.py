@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/desco_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert L.desco_abi_version() == _lib.ABI_VERSION == 3
+    assert L.desco_abi_version() == _lib.ABI_VERSION == 4
     assert L.desco_count_head_bwd_workspace(512, 29, 256) == 32 * 30 * 256 * 4
     assert L.desco_count_head_bwd_workspace(10 ** 6, 29, 256) == 1024 * 30 * 256 * 4
 
@@ -45,14 +45,14 @@ def test_new_entry_points_validate_their_arguments():
     L = _lib.lib()
     cp = np.zeros(1, np.int32)
     vr = np.zeros(1, np.int32)
-    assert L.desco_partition_degree_sort(None, 0, vr.ctypes.data, None, None, None, vr.ctypes.data, None, 0) == -1
+    assert L.desco_partition_degree_sort(None, 0, vr.ctypes.data, None, None, None, vr.ctypes.data, None, None, 0) == -1
     assert b"desco_partition_degree_sort" in L.desco_last_error()
     assert L.desco_partition_degree_sort(cp.ctypes.data, -1, vr.ctypes.data, None, None, cp.ctypes.data,
-                                         vr.ctypes.data, None, 0) == -1
+                                         vr.ctypes.data, None, None, 0) == -1
     # an empty block is fine (no rows, no edges)
     out = np.zeros(1, np.int32)
     assert L.desco_partition_degree_sort(cp.ctypes.data, 0, vr.ctypes.data, None, None, cp.ctypes.data,
-                                         out.ctypes.data, None, 1) == 0 and out[0] == 0
+                                         out.ctypes.data, None, None, 1) == 0 and out[0] == 0
     assert L.desco_gossip_tile_order(None, 5, None, None) == -1
     assert b"desco_gossip_tile_order" in L.desco_last_error()
     assert L.desco_gossip_tile_order(None, 0, None, None) == 0          # nothing to do

@@ -190,7 +190,7 @@ def test_two_rank_trainer_fit_equals_one_rank_union_steps(tmp_path):
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_starts_its_own_ranks(scaling):
-    env = dict(os.environ, DESCO_SHARE_GPU="1")
+    env = dict(os.environ, DESCO_SHARE_GPU="1", DESCO_BENCH_GRAD_CHECK="1" if scaling == "weak" else "0")
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                         "--warmup", "1", "--replicas", "2", "--scaling", scaling, "--no-cpu-baseline"],
@@ -200,6 +200,13 @@ def test_bench_starts_its_own_ranks(scaling):
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == scaling and r["value"] > 0
+    # the run proves its own collective path: live backend, ranks reached by an all-reduce of ones,
+    # and (nccl always; here on request, through the host-staged gloo path) the bucketed gradient all-reduce check
+    col = r["collective"]
+    assert col["ranks_seen"] == 2 and col["backend"] == "gloo" and col["shared_gpu_test_mode"] is True
+    if scaling == "weak":
+        gc = col["grad_allreduce_selftest"]
+        assert gc["status"] == "ok" and gc["world"] == 2 and gc["worst_rel_grad_diff_vs_union_batch"] < 1e-4
     total = 467 * 2
     per = r["config"]["graphs_per_gpu"]
     assert (per == total) if scaling == "weak" else (0 < per < total)
