@@ -13,7 +13,8 @@ struct ShmpArgs {
   int64_t row0, num_rows;
   int S, sm, st;
   const float* wt;          // f32 mode: [(sm+1)*64][64]
-  const short* wplanes;     // x6 mode: [3][64 n][(sm+1)*64 k] bf16 planes (hi, mid, lo)
+  const short* wplanes;     // x6 mode: [3][64 n][(sm+1)*64 k] bf16 planes (hi, mid, lo); f16x3 mode: [2][64 n][..] fp16 (hi, lo)
+  const float* wscale;      // f16x3 mode: device {scale, 1/scale} of the weight planes (desco_split_f16x2_f32); else null
   const float* bias;
   const float* ytab;
   int64_t ldy, ytab_row0;

@@ -803,12 +803,12 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                        float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream,
                        const uint32_t* pool_bits = nullptr, const int32_t* pool_slot = nullptr,
-                       float* pool_part = nullptr) {
+                       float* pool_part = nullptr, const float* wscale = nullptr) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
   const bool pool = pool_part != nullptr;
-  const int tile_rows = x6 ? shmp_tile_rows() : 32;
+  const int tile_rows = wscale ? 16 : x6 ? shmp_tile_rows() : 32;      // (the fp16 form exists for 16-row tiles only)
   if (pool && (!pool_bits || !pool_slot || row0 % tile_rows || mis16(pool_part) || out2 || !x6 || slots_mfma != 2 ||
                slots_table != 2))
     return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % tile rows, no out2, "
@@ -841,6 +841,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              slots_table,
              x6 ? nullptr : static_cast<const float*>(weights),
              x6 ? static_cast<const short*>(weights) : nullptr,
+             wscale,
              bias,
              ytab,
              ldy,
@@ -916,6 +917,38 @@ extern "C" int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, con
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
                             ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
                             pool_bits, pool_slot, pool_part);
+}
+
+// The same layer in the three-product fp16 form (16-row tiles): wt_planes[2][64 n][(slots_mfma+1)*64 k] and
+// w_scale[2] = {scale, 1/scale} (device) from desco_split_f16x2_f32; row scales are found in the kernel.
+extern "C" int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                          const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                          int slots_stored, int slots_mfma, int slots_table,
+                                          const int16_t* wt_planes, const float* w_scale, const float* bias,
+                                          const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                          float* out, int64_t ldo, float* out2, int64_t ldo2,
+                                          desco_stream_t stream) {
+  if (!w_scale) return desco::fail(DESCO_EINVAL, "desco_shmp_layer_f16x3_f32: w_scale is null");
+  return desco::shmp_launch("desco_shmp_layer_f16x3_f32", true, x, ldx, vrowptr, vcol, row0,
+                            num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
+                            ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream, nullptr, nullptr,
+                            nullptr, w_scale);
+}
+
+extern "C" int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                               const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                               int slots_stored, int slots_mfma, int slots_table,
+                                               const int16_t* wt_planes, const float* w_scale, const float* bias,
+                                               const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                               float* out, int64_t ldo, const uint32_t* pool_bits,
+                                               const int32_t* pool_slot, float* pool_part,
+                                               desco_stream_t stream) {
+  if (!pool_part || !w_scale)
+    return desco::fail(DESCO_EINVAL, "desco_shmp_layer_pool_f16x3_f32: pool_part / w_scale is null");
+  return desco::shmp_launch("desco_shmp_layer_pool_f16x3_f32", true, x, ldx, vrowptr, vcol, row0,
+                            num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
+                            ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
+                            pool_bits, pool_slot, pool_part, w_scale);
 }
 
 extern "C" int desco_shmp_pool_tile_rows(void) { return desco::shmp_tile_rows(); }

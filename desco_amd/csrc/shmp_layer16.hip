@@ -37,9 +37,13 @@ constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 2;
 constexpr int EXTRA_STEPS = 9; // batched 2-source steps after the prefetched one (<= 20 sources per row)
 constexpr int WCAP = 200;     // source ids staged per wave and buffer (longer slices fall back to global)
-constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(16*33, 3*16*32/2) floats
+constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(16*36, 3*16*32/2) floats (bf16x6 form)
 constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
+// fp16 three-product form: two planes (512 floats) < the fp32 table image (576); + 16 row scales per wave
+constexpr int A_FLOATS_F16 = WR * AH;
+constexpr int WAVE_LDS_F16 = A_FLOATS_F16 + 2 * RPN + 2 * WCAP + WR;
+static_assert(A_FLOATS_F16 >= 2 * WR * APS / 2, "the fp16 planes must fit in the image region");
 
 // absent sources of a batched gather step read this row instead of being predicated away
 __device__ __attribute__((aligned(16))) float shmp16_zero_row[64] = {};
@@ -315,6 +319,101 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
     DESCO_M16(ah_, b2m_, q2) DESCO_M16(ah_, b3m_, q3)                                             \
     DESCO_M16(ah_, b2h_, q2) DESCO_M16(ah_, b3h_, q3)                                             \
   }
+// ---- fp16 three-product form (common_device.hpp: x s = hi + lo, hi*hi + hi*lo + lo*hi) --------------------------------
+// Row scales.  The operands of a row are multiplied by ONE power of two per row, re-chosen only when a K block does not
+// fit under it.  The lane group that holds a row reduces the maximum of its 64 gathered sums (3 DPP steps over the
+// group's 8 lanes); the accumulators (C/D layout: lane quarter g holds rows 4 g + e) follow a change of scale by an
+// exact multiplication and leave the scales in the epilogue.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+// (a chain: hipcc folds it into four v_max3_f32 with |.| source modifiers)
+#define DESCO_ABSMAX8(a_, b_)                                                                                   \
+  fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fabsf(a_.x), fabsf(a_.y)), fabsf(a_.z)), fabsf(a_.w)), fabsf(b_.x)), \
+                    fabsf(b_.y)), fabsf(b_.z)), fabsf(b_.w))
+// max over the 8 lanes of a lane group (non-negative floats compared as unsigned integers)
+#define DESCO_GROUP_MAX(m_)                                                                                     \
+  {                                                                                                             \
+    uint32_t v_ = __float_as_uint(m_);                                                                          \
+    uint32_t o_ = __builtin_amdgcn_update_dpp(0u, v_, 0xB1, 0xf, 0xf, true);  /* quad_perm [1,0,3,2] */         \
+    v_ = v_ > o_ ? v_ : o_;                                                                                     \
+    o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x4E, 0xf, 0xf, true);           /* quad_perm [2,3,0,1] */         \
+    v_ = v_ > o_ ? v_ : o_;                                                                                     \
+    o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x141, 0xf, 0xf, true);          /* row_half_mirror */             \
+    v_ = v_ > o_ ? v_ : o_;                                                                                     \
+    m_ = __uint_as_float(v_);                                                                                   \
+  }
+// Scales of this lane group's two rows for the block whose sums are complete.  A row keeps its scale from block to
+// block as long as the new block fits under it (scaled maximum < 2^15.9; a fresh scale puts the maximum at 2^12 ..
+// 2^13, so later blocks may be 8x larger; blocks that are smaller lose absolute precision only relative to the row's
+// LARGEST block, which is what their common output sum is accurate to anyway): the common case is a maximum, two
+// multiplications and one wave vote.  When a row of the tile does not fit (or has no scale yet: the tile's first
+// block with a source for it), the rows that need it take a new scale, the scales cross to the C/D layout through LDS
+// (sentinel 0 = unchanged) and the accumulators follow by an exact multiplication.
+#define DESCO_BLOCK_SCALES()                                                                                    \
+  {                                                                                                             \
+    float m0_ = DESCO_ABSMAX8(lo0, hi0), m1_ = DESCO_ABSMAX8(lo1, hi1);                                         \
+    DESCO_GROUP_MAX(m0_) DESCO_GROUP_MAX(m1_)                                                                   \
+    const bool o0_ = m0_ * sc0 > 60000.f || (sc0 == 0.f && m0_ > 0.f);                                          \
+    const bool o1_ = m1_ * sc1 > 60000.f || (sc1 == 0.f && m1_ > 0.f);                                          \
+    if (__any(o0_ | o1_)) {                                                                                     \
+      const float s0_ = f16_scale_for(m0_) * 0.25f, s1_ = f16_scale_for(m1_) * 0.25f;                           \
+      if (o0_) sc0 = s0_;                                                                                       \
+      if (o1_) sc1 = s1_;                                                                                       \
+      rs[g8] = o0_ ? s0_ : 0.f;                                                                                 \
+      rs[8 + g8] = o1_ ? s1_ : 0.f;                                                                             \
+      const float4 n_ = *reinterpret_cast<const float4*>(rs + 4 * (lane >> 4));                                 \
+      const float n0_ = n_.x > 0.f ? n_.x : cs[0], n1_ = n_.y > 0.f ? n_.y : cs[1];                             \
+      const float n2_ = n_.z > 0.f ? n_.z : cs[2], n3_ = n_.w > 0.f ? n_.w : cs[3];                             \
+      const f32x4 r_ = {n0_ * pow2_inverse(cs[0]), n1_ * pow2_inverse(cs[1]), n2_ * pow2_inverse(cs[2]),        \
+                        n3_ * pow2_inverse(cs[3])};                                                             \
+      q0 *= r_; q1 *= r_; q2 *= r_; q3 *= r_;                                                                   \
+      cs = f32x4{n0_, n1_, n2_, n3_};                                                                           \
+    }                                                                                                           \
+  }
+// write one half image as two fp16 planes (same addressing as the bf16 planes)
+#define DESCO_PUT_F16(av_, it_, sc_)                                            \
+  {                                                                             \
+    uint32_t h0_, l0_, h1_, l1_;                                                \
+    split2_f16x2(av_.x * (sc_), av_.y * (sc_), h0_, l0_);                       \
+    split2_f16x2(av_.z * (sc_), av_.w * (sc_), h1_, l1_);                       \
+    short* d_ = Ap + ((it_) * 8 + g8) * APS +                                   \
+                ((((l8 >> 1) ^ (0 - ((it_) * 2 + (g8 >> 2)))) & 3) << 3) + 4 * (l8 & 1); \
+    *reinterpret_cast<uint2*>(d_) = make_uint2(h0_, h1_);                       \
+    *reinterpret_cast<uint2*>(d_ + WR * APS) = make_uint2(l0_, l1_);            \
+  }
+#define DESCO_F16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0);
+// 12 fp16 MFMAs (3-product split) on the staged half (32 k) of block b_
+#define DESCO_MFMA_HALF_F16(b_, h_)                                                               \
+  {                                                                                               \
+    const short* ap_ = Ap + (lane & 15) * APS + ((((lane >> 4) ^ (0 - (lane >> 2))) & 3) << 3);   \
+    const short* bp_ = Wp + (lane & 15) * WST + (b_) * 64 + (h_) * 32 + 8 * (lane >> 4);          \
+    const f16x8 ah_ = *reinterpret_cast<const f16x8*>(ap_);                                       \
+    const f16x8 al_ = *reinterpret_cast<const f16x8*>(ap_ + WR * APS);                            \
+    const f16x8 b0h_ = *reinterpret_cast<const f16x8*>(bp_);                                      \
+    const f16x8 b0l_ = *reinterpret_cast<const f16x8*>(bp_ + WPL);                                \
+    const f16x8 b1h_ = *reinterpret_cast<const f16x8*>(bp_ + 16 * WST);                           \
+    const f16x8 b1l_ = *reinterpret_cast<const f16x8*>(bp_ + 16 * WST + WPL);                     \
+    DESCO_F16(al_, b0h_, q0) DESCO_F16(al_, b1h_, q1)                                             \
+    DESCO_F16(ah_, b0l_, q0) DESCO_F16(ah_, b1l_, q1)                                             \
+    const f16x8 b2h_ = *reinterpret_cast<const f16x8*>(bp_ + 32 * WST);                           \
+    const f16x8 b2l_ = *reinterpret_cast<const f16x8*>(bp_ + 32 * WST + WPL);                     \
+    const f16x8 b3h_ = *reinterpret_cast<const f16x8*>(bp_ + 48 * WST);                           \
+    const f16x8 b3l_ = *reinterpret_cast<const f16x8*>(bp_ + 48 * WST + WPL);                     \
+    DESCO_F16(ah_, b0h_, q0) DESCO_F16(ah_, b1h_, q1)                                             \
+    DESCO_F16(al_, b2h_, q2) DESCO_F16(al_, b3h_, q3)                                             \
+    DESCO_F16(ah_, b2l_, q2) DESCO_F16(ah_, b3l_, q3)                                             \
+    DESCO_F16(ah_, b2h_, q2) DESCO_F16(ah_, b3h_, q3)                                             \
+  }
+// table half rows in the scaled accumulators: the (unscaled, fp32) table values enter at the rows' current scales
+// (the accumulators are in units of row scale x weight scale)
+#define DESCO_TAB_HALF_F16(qa_, qb_)                                                        \
+  {                                                                                        \
+    const f32x4 cw_ = cs * wsc;                                                            \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                     \
+      const float* t_ = Aw + (4 * (lane >> 4) + e_) * AH + (lane & 15);                    \
+      qa_[e_] += t_[0] * cw_[e_];                                                          \
+      qb_[e_] += t_[16] * cw_[e_];                                                         \
+    }                                                                                      \
+  }
 // add the staged (fp32) table half rows (32 columns) in the C/D layout of two 16-column tiles:
 // lane (c = lane&15, g = lane>>4) holds rows 4 g + e, column 16 t + c
 #define DESCO_TAB_HALF(qa_, qb_)                                                            \
@@ -334,7 +433,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #ifdef SH16_TAIL     // tail probe (tools/debug): per block its start and the end of its last wave, 100 MHz ticks
 __device__ unsigned long long sh16_tail[1024][2];
 #endif
-template <int NW, int KB, int ST, bool LD64, bool POOL>
+template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16>
 __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const int32_t* __restrict__ rowptr_s,
                                                               const uint32_t* __restrict__ pool_bits_s,
                                                               const int32_t* __restrict__ pool_slot_s) {
@@ -344,23 +443,28 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WST = KB * 64 + 16;                        // weight plane row stride (shorts): 32 B of padding, conflict-free B fragments
   constexpr int WPL = 64 * WST;                            // shorts per weight plane
-  constexpr int W_FLOATS = 3 * WPL / 2;
-  short* Wp = reinterpret_cast<short*>(lds);               // [3][64 n][WST]
+  constexpr int NP = F16 ? 2 : 3;                          // operand planes (fp16 hi / lo; bf16 hi / mid / lo)
+  constexpr int W_FLOATS = NP * WPL / 2;
+  constexpr int WAVE_LDS_ = F16 ? WAVE_LDS_F16 : WAVE_LDS;
+  constexpr int A_FLOATS_ = F16 ? A_FLOATS_F16 : A_FLOATS;
+  short* Wp = reinterpret_cast<short*>(lds);               // [NP][64 n][WST]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping stays in SGPRs
-  float* Aw = lds + W_FLOATS + wave * WAVE_LDS;            // fp32 half image [16][33] (table block)
-  short* Ap = reinterpret_cast<short*>(Aw);                // bf16 planes [3][16][32] of a half image
-  int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS);        // 2 x [16*S+1] row pointers (absolute)
+  float* Aw = lds + W_FLOATS + wave * WAVE_LDS_;           // fp32 half image [16][36] (table block)
+  short* Ap = reinterpret_cast<short*>(Aw);                // operand planes [NP][16][32] of a half image
+  int* rpb = reinterpret_cast<int*>(Aw + A_FLOATS_);       // 2 x [16*S+1] row pointers (absolute)
   int* ecb = rpb + 2 * RPN;                                // 2 x [WCAP] source ids (current / next tile)
   int* ec = ecb;
-  float* biasL = lds + W_FLOATS + NW * WAVE_LDS;           // [64] bias (zeros without one), block-shared
+  float* rs = reinterpret_cast<float*>(ecb + 2 * WCAP);    // F16: [16] row scales of the block being staged
+  (void)rs;
+  float* biasL = lds + W_FLOATS + NW * WAVE_LDS_;          // [64] bias (zeros without one), block-shared
   int* next_sub = reinterpret_cast<int*>(biasL + 64);      // the block's tile hand-out counter
 
   // ---- resident weights -------------------------------------------------------------------
   {
-    // global planes [3][64][KB*64] -> LDS [3][64][WST], 16 bytes at a time
+    // global planes [NP][64][KB*64] -> LDS [NP][64][WST], 16 bytes at a time
     constexpr int CH = KB * 8;                             // uint4 chunks per row
-    for (int i = tid; i < 3 * 64 * CH; i += NW * 64) {
+    for (int i = tid; i < NP * 64 * CH; i += NW * 64) {
       const int row = i / CH, ch = i - row * CH;           // row = plane*64 + n
       *reinterpret_cast<uint4*>(Wp + row * WST + 8 * ch) =
           *reinterpret_cast<const uint4*>(g.wplanes + (int64_t)row * (KB * 64) + 8 * ch);
@@ -374,6 +478,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   __syncthreads();
 
   const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
+  const float wsc = F16 ? g.wscale[0] : 1.f;               // power-of-two scale of the weight planes ...
+  const float winv = F16 ? g.wscale[1] : 1.f;              // ... and its inverse
+  (void)wsc;
   const int S = g.S;
   const int nslot = WR * S + 1;                            // <= 65: at most 2 per lane
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
@@ -503,7 +610,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 
     // ---- accumulator init: bias ----------------------------------------------------------------
     f32x4 q0, q1, q2, q3;                        // 16 rows x 64 columns: four 16-column tiles
-    {
+    f32x4 cs = {1.f, 1.f, 1.f, 1.f};             // F16: current scale of rows 4 (lane >> 4) + e of the accumulators
+    float sc0 = 0.f, sc1 = 0.f;                  // F16: the same scales in the gather layout: rows g8 and 8 + g8
+    (void)cs; (void)sc0; (void)sc1;              //      (0 = the row has had no non-zero block yet: its operands are zeros)
+    if constexpr (F16) {
+      q0 = q1 = q2 = q3 = f32x4{0.f, 0.f, 0.f, 0.f};         // (the bias joins in the epilogue, behind the scales)
+    } else {
       const int c_ = lane & 15;
       const float b0_ = biasL[c_], b1_ = biasL[16 + c_], b2_ = biasL[32 + c_], b3_ = biasL[48 + c_];
       q0 = f32x4{b0_, b0_, b0_, b0_};
@@ -556,7 +668,12 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
       //      under this block's MFMAs (after the low halves have left their registers)
       {
         if (b < KB) {
-          DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1)
+          if constexpr (F16) {
+            DESCO_BLOCK_SCALES()
+            DESCO_PUT_F16(lo0, 0, sc0) DESCO_PUT_F16(lo1, 1, sc1)
+          } else {
+            DESCO_PUT_X6(lo0, 0) DESCO_PUT_X6(lo1, 1)
+          }
         } else {
           DESCO_PUT_F32(lo0, 0) DESCO_PUT_F32(lo1, 1)
         }
@@ -564,19 +681,39 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
       DESCO_ISSUE_AFTER(b)
       {
         if (b >= KB) {
-          DESCO_TAB_HALF(q0, q1)
+          if constexpr (F16) {
+            DESCO_TAB_HALF_F16(q0, q1)
+          } else {
+            DESCO_TAB_HALF(q0, q1)
+          }
         } else {
-          DESCO_MFMA_HALF_X6(b, 0)
+          if constexpr (F16) {
+            DESCO_MFMA_HALF_F16(b, 0)
+          } else {
+            DESCO_MFMA_HALF_X6(b, 0)
+          }
         }
         if (b < KB) {
-          DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1)
+          if constexpr (F16) {
+            DESCO_PUT_F16(hi0, 0, sc0) DESCO_PUT_F16(hi1, 1, sc1)
+          } else {
+            DESCO_PUT_X6(hi0, 0) DESCO_PUT_X6(hi1, 1)
+          }
         } else {
           DESCO_PUT_F32(hi0, 0) DESCO_PUT_F32(hi1, 1)
         }
         if (b >= KB) {
-          DESCO_TAB_HALF(q2, q3)
+          if constexpr (F16) {
+            DESCO_TAB_HALF_F16(q2, q3)
+          } else {
+            DESCO_TAB_HALF(q2, q3)
+          }
         } else {
-          DESCO_MFMA_HALF_X6(b, 1)
+          if constexpr (F16) {
+            DESCO_MFMA_HALF_F16(b, 1)
+          } else {
+            DESCO_MFMA_HALF_X6(b, 1)
+          }
         }
       }
     }
@@ -607,6 +744,17 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     //      quarter t: v_permlane32_swap, then v_permlane16_swap) leaves lane = column with the 16 rows
     //      of the tile in registers, row 4 t + e in q_t[e]: every store is one full 256-byte row, and
     //      the pooling pass is a running sum in row order ------------------------------------------------
+    if constexpr (F16) {
+      // leave the scales (exact: powers of two) and add the bias: row 4 g + e of column 16 t + c
+      const int c_ = lane & 15;
+      const float b0_ = biasL[c_], b1_ = biasL[16 + c_], b2_ = biasL[32 + c_], b3_ = biasL[48 + c_];
+      const f32x4 f_ = {pow2_inverse(cs[0]) * winv, pow2_inverse(cs[1]) * winv, pow2_inverse(cs[2]) * winv,
+                        pow2_inverse(cs[3]) * winv};
+      q0 = q0 * f_ + b0_;
+      q1 = q1 * f_ + b1_;
+      q2 = q2 * f_ + b2_;
+      q3 = q3 * f_ + b3_;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       q0[e] = apply_act(q0[e], g.act, g.slope);
@@ -709,33 +857,40 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_M16
 #undef DESCO_MFMA_HALF_X6
 #undef DESCO_TAB_HALF
+#undef DESCO_TAB_HALF_F16
+#undef DESCO_MFMA_HALF_F16
+#undef DESCO_F16
+#undef DESCO_PUT_F16
+#undef DESCO_BLOCK_SCALES
+#undef DESCO_GROUP_MAX
+#undef DESCO_ABSMAX8
 
-template <int NW, int KB, int ST, bool LD64, bool POOL>
+template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16>
 static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 16;
-  constexpr size_t w_floats = (size_t)3 * 64 * WST / 2;
-  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * WAVE_LDS + 64 + 4);
+  constexpr size_t w_floats = (size_t)(F16 ? 2 : 3) * 64 * WST / 2;
+  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * (F16 ? WAVE_LDS_F16 : WAVE_LDS) + 64 + 4);
   static_assert(shmem <= 160 * 1024, "SHMP layer (16-row tiles): LDS budget exceeded");
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer16_kernel<NW, KB, ST, LD64, POOL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.mark();
   }
-  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL>), dim3(grid), dim3(NW * 64), shmem, st, g,
+  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16>), dim3(grid), dim3(NW * 64), shmem, st, g,
                      g.vrowptr, g.pool_bits, g.pool_slot);
 }
 
-template <int NW, int KB>
+template <int NW, int KB, bool F16>
 static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st) && (!g.out || g.ldo == 64);
   if (g.pool_part) {
     if constexpr (KB == 3) {
       if (g.st != 2) return false;
       if (ld64)
-        shmp16_launch_one<NW, 3, 2, true, true>(g, grid, st);
+        shmp16_launch_one<NW, 3, 2, true, true, F16>(g, grid, st);
       else
-        shmp16_launch_one<NW, 3, 2, false, true>(g, grid, st);
+        shmp16_launch_one<NW, 3, 2, false, true, F16>(g, grid, st);
       return true;
     } else {
       return false;
@@ -743,9 +898,9 @@ static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   }
 #define DESCO_ONE(ST_)                                \
   if (ld64)                                           \
-    shmp16_launch_one<NW, KB, ST_, true, false>(g, grid, st);    \
+    shmp16_launch_one<NW, KB, ST_, true, false, F16>(g, grid, st);    \
   else                                                \
-    shmp16_launch_one<NW, KB, ST_, false, false>(g, grid, st);
+    shmp16_launch_one<NW, KB, ST_, false, false, F16>(g, grid, st);
   switch (g.st) {
     case 0: DESCO_ONE(0) break;
     case 1: DESCO_ONE(1) break;
@@ -756,14 +911,14 @@ static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   return true;
 }
 
-template <int NW>
+template <int NW, bool F16>
 static bool shmp16_launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
   const int64_t ntiles = (g.num_rows + NW * WR - 1) / (NW * WR);
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   switch (g.sm) {
-    case 0: return shmp16_launch_st<NW, 1>(g, grid, st);
-    case 1: return shmp16_launch_st<NW, 2>(g, grid, st);
-    default: return shmp16_launch_st<NW, 3>(g, grid, st);
+    case 0: return shmp16_launch_st<NW, 1, F16>(g, grid, st);
+    case 1: return shmp16_launch_st<NW, 2, F16>(g, grid, st);
+    default: return shmp16_launch_st<NW, 3, F16>(g, grid, st);
   }
 }
 
@@ -771,7 +926,8 @@ static bool shmp16_launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
 bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
   if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
   // 16 waves per block (12 x 16 rows measured 2-6 % slower: profiles/r2_h_ab_tile_rows.log)
-  return shmp16_launch_nw<16>(g, cus, (hipStream_t)stream);
+  if (g.wscale) return shmp16_launch_nw<16, true>(g, cus, (hipStream_t)stream);     // fp16 three-product planes
+  return shmp16_launch_nw<16, false>(g, cus, (hipStream_t)stream);
 }
 
 }  // namespace desco

@@ -41,6 +41,9 @@ GEMM_BF16X6 = True
 GEMM_F16X3 = os.environ.get("DESCO_GEMM_F16X3", "1") != "0"
 # True: the fused SHMP layer's MFMA blocks also run as the bf16x6 split (csrc/shmp_layer.hip, K <= 192)
 SHMP_BF16X6 = True
+# ... in the three-product fp16 form with per-row power-of-two scales (csrc/shmp_layer16.hip, F16 instantiations); needs
+# SHMP_BF16X6 and 16-row wave tiles
+SHMP_F16X3 = os.environ.get("DESCO_SHMP_F16X3", "1") != "0"
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
@@ -342,10 +345,12 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
                 if bf16_planes and GEMM_BF16X6:
                     entry["wt_tab_l64"] = ops.linear64_planes(entry["wt_tab"].t())     # [2,3,64,64]
             if bf16_planes and SHMP_BF16X6:
-                # n-major bf16 planes of the MFMA blocks for the x6 form of the fused layer (K <= 192)
+                # n-major operand planes of the MFMA blocks of the fused layer (K <= 192): fp16 (hi, lo) + one scale
+                # per matrix, or bf16 (hi, mid, lo)
+                f16 = SHMP_F16X3 and ops.pool_tile_rows() == 16
                 for name in ("wt_mfma", "wt"):
                     if name in entry and entry[name].shape[0] <= 192:
-                        entry[name + "_x6"] = ops.split_bf16_planes(entry[name].t())
+                        entry[name + "_x6"] = (ops.split_f16_planes if f16 else ops.split_bf16_planes)(entry[name].t())
             per_type[t] = entry
         pk["layers"].append(per_type)
     pk["anchor"] = _lin_t(gnn.anchor_mlp[0])

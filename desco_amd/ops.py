@@ -235,11 +235,14 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     ``pool`` = (pool_bits, pool_slot, pool_part): also leave the per-(tile, segment) partial sums of
     the produced rows in ``pool_part`` (fused global_add_pool, finished by ``pool_reduce``); ``out``
     may then be None (rows not stored)."""
-    x6 = wt.dtype == torch.int16
+    f16 = isinstance(wt, F16Planes)
+    x6 = f16 or wt.dtype == torch.int16
     if pool is not None:
         return _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out,
                                 ytab, ytab_row0, pool)
-    if x6:
+    if f16:
+        assert wt.planes.is_contiguous() and wt.planes.shape == (2, 64, (slots_mfma + 1) * 64)
+    elif x6:
         assert wt.is_contiguous() and wt.shape == (3, 64, (slots_mfma + 1) * 64)
     else:
         assert wt.is_contiguous() and wt.shape == ((slots_mfma + 1) * 64, 64)
@@ -251,24 +254,28 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
         yp, ldy = _rows(ytab, "ytab")
     o2p, ldo2 = (None, 0) if out2 is None else _rows(out2, "out2")
     L = _lib.lib()
-    fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
     # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
     # profiler key = the device kernel's template instance (KB = sm + 1 weight blocks, ST table slots)
-    with _Timed(shmp_kernel_name(slots_mfma + 1, st, x6), fl, nb):
-        _lib.check(fn(xp, ldx, _dev(vrowptr, "vrowptr", torch.int32),
-                      _dev(vcol, "vcol", torch.int32), row0, num_rows,
-                      slots_stored, slots_mfma, st, _dev(wt, "wt", wt.dtype),
-                      _dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0,
-                      op, ldo, o2p, ldo2, _stream()), "shmp_layer")
+    with _Timed(shmp_kernel_name(slots_mfma + 1, st, x6, f16), fl, nb):
+        head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
+                slots_stored, slots_mfma, st)
+        tail = (_dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0, op, ldo, o2p, ldo2, _stream())
+        if f16:
+            rc = L.desco_shmp_layer_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16), _dev(wt.scale, "w_scale"), *tail)
+        else:
+            fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
+            rc = fn(*head, _dev(wt, "wt", wt.dtype), *tail)
+        _lib.check(rc, "shmp_layer")
     return out
 
 
 def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out, ytab,
                      ytab_row0, pool):
     bits, slot, part = pool
-    assert wt.dtype == torch.int16 and wt.is_contiguous() and ytab is not None
+    f16 = isinstance(wt, F16Planes)
+    assert ytab is not None and (f16 or (wt.dtype == torch.int16 and wt.is_contiguous()))
     xp, ldx = _rows(x, "x")
     op, ldo = (None, 0) if out is None else _rows(out, "out")
     st = ytab.shape[1] // 64
@@ -278,12 +285,17 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
     # x once (+ out once when stored) + indices + the partial rows (about one per 32 rows + one per segment)
     nb = (256.0 if out is None else 512.0) * num_rows + 4.0 * (num_rows * slots_stored +
                                                                 vcol.numel() * num_rows / max(x.shape[0], 1))
-    with _Timed(shmp_kernel_name(slots_mfma + 1, st, True), fl, nb):
-        _lib.check(L.desco_shmp_layer_pool_bf16x6_f32(
-            xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
-            slots_stored, slots_mfma, st, _dev(wt, "wt", torch.int16), _dev(bias.contiguous(), "bias"), yp, ldy,
-            ytab_row0, op, ldo, _dev(bits, "pool_bits", torch.int32), _dev(slot, "pool_slot", torch.int32),
-            _dev(part, "pool_part"), _stream()), "shmp_layer_pool")
+    with _Timed(shmp_kernel_name(slots_mfma + 1, st, True, f16), fl, nb):
+        head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
+                slots_stored, slots_mfma, st)
+        tail = (_dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0, op, ldo, _dev(bits, "pool_bits", torch.int32),
+                _dev(slot, "pool_slot", torch.int32), _dev(part, "pool_part"), _stream())
+        if f16:
+            rc = L.desco_shmp_layer_pool_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16),
+                                                   _dev(wt.scale, "w_scale"), *tail)
+        else:
+            rc = L.desco_shmp_layer_pool_bf16x6_f32(*head, _dev(wt, "wt", torch.int16), *tail)
+        _lib.check(rc, "shmp_layer_pool")
     return out
 
 
@@ -307,9 +319,12 @@ def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_
     return out
 
 
-def shmp_kernel_name(kb: int, st: int, x6: bool) -> str:
+def shmp_kernel_name(kb: int, st: int, x6: bool, f16: bool = False) -> str:
     """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
-    the bf16x6 form unless DESCO_SHMP_ROWS=32) and its <weight blocks, table slots>."""
+    the bf16x6 form unless DESCO_SHMP_ROWS=32; always for the fp16 three-product form) and its
+    <weight blocks, table slots>."""
+    if f16:
+        return f"shmp_layer16_kernel<{kb},{st},f16x3>"
     if x6 and pool_tile_rows() == 16:
         return f"shmp_layer16_kernel<{kb},{st}>"
     return f"shmp_layer_f32_kernel<{kb},{st},{'x6' if x6 else 'f32'}>"

@@ -266,6 +266,23 @@ int desco_shmp_layer_pool_bf16x6_f32(const float* x, int64_t ldx, const int32_t*
                                      int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                                      const uint32_t* pool_bits, const int32_t* pool_slot,
                                      float* pool_part, desco_stream_t stream);
+/* The same fused layer (and its pooling variant) in the THREE-product fp16 form (csrc/shmp_layer16.hip, 16-row wave
+ * tiles): wt_planes[2][64 n][(slots_mfma+1)*64 k] fp16 (hi, lo) and w_scale[2] = {scale, 1/scale} on the device, both
+ * from desco_split_f16x2_f32 of the transposed folded weight; slots_mfma <= 2.  The activation side is scaled inside
+ * the kernel: one power of two per (row, K block) -- the largest |value| of the row's 64 gathered sums -> [2^14,
+ * 2^15) --, the accumulators follow by exact multiplications and leave the scales in the epilogue. */
+int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
+                               int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
+                               int slots_table, const int16_t* wt_planes, const float* w_scale,
+                               const float* bias, const float* ytab, int64_t ldy, int64_t ytab_row0,
+                               float* out, int64_t ldo, float* out2, int64_t ldo2, desco_stream_t stream);
+int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
+                                    int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
+                                    int slots_table, const int16_t* wt_planes, const float* w_scale,
+                                    const float* bias, const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                    float* out, int64_t ldo, const uint32_t* pool_bits,
+                                    const int32_t* pool_slot, float* pool_part, desco_stream_t stream);
+
 int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, const int32_t* pool_slot,
                           const int32_t* seg_ptr, int64_t num_seg, const float* extra,
                           int64_t ld_extra, float* out, int64_t ldo, int tile_rows,

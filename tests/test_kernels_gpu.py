@@ -193,10 +193,10 @@ def test_gossip_layer0_and_gather():
 @pytest.mark.parametrize("S,sm,st", [(4, 3, 0), (4, 2, 0), (2, 2, 0), (4, 2, 2), (1, 1, 0), (4, 0, 1), (4, 3, 1)])
 @pytest.mark.parametrize("num_rows,row0,max_deg", [(1, 0, 3), (63, 5, 4), (256, 0, 2), (1000, 17, 9),
                                                    (333, 0, 70), (70000, 3, 3), (70000, 0, 6)])
-@pytest.mark.parametrize("x6", [False, True])
+@pytest.mark.parametrize("x6", [False, True, "f16x3"])
 def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
     if x6 and sm > 2:
-        pytest.skip("bf16x6 form holds at most three resident weight blocks")
+        pytest.skip("the split forms hold at most three resident weight blocks")
     g = torch.Generator().manual_seed(S * 1000 + sm * 100 + st * 10 + num_rows)
     n_all = row0 + num_rows + 9
     x = torch.randn(n_all, 64, generator=g)
@@ -217,7 +217,8 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
         ytab = ytab_cpu.to(DEV)
     ref = torch.relu(ref)[row0:row0 + num_rows]
     out = torch.full((n_all, 64), -7.0, device=DEV)
-    w_dev = ops.split_bf16_planes(wt.t().contiguous().to(DEV)) if x6 else wt.to(DEV)
+    w_dev = (ops.split_f16_planes(wt.t().contiguous().to(DEV)) if x6 == "f16x3" else
+             ops.split_bf16_planes(wt.t().contiguous().to(DEV)) if x6 else wt.to(DEV))
     ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, w_dev,
                    bias.to(DEV), out, ytab=ytab, ytab_row0=0)
     _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
@@ -226,7 +227,8 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
 
 
 @pytest.mark.parametrize("S,sm,st", [(4, 2, 2), (4, 2, 0), (2, 1, 0)])
-def test_fused_shmp_layer_strided_operands(S, sm, st):
+@pytest.mark.parametrize("f16", [False, True])
+def test_fused_shmp_layer_strided_operands(S, sm, st, f16):
     """The general-stride instantiations of the bf16x6 layer kernel (LD64 = false): x, the table and the
     output are column blocks of wider tensors (ldx = 96, ldy = 64 st + 32, ldo = 128)."""
     num_rows, row0, max_deg = 3000, 16, 7
@@ -252,8 +254,9 @@ def test_fused_shmp_layer_strided_operands(S, sm, st):
     ref = torch.relu(ref)[row0:row0 + num_rows]
     outw = torch.full((n_all, 128), -7.0, device=DEV)
     out = outw[:, 32:96]
+    split = ops.split_f16_planes if f16 else ops.split_bf16_planes
     ops.shmp_layer(xw.to(DEV)[:, 16:80], ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm,
-                   ops.split_bf16_planes(wt.t().contiguous().to(DEV)), bias.to(DEV), out, ytab=ytab, ytab_row0=0)
+                   split(wt.t().contiguous().to(DEV)), bias.to(DEV), out, ytab=ytab, ytab_row0=0)
     _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
     assert (outw[:, :32] == -7.0).all() and (outw[:, 96:] == -7.0).all() and (outw[:row0] == -7.0).all()
 
@@ -512,3 +515,51 @@ def test_gemm_f16x3_weight_scale_and_planes():
     rec = (planes[0] + planes[1]) / scale[0].double()
     err = (rec - w.double()).abs()
     assert bool((err <= torch.clamp(2.0 ** -22 * w.double().abs(), min=2.0 ** -25 / scale[0].item())).all())
+
+
+@pytest.mark.parametrize("kind", ["O(1)", "rows_2^+-16", "1e5", "1e-4", "hub"])
+def test_fused_shmp_layer_f16x3_is_fp32_accurate_over_the_fp32_range(kind):
+    """The fp16 three-product layer against fp64, next to the bf16x6 and f32-MFMA forms of the same launch: error
+    relative to sum |a||w| per output (the scale fp32 rounding errors live on).  Rows of very different magnitude
+    share 16-row tiles (per-row power-of-two scales), all-zero slots and rows keep their scale, hub rows sum hundreds
+    of sources."""
+    S, sm, st, num_rows, row0 = 4, 2, 2, 5000, 0
+    g = torch.Generator().manual_seed(len(kind))
+    n_all = num_rows + 16
+    x = torch.randn(n_all, 64, generator=g).abs()
+    if kind == "rows_2^+-16":
+        x = x * 2.0 ** torch.randint(-16, 17, (n_all, 1), generator=g).float()
+    elif kind == "1e5":
+        x = x * 1e5
+    elif kind == "1e-4":
+        x = x * 1e-4
+    ptr, col, cnt = _random_vcsr(n_all, S, 300 if kind == "hub" else 5, n_all, g)
+    wt = torch.randn((sm + 1) * 64, 64, generator=g) / 12
+    bias = torch.zeros(64)
+    wtab = torch.randn(64, 64 * st, generator=g) / 8
+    agg = torch.zeros(n_all * S, 64, dtype=torch.double)
+    agg.index_add_(0, torch.repeat_interleave(torch.arange(n_all * S), cnt), x.double()[col.long()])
+    aggv = agg.view(n_all, S * 64)
+    A = torch.cat([aggv[:, :sm * 64], x.double()], 1)
+    ytab_cpu = x @ wtab
+    ref = A @ wt.double()
+    mag = A.abs() @ wt.double().abs()
+    for s_ in range(st):
+        t_agg = torch.zeros(n_all, 64, dtype=torch.double)
+        rows = torch.repeat_interleave(torch.arange(n_all * S), cnt)
+        sel = (rows % S) == (sm + s_)
+        t_agg.index_add_(0, rows[sel] // S, ytab_cpu.double()[col.long()[sel], s_ * 64:(s_ + 1) * 64])
+        ref = ref + t_agg
+        mag = mag + t_agg.abs()
+    ref = torch.relu(ref)[:num_rows]
+    mag = mag[:num_rows].clamp_min(1e-300)
+    errs = {}
+    for name, w_dev in (("f16x3", ops.split_f16_planes(wt.t().contiguous().to(DEV))),
+                        ("bf16x6", ops.split_bf16_planes(wt.t().contiguous().to(DEV))), ("f32", wt.to(DEV))):
+        out = torch.empty((n_all, 64), device=DEV)
+        ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, w_dev, bias.to(DEV), out,
+                       ytab=ytab_cpu.to(DEV), ytab_row0=0)
+        errs[name] = ((out[:num_rows].cpu().double() - ref).abs() / mag).max().item()
+    print(f"[accuracy] shmp layer {kind}: max err / sum|a||w|  f16x3 {errs['f16x3']:.2e}  bf16x6 {errs['bf16x6']:.2e}  "
+          f"f32-MFMA {errs['f32']:.2e}")
+    assert errs["f16x3"] <= 2.0 * max(errs["f32"], errs["bf16x6"])
