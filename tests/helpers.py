@@ -70,6 +70,41 @@ def report(name, got, ref):
     return d.max().item()
 
 
+# ---- THE float tolerance of the HIP-vs-oracle gates (quoted in BASELINE.md section 2, DESIGN.md section 2, README) -------
+# Every comparison of model outputs with the CPU oracle -- log-space head outputs ("logits"), embeddings, counts --
+# uses ONE metric and ONE number:   max |got - ref| / (1 + |ref|)  <=  LOGIT_TOL,
+# counts c = 2**logit - 1 being compared as sign(c) log2(1 + |c|) (so that the gate means the same for a count of 0.1 and of 1e6).
+# Measured worst cases on the parity sets (printed by every test): logits 1.5e-5, node-level counts after both stages 3.4e-5 (neighborhood counts 1.8e-5),
+# embeddings 1.3e-6, gossip corrections 3.8e-6 absolute on magnitude 2.5.  5e-5 is 1.5x the worst of them (3x the worst logit figure) and
+# 20x below the smallest perturbation a wrong index or weight produces (see test_the_gate_catches_a_1e4_logit_error).
+LOGIT_TOL = 5e-5
+
+
+def log_space_err(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return ((got - ref).abs() / (1.0 + ref.abs())).max().item() if ref.numel() else 0.0
+
+
+def assert_logits_close(name, got, ref, tol=LOGIT_TOL):
+    """Gate on log-space quantities (head outputs, embeddings): prints the measured value, fails above ``tol``."""
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = log_space_err(got, ref)
+    print(f"[gate] {name}: max |got - ref| / (1 + |ref|) = {err:.2e} (gate {tol:.0e})")
+    assert err <= tol, f"{name}: {err:.3e} exceeds the gate {tol:.0e}"
+    return err
+
+
+def assert_counts_close(name, got, ref, tol=LOGIT_TOL):
+    """Gate on counts (2**logit - 1, their node / graph sums, gossip-corrected counts), compared in signed log space:
+    slog(c) = sign(c) log2(1 + |c|).  For c >= 0 that is log2(1 + c) = the logit; for the rare negative values (counts
+    of absent patterns are 2**logit - 1 in (-1, 0), the gossip stage adds a signed correction) it stays smooth where
+    log2(1 + c) would blow a 4e-6 absolute difference near c = -1 up to any size."""
+    slog = lambda c: torch.sign(c) * torch.log2(1.0 + c.abs())          # noqa: E731
+    g, r = got.detach().cpu().double(), ref.detach().cpu().double()
+    return assert_logits_close(name + " [signed log2(1+|count|)]", slog(g), slog(r), tol)
+
+
 def random_family_graphs(seed, count):
     """Graph families the fixtures do not hold: stars, wheels, paths, cycles, cliques with tails, grids, barbells, random
     trees, G(n,p) at three densities, graphs with isolated nodes and with several components."""

@@ -1,7 +1,7 @@
 """Model-level parity on the GPU: HIP path (through the C ABI) vs. the CPU oracle in the reference's
-form, same seeded weights, golden-fixture graphs.  fp32 tolerance: rtol 1e-4 / atol 1e-4 on the
-log-space head outputs and on gossip corrections (different but equivalent summation orders and
-folded weights; both sides are fp32)."""
+form, same seeded weights, golden-fixture graphs.  ONE float tolerance (tests/helpers.py: LOGIT_TOL = 5e-5 on
+max |got - ref| / (1 + |ref|), counts compared as log2(1 + count)); every gate prints what it measured.  Both sides
+are fp32; the HIP path folds weights and sums in other (equivalent) orders."""
 import numpy as np
 import pytest
 import torch
@@ -14,10 +14,11 @@ from desco_amd.partition import build_partition  # noqa: E402
 from oracle import model as OM  # noqa: E402
 from oracle import partition as OP  # noqa: E402
 
-from helpers import cpu_sd, golden_graphs, make_models, random_family_graphs, report, standard_queries  # noqa: E402
+from helpers import (LOGIT_TOL, assert_counts_close, assert_logits_close, cpu_sd, golden_graphs, make_models,  # noqa: E402
+                     random_family_graphs, report, standard_queries)
 
 DEV = "cuda"
-RTOL, ATOL = 1e-4, 1e-4
+RTOL, ATOL = LOGIT_TOL, LOGIT_TOL        # (legacy names: the one gate of tests/helpers.py)
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +36,7 @@ def test_query_embeddings(setup):
     got = nm.get_query_emb()
     ref = OM.neighborhood_embed_queries(cpu_sd(nm), OP.query_batch(queries), 8)
     report("query_emb", got, ref)
-    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5)        # measured 2.0e-6 (29 graphs, 135 nodes)
+    assert_logits_close("query_emb", got, ref, tol=1e-5)        # measured 1.5e-6 (29 graphs, 135 nodes): its own, tighter gate
 
 
 @pytest.mark.parametrize("quirk", [0, 512, 16])
@@ -56,9 +57,30 @@ def test_neighborhood_logits_vs_oracle(setup, quirk):
     with torch.no_grad():
         got = nm._logits(batch, exp2=False)
     report(f"neigh_logits quirk={quirk}", got, ref)
-    torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=ATOL)
+    assert_logits_close(f"neigh_logits quirk={quirk}", got, ref)
     cnt = nm.graph_to_count(batch)
-    torch.testing.assert_close(cnt.cpu(), 2 ** ref - 1, rtol=1e-3, atol=1e-3)
+    assert_counts_close(f"neigh_count quirk={quirk}", cnt, 2 ** ref - 1)
+
+
+def test_the_gate_catches_a_1e4_logit_error(setup):
+    """the gate must fail on a 1e-4 error.  One logit of a correct result is moved by
+    1e-4 (1 + |ref|) -- a fifth of what the old rtol = atol = 1e-3 count gates let through -- and both gates (logits,
+    counts in log space) must raise."""
+    nm, gm, qids, queries = setup
+    graphs = golden_graphs(max_n=41)
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs), OP.query_batch(queries), emulate_quirk=False)[0]
+    with torch.no_grad():
+        got = nm._logits(NeighborhoodBatch(part, DEV), exp2=False).cpu()
+    assert_logits_close("unperturbed logits", got, ref)
+    bad = got.clone()
+    i = int(ref.argmax())              # (a positive logit: its count 2**logit - 1 carries the error at full fp32 resolution)
+    bad.view(-1)[i] += 1e-4 * (1.0 + abs(float(ref.view(-1)[i])))
+    with pytest.raises(AssertionError):
+        assert_logits_close("perturbed logits", bad, ref)
+    with pytest.raises(AssertionError):
+        assert_counts_close("perturbed counts", 2 ** bad - 1, 2 ** ref - 1)
 
 
 def test_neighborhood_batch_slicing_equals_full(setup):
@@ -108,7 +130,7 @@ def test_end_to_end_pipeline_vs_oracle(setup):
     assert (pipe.partition.indicator == ref["indicator"]).all()
     for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
         report(k, out[k], ref[k])
-        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
+        assert_counts_close(k, out[k], ref[k])
 
 
 def test_full_size_run_is_replica_invariant(setup):
@@ -168,13 +190,13 @@ def test_full_size_dense_workloads_are_shard_invariant(workload):
         assert torch.isfinite(ref).all() and torch.isfinite(got).all(), key
         assert float(ref.abs().max()) > 1e-3 and float(ref.std()) > 0.0, key
         # counts are 2**logit - 1 with logits up to ~31 here: compared where they are computed, in log
-        # space, with the tolerance every logit comparison of this suite uses (rtol = atol = 1e-4)
+        # space, with the tolerance every comparison of this suite uses (helpers.LOGIT_TOL)
         lg = lambda c: torch.sign(c) * torch.log2(1.0 + c.abs().double())          # noqa: E731
         dev = (lg(got) - lg(ref)).abs()
         worst = float((dev / (1.0 + lg(ref).abs())).max())
         print(f"[property] {workload} {key}: whole vs two halves, worst log2-space deviation "
               f"{float(dev.max()):.2e} (relative {worst:.2e}); max |count| {float(ref.abs().max()):.3e}")
-        assert worst < 1e-4, (key, worst)
+        assert worst < LOGIT_TOL, (key, worst)
 
 
 @pytest.mark.parametrize("seed", [11, 12])
@@ -225,7 +247,7 @@ def test_mutag_shaped_pipeline_vs_oracle(setup):
     for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
         report("mutag " + k, out[k], ref[k])
         assert torch.isfinite(ref[k]).all() and float(ref[k].std()) > 0
-        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-3, atol=1e-3)
+        assert_counts_close("mutag " + k, out[k], ref[k])
 
 
 def test_gossip_conv_standalone_forward(setup):
@@ -827,13 +849,13 @@ def test_degenerate_inputs(setup):
     ref = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), graphs, queries, emulate_quirk=False)
     assert out["neigh_count"].shape == (2, 29) and out["node_count"].shape == (15, 29)
     for k in ("neigh_count", "node_count", "graph_neigh_count", "graph_gossip_count"):
-        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=1e-4, atol=1e-4)
+        assert_counts_close("degenerate " + k, out[k], ref[k])
     # nothing but isolated nodes: zero neighborhoods, gossip still runs on x = 0
     gs0 = GraphSet.from_edge_lists([(3, []), (2, [])])
     out0 = InferencePipeline(nm, gm, gs0, depth=4, device=DEV).run()
     ref0 = OM.reference_pipeline(cpu_sd(nm), cpu_sd(gm), [(3, []), (2, [])], queries, emulate_quirk=False)
     assert out0["neigh_count"].shape == (0, 29)
-    torch.testing.assert_close(out0["node_count"].cpu(), ref0["node_count"], rtol=1e-4, atol=1e-4)
+    assert_counts_close("isolated nodes node_count", out0["node_count"], ref0["node_count"])
     assert float(out0["graph_neigh_count"].abs().max()) == 0.0
 
 
@@ -881,5 +903,5 @@ def test_without_tconv_matches_oracle(setup):
         got_t = nm.emb_model(NeighborhoodBatch(part, DEV))
     report("no-tconv query_emb", got_q, emb_q)
     report("no-tconv target_emb", got_t, emb_t)
-    torch.testing.assert_close(got_q.cpu(), emb_q, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(got_t.cpu(), emb_t, rtol=1e-4, atol=1e-4)
+    assert_logits_close("no-tconv query_emb", got_q, emb_q)
+    assert_logits_close("no-tconv target_emb", got_t, emb_t)

@@ -86,7 +86,7 @@ def test_node_feature_model_vs_oracle():
     from desco_amd.batch import GossipBatch
     from desco_amd.lightning_model import GossipCountingModel, NeighborhoodCountingModel
     from desco_amd.workload import Workload
-    from helpers import cpu_sd, report
+    from helpers import assert_logits_close, cpu_sd, report
     from oracle import model as OM
     from oracle import partition as OP
     dev = "cuda"
@@ -120,9 +120,9 @@ def test_node_feature_model_vs_oracle():
     with torch.no_grad():
         got = nm._logits(batch, exp2=False)                        # 80 queries: three head launches
     report("node-feature logits", got, ref)
-    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert_logits_close("node-feature logits", got, ref)
     assert float(ref.std()) > 1e-3 and float((ref[:, 0] - ref[:, 1]).abs().max()) > 1e-4   # labels matter
-    torch.testing.assert_close(nm.get_query_emb().cpu(), emb_q, rtol=1e-4, atol=1e-4)
+    assert_logits_close("node-feature query_emb", nm.get_query_emb(), emb_q)
     # gossip over 80 query columns: two column groups of the scalars / fused launches
     g = torch.Generator().manual_seed(1)
     x = torch.rand(gs.num_nodes, 80, generator=g) * 20
@@ -131,7 +131,7 @@ def test_node_feature_model_vs_oracle():
     gref = OM.gossip_graph_to_count(cpu_sd(gm), x, gb.edge_index.numpy(), emb_q, 2) - x
     ggot = gm.graph_to_count(gb).cpu() - x
     report("node-feature gossip_corr", ggot, gref)
-    torch.testing.assert_close(ggot, gref, rtol=1e-4, atol=1e-4)
+    assert_logits_close("node-feature gossip_corr", ggot, gref)
     # training step with features: loss vs oracle
     y = torch.floor(torch.rand(len(nd), 80, generator=g) ** 3 * 40)
     nd.y = y
