@@ -133,7 +133,12 @@ class GossipConv(nn.Module):
             nn.Linear(out_channels, 1), nn.Sigmoid(), nn.LeakyReLU())
 
     def _gate_value(self, query_emb: torch.Tensor):
-        return self.lin_gate(query_emb)            # gnn_model.py:357-359 ([Q,1]; tiny, host-side op)
+        """lin_gate(query_emb) (gnn_model.py:294-301, 357-359) -> [Q, 1].  Written out: the 64 -> 1 Linear as a product
+        and a row sum instead of a matrix-vector product (rocBLAS gemv reduces with float atomics: see ``_mv``)."""
+        l0, l2 = self.lin_gate[0], self.lin_gate[2]
+        h = torch.sigmoid(torch.nn.functional.linear(query_emb, l0.weight, l0.bias))
+        g = torch.sigmoid((h * l2.weight[0]).sum(-1, keepdim=True) + l2.bias)
+        return torch.nn.functional.leaky_relu(g, self.lin_gate[4].negative_slope)
 
     def forward(self, x, edge_index, edge_weight=None, size=None, res_n_id=None, query_emb=None):
         """Stand-alone layer call with the reference's semantics (gnn_model.py:303-350) on device
@@ -295,6 +300,18 @@ class BaseGNN(nn.Module):
 # -------------------------------------------------------------------------------------------------
 # SHMP (neighborhood / query) path
 # -------------------------------------------------------------------------------------------------
+def _mv(A: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """A [..., m, k] times v [..., k] -> [..., m] as a broadcast product and a row sum.  torch routes a matrix-vector
+    product to rocBLAS gemv, whose split reduction uses float atomics: the folded weights -- and with them a seeded
+    training run -- were not reproducible from run to run.  This form is a fixed-order reduction."""
+    return (A * v.unsqueeze(-2)).sum(-1)
+
+
+def _vm(v: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
+    """v [k] times A [k, n] -> [n], same reason as ``_mv``."""
+    return (v.unsqueeze(-1) * A).sum(0)
+
+
 def _lin_t(lin: nn.Linear):
     return lin.weight.t().contiguous(), lin.bias.contiguous()
 
@@ -323,7 +340,7 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
             bias_items.append(bsum)
             un_rows.append(Un)
     folded = torch.bmm(torch.stack(un_items), torch.stack(items)).transpose(1, 2)    # (U_n W_s)^T
-    fbias = torch.bmm(torch.stack(un_rows), torch.stack(bias_items).unsqueeze(2)).squeeze(2)
+    fbias = _mv(torch.stack(un_rows), torch.stack(bias_items))
     it = ib = 0
     for l in range(core.layer_num):
         per_type = {}
@@ -396,9 +413,9 @@ def _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev):
     if ck not in pk:
         e = pk["layers"][0][t]
         wt = e["wt"]                                    # [(su+1)*64, 64]
-        rows = [x0[src_of_slot(t, s)] @ wt[s * H:(s + 1) * H] for s in range(su)]
+        rows = [_vm(x0[src_of_slot(t, s)], wt[s * H:(s + 1) * H]) for s in range(su)]
         rows += [torch.zeros(H, device=dev)] * (S - su)  # unused slots of this type
-        rows.append(x0[t] @ wt[su * H:(su + 1) * H] + e["b"])
+        rows.append(_vm(x0[t], wt[su * H:(su + 1) * H]) + e["b"])
         pk[ck] = torch.stack(rows).contiguous()
     return pk[ck]
 
@@ -412,7 +429,7 @@ def _anchor_const_input(pk, gnn, canon):
         w, b = gnn.anchor_mlp[0].weight, gnn.anchor_mlp[0].bias
         x0 = pk["pre"]["canonical"][1]
         _split = ops.split_f16_planes if GEMM_F16X3 else ops.split_bf16_planes
-        pk["anchor_nk_const"] = (_split(w[:, H:].contiguous()), (b + w[:, :H] @ x0).contiguous())
+        pk["anchor_nk_const"] = (_split(w[:, H:].contiguous()), (b + _mv(w[:, :H], x0)).contiguous())
     return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1)
 
 
@@ -512,14 +529,24 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     pooled = torch.empty((B, P), device=dev)
     if isinstance(batch, NeighborhoodBatch):
         c0 = x0["canonical"].expand(B, H) if const_input else X[0][Nc:]
+        folded_x0 = GEMM_BF16X6 and const_input and direct_canon and first == 1    # (_anchor_const_input: K = 512)
         if direct_canon:
-            canon[:, :H] = c0
+            if not folded_x0:
+                canon[:, :H] = c0
             for l in range(1, first + 1):        # layers produced outside the fused launches
-                canon[:, l * H:(l + 1) * H] = X[l][Nc:]
+                if const_input and l == 1:
+                    # the closed-form first layer once more for the canonical rows, straight into its column block of
+                    # the anchor operand (a 1/9-size launch of our own instead of a strided torch copy per pass)
+                    t, r0, r1, su = groups[1]
+                    ops.degree_affine(batch.vrowptr, r0, r1 - r0, S,
+                                      _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev), ops.ACT_RELU, 0.0,
+                                      canon[:, H:2 * H], out_row0=0)
+                else:
+                    canon[:, l * H:(l + 1) * H] = X[l][Nc:]
         else:
             canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)        # emb["canonical"] [B,P]
         aw, ab = pk["anchor"]
-        if GEMM_BF16X6 and const_input and direct_canon and first == 1:
+        if folded_x0:
             anch = _anchor_const_input(pk, gnn, canon)
         elif GEMM_BF16X6:
             anch = _gemm_planes(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
@@ -564,7 +591,7 @@ def pack_shmp_stacked(gnn: BaseGNN) -> dict:
         bs = torch.stack([core.convs[l][k].lin.bias for l in range(L) for k in uniq]).view(L, len(uniq), H).sum(1)
         folded = torch.matmul(Un.unsqueeze(1), W).transpose(-1, -2)                       # (U_n W_s)^T
         Wt = torch.cat([folded, Ux.transpose(-1, -2).unsqueeze(1)], dim=1).reshape(L, (len(keys) + 1) * H, H)
-        fb = torch.matmul(Un, bs.unsqueeze(-1)).squeeze(-1) + c
+        fb = _mv(Un, bs) + c
         out[t] = (Wt, fb)
     return out
 
@@ -661,12 +688,12 @@ def pack_gossip(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     D1 = c1.lin_update.weight
     D1a, D1b = D1[:, :H], D1[:, H:]
     pk["wt1"] = torch.cat([(D1a @ c1.lin_com.weight).t(), D1b.t()], 0).contiguous()   # [128,64]
-    pk["ws1"] = torch.stack([D1a @ c1.lin_com.bias, torch.zeros_like(c1.lin_com.bias)]).contiguous()
+    pk["ws1"] = torch.stack([_mv(D1a, c1.lin_com.bias), torch.zeros_like(c1.lin_com.bias)]).contiguous()
     pk["d1"] = c1.lin_update.bias.contiguous()
     P0, p0 = gnn.post_mp[0].weight, gnn.post_mp[0].bias
     pk["P0"], pk["p0"] = P0, p0
     pk["wtp"] = torch.cat([P0[:, 2 * H:3 * H].t(), P0[:, 3 * H:4 * H].t()], 0).contiguous()
-    pk["wsp"] = torch.stack([torch.zeros(H, device=P0.device), P0[:, H:2 * H] @ pk["w_pre"]]).contiguous()
+    pk["wsp"] = torch.stack([torch.zeros(H, device=P0.device), _mv(P0[:, H:2 * H], pk["w_pre"])]).contiguous()
     pk["post"] = [_lin_t(gnn.post_mp[i]) for i in (3, 5)]
     pk["w7"] = gnn.post_mp[7].weight[0].contiguous()
     pk["b7"] = float(gnn.post_mp[7].bias[0])
@@ -696,15 +723,15 @@ def _gossip_query_terms(gnn: BaseGNN, pk: dict, query_emb: torch.Tensor) -> dict
     q = {}
     q["g0"] = core.convs[0]._gate_value(E).reshape(-1).contiguous()          # gnn_model.py:340
     q["g1"] = core.convs[1]._gate_value(E).reshape(-1).contiguous()
-    a_q = E @ C0[:, :H].t() + (C0[:, H:] @ b_pre + pk["c0"])                 # lin_com(h0) const part
-    v = C0[:, H:] @ w_pre
+    a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + pk["c0"])             # lin_com(h0) const part
+    v = _mv(C0[:, H:], w_pre)
     D0a, D0b, D0c = D0[:, :H], D0[:, H:2 * H], D0[:, 2 * H:]
     q["p"] = (a_q @ D0a.t()).contiguous()
-    q["r"] = (D0a @ v).contiguous()
-    q["t"] = (D0c @ w_pre).contiguous()
-    q["z"] = (E @ D0b.t() + (D0c @ b_pre + pk["d0"])).contiguous()
+    q["r"] = _mv(D0a, v).contiguous()
+    q["t"] = _mv(D0c, w_pre).contiguous()
+    q["z"] = (E @ D0b.t() + (_mv(D0c, b_pre) + pk["d0"])).contiguous()
     P0 = pk["P0"]
-    q["zp"] = (E @ P0[:, :H].t() + (P0[:, H:2 * H] @ b_pre + pk["p0"])).contiguous()     # [Q,64]
+    q["zp"] = (E @ P0[:, :H].t() + (_mv(P0[:, H:2 * H], b_pre) + pk["p0"])).contiguous()     # [Q,64]
     pk["qcache"] = (key, q)
     return q
 
@@ -739,7 +766,8 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
             if GOSSIP_F16X3:
                 v["wstream"], v["winv"] = pk["wstream"], pk["winv"]
                 outs.append(ops.gossip_fused_f16(scal4, batch.rowptr, batch.col, N, q1 - q0, v, batch.work_queue,
-                                                 tile_perm=tperm))
+                                                 tile_perm=tperm,
+                                                 out=getattr(batch, "out_buf", None) if (q0 == 0 and q1 == Q) else None))
             else:
                 outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v, tile_perm=tperm))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
@@ -790,13 +818,13 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
         C3 = torch.stack([deg_hi, deg_lo - deg_hi, one], 1).contiguous()
         C2 = torch.stack([xr, one], 1).contiguous()
     # ---- layer 0 (closed form) -----------------------------------------------------
-    a_q = E @ C0[:, :H].t() + (C0[:, H:] @ b_pre + cb0)
-    v = C0[:, H:] @ w_pre
+    a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + cb0)
+    v = _mv(C0[:, H:], w_pre)
     D0a, D0b, D0c = D0[:, :H], D0[:, H:2 * H], D0[:, 2 * H:]
     p = a_q @ D0a.t()
-    r = (D0a @ v).expand(Q, H)
-    t = (D0c @ w_pre).expand(Q, H)
-    z = E @ D0b.t() + (D0c @ b_pre + db0)
+    r = _mv(D0a, v).expand(Q, H)
+    t = _mv(D0c, w_pre).expand(Q, H)
+    z = E @ D0b.t() + (_mv(D0c, b_pre) + db0)
     V0 = torch.stack([p, g0[:, None] * p, r, g0[:, None] * r, t, z], 1)          # [Q,6,64]
     h1 = AG.AffineRows.apply(None, C6, V0, ops.ACT_RELU, 0.0)
     drop = gnn.training and core.dropout > 0
@@ -807,7 +835,7 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     D1a, D1b = D1[:, :H], D1[:, H:]
     wt1 = torch.cat([(D1a @ C1).t(), D1b.t()], 0)
     lin1 = AG.Linear.apply(hh, h1, wt1, None, ops.ACT_NONE, 0.0)
-    u = (D1a @ cb1).expand(Q, H)
+    u = _mv(D1a, cb1).expand(Q, H)
     V1 = torch.stack([u, g1[:, None] * u, db1.expand(Q, H)], 1)                     # [Q,3,64]
     h2 = AG.AffineRows.apply(lin1, C3, V1, ops.ACT_RELU, 0.0)
     if drop:
@@ -816,8 +844,8 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     P0, p0 = gnn.post_mp[0].weight, gnn.post_mp[0].bias
     wtp = torch.cat([P0[:, 2 * H:3 * H].t(), P0[:, 3 * H:4 * H].t()], 0)
     linp = AG.Linear.apply(h1, h2, wtp, None, ops.ACT_NONE, 0.0)
-    tp = (P0[:, H:2 * H] @ w_pre).expand(Q, H)
-    zp = E @ P0[:, :H].t() + (P0[:, H:2 * H] @ b_pre + p0)
+    tp = _mv(P0[:, H:2 * H], w_pre).expand(Q, H)
+    zp = E @ P0[:, :H].t() + (_mv(P0[:, H:2 * H], b_pre) + p0)
     Vp = torch.stack([tp, zp], 1)                                                   # [Q,2,64]
     if drop:                                                                        # post_mp.1 Dropout
         y = AG.AffineRows.apply(linp, C2, Vp, ops.ACT_NONE, 0.0)

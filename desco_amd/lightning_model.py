@@ -219,13 +219,22 @@ class NeighborhoodCountingModel(_LightningLike):
         from . import gnn_model as GM
         if GM.GEMM_BF16X6:
             T = ops.linear64(emb_t, hp["w_t_l64"])                         # target half
-            Qh = ops.gemm_split(emb_q, hp["w_q_nk"], hp["b1"])              # query half + bias
+            # query half + bias: a function of (head weights, query embeddings) only -- cached with them at inference
+            qkey = (emb_q.data_ptr(), emb_q._version)
+            if torch.is_grad_enabled() or hp.get("qh_key") != qkey:
+                Qh = ops.gemm_split(emb_q, hp["w_q_nk"], hp["b1"])
+                if not torch.is_grad_enabled():
+                    hp["qh_key"], hp["qh"] = qkey, Qh
+            else:
+                Qh = hp["qh"]
         else:
             T = ops.gemm(emb_t, hp["wt_t"])
             Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])
         slope = self.count_model[1].negative_slope
         if Qh.shape[0] <= 32:
-            return ops.count_head(T, Qh, hp["w2"], hp["b2"], slope, exp2)
+            # (InferencePipeline hands every block a slice of ONE persistent result tensor: no torch.cat per pass)
+            return ops.count_head(T, Qh, hp["w2"], hp["b2"], slope, exp2,
+                                  out=getattr(batch, "out_buf", None) if exp2 else None)
         # more than 32 queries (labelled queries of --use_node_feature: 784 for input_dim 2): the head
         # kernel keeps one accumulator per query in registers, so the query axis goes in groups of 32
         return torch.cat([ops.count_head(T, Qh[q0:q0 + 32], hp["w2"], hp["b2"], slope, exp2)

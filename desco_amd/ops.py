@@ -368,10 +368,14 @@ def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor]
 
 def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, coef: torch.Tensor,
                   act: int, slope: float, out: torch.Tensor,
-                  extra: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[row0+i] = act(coef[slots] + sum_s deg_s(i) * coef[s]) + extra[i]   (see desco_hip.h)."""
+                  extra: Optional[torch.Tensor] = None, out_row0: Optional[int] = None) -> torch.Tensor:
+    """out[row0+i] = act(coef[slots] + sum_s deg_s(i) * coef[s]) + extra[i]   (see desco_hip.h).
+    ``out_row0``: row of ``out`` that receives row ``row0`` (default ``row0``: out is indexed like the CSR)."""
     assert coef.is_contiguous() and coef.shape == (slots + 1, 64)
     op, ldo = _rows(out, "out")
+    if out_row0 is not None:
+        assert out.shape[0] >= out_row0 + num_rows
+        op += 4 * ldo * (out_row0 - row0)          # the entry point indexes out by the CSR row id
     ep, lde = (None, 0) if extra is None else _rows(extra, "extra")
     L = _lib.lib()
     with _Timed("degree_affine_kernel", 2.0 * num_rows * slots * 64,
@@ -584,12 +588,16 @@ def segment_sum_layers(xall: torch.Tensor, num_rows: int, seg_ptr: torch.Tensor,
 
 
 def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2, slope: float,
-               exp2_minus_1: bool) -> torch.Tensor:
+               exp2_minus_1: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[B,Q] logits (or 2**logit - 1) of the separable count head (lightning_model.py:176-221).
-    ``b2``: a float, or a 0-d / 1-element device tensor read by the kernel (no host sync)."""
+    ``b2``: a float, or a 0-d / 1-element device tensor read by the kernel (no host sync).
+    ``out``: optional contiguous [B, Q] destination (a slice of a persistent result buffer)."""
     B, hid = t.shape
     Q = qh.shape[0]
-    out = torch.empty((B, Q), device=t.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, Q), device=t.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, Q) or not out.is_contiguous():
+        raise ValueError("count_head: `out` must be a contiguous [B, Q] tensor")
     tp, ldt = _rows(t, "t")
     qp, ldq = _rows(qh, "qh")
     L = _lib.lib()
@@ -732,10 +740,14 @@ def gossip_f16_stream(w1: F16Planes, wp: F16Planes, w3: F16Planes, w5: F16Planes
 
 
 def gossip_fused_f16(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
-                     num_q: int, v: dict, queue: torch.Tensor, tile_perm: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     num_q: int, v: dict, queue: torch.Tensor, tile_perm: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One on-chip pass per (128-node tile, query) in the three-product fp16 form (csrc/gossip_f16.hip): returns
-    pred [N, Q].  ``queue``: two zeroed int64 words (see desco_hip.h)."""
-    out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
+    pred [N, Q].  ``queue``: two zeroed int64 words (see desco_hip.h); ``out``: optional contiguous [N, Q] destination."""
+    if out is None:
+        out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
+    elif tuple(out.shape) != (num_nodes, num_q) or not out.is_contiguous():
+        raise ValueError("gossip_fused_f16: `out` must be a contiguous [N, Q] tensor")
     if tile_perm is not None and tile_perm.numel() < ((num_nodes + 127) // 128) * 128:
         raise ValueError("gossip_fused_f16: tile_perm is shorter than the tiles of this batch")
     if queue.dtype != torch.int64 or queue.numel() < 2:
