@@ -422,6 +422,86 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     }
 
 
+def train_gossip_leg(device, batch_graphs=256):
+    """BASELINE config 4's second stage (Syn_1827 full training): the gossip model's training step -- forward, backward
+    (every op a C-ABI kernel, desco_amd.autograd), Adam -- on all 1 827 Syn_1827-shaped graphs in the reference's batches
+    of 256 graphs (config.py:319), node inputs = the exact canonical counts perturbed by 10 % (what a trained
+    neighborhood stage hands over), labels = the exact counts; loss = sum log2(|pred - y| + 1)
+    (lightning_model.py:585-608, 630-635).  One untimed epoch, then two timed epochs with per-launch HIP events."""
+    import torch
+    from desco_amd import ops, synthetic
+    from desco_amd.batch import GossipBatch
+    from desco_amd.data import STANDARD_QUERY_IDS, graph_atlas_plus
+    from desco_amd.groundtruth import canonical_counts
+    nm, gm = build_models(device, gains=(0.8, 1.2))
+    nm.set_queries(STANDARD_QUERY_IDS)
+    gm.set_query_emb(nm.get_query_emb().detach())
+    gs = synthetic.WORKLOADS["syn_1827"]()
+    t0 = time.perf_counter()
+    queries = [graph_atlas_plus(i) for i in STANDARD_QUERY_IDS]
+    y = canonical_counts(gs, queries, backend="auto").float()
+    g = torch.Generator().manual_seed(5)
+    x = y * (1.0 + 0.1 * torch.randn(y.shape, generator=g)).clamp_min(0.0)
+    t_prep = time.perf_counter() - t0
+    batches, off = [], 0
+    for g0 in range(0, gs.num_graphs, batch_graphs):
+        sub = gs.subset(g0, min(g0 + batch_graphs, gs.num_graphs))
+        batches.append(GossipBatch(sub, device, x=x[off:off + sub.num_nodes], y=y[off:off + sub.num_nodes]))
+        off += sub.num_nodes
+    opt = gm.configure_optimizers()["optimizer"]
+
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = gm.training_step(b, 0)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    first = None
+    for b in batches:
+        l = step(b)
+        first = l if first is None else first
+    torch.cuda.synchronize(device)
+    ops.PROFILER.enabled = True
+    ops.PROFILER.reset()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        for b in batches:
+            last = step(b)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    ops.PROFILER.enabled = False
+    summ = ops.PROFILER.summary()
+    tot = sum(v["ms"] for v in summ.values())
+    steps = 2 * len(batches)
+    nodes = 2 * sum(b.num_nodes for b in batches)
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    peak = {"gemm_f32_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": PEAK_F32_MFMA_TFLOPS,
+            "gemm_tn_partial_kernel": PEAK_F32_MFMA_TFLOPS}.get(name)
+    if peak:
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+    else:
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS}
+    roof.update({"launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"], "share_of_kernel_time": d["ms"] / tot,
+                 "traffic": None})
+    return {
+        "metric": "nodes/s (gossip-model training step: forward, backward, Adam; 29 queries per node)",
+        "value": nodes / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+        "node_query_rows_per_s": 29.0 * nodes / dt, "kernel_ms_per_step": tot / steps,
+        "launches_per_step": sum(v["calls"] for v in summ.values()) / steps, "launch_mode": "eager launches",
+        "dtype": "f32", "data": "synthetic", "loss_first_batch": float(first), "loss_last_batch": float(last),
+        "config": {"workload": f"Syn_1827-shaped synthetic, all {gs.num_graphs} graphs ({gs.num_nodes} nodes), batch "
+                               f"{batch_graphs} graphs, 29 queries, inputs = exact canonical counts +-10 %, labels = exact "
+                               f"counts, Adam (torch)", "prep_s": round(t_prep, 2)},
+        "roofline": roof,
+        "kernels": {k: {"launches_per_step": round(v["calls"] / steps, 1), "ms_per_step": round(v["ms"] / steps, 3)}
+                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+    }
+
+
 def nccl_gradient_check(device):
     """One REAL neighborhood training step per rank on its (unequal) share of a union batch, the gradient buckets
     all-reduced asynchronously from the autograd hooks (desco_amd.distributed.GradBuckets), compared with the
@@ -525,7 +605,7 @@ def main():
     ap.add_argument("--no-train", action="store_true",
                     help="skip the training leg (Syn_1827-shaped neighborhood training steps, N=1 only)")
     ap.add_argument("--train-stride", type=int, default=4, help="training leg: time every k-th batch of the epoch")
-    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--train-precision", default="both", choices=["fp32", "bf16", "both"])
     ap.add_argument("--selftest-nccl", action="store_true",
                     help="2-rank RCCL gradient all-reduce check (needs 2 visible GPUs; skips otherwise)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -824,7 +904,15 @@ def main():
         if world == 1 and not args.no_train:
             del pipe
             torch.cuda.empty_cache()
-            result["train_syn_1827"] = train_leg(device, stride=args.train_stride, precision=args.train_precision)
+            # fp32 (the parity-tested default) AND bf16 (BASELINE config 3 names bf16) -- each with its own roofline --,
+            # then the gossip stage of config 4
+            precisions = ["fp32", "bf16"] if args.train_precision == "both" else [args.train_precision]
+            legs = {p_: train_leg(device, stride=args.train_stride, precision=p_) for p_ in precisions}
+            result["train_syn_1827"] = legs[precisions[0]]
+            for p_ in precisions[1:]:
+                result["train_syn_1827"][p_] = legs[p_]
+            torch.cuda.empty_cache()
+            result["train_gossip"] = train_gossip_leg(device)
         # ---- CPU baseline (N=1 only) + parity of the sample ------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as f:

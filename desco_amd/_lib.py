@@ -42,10 +42,10 @@ SIGNATURES = {
     "desco_shmp_layer_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_layer_pool_bf16x6_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
     "desco_pool_reduce_f32": (c_int, [vp, vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]),
-    "desco_shmp_layer_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp]),
+    "desco_shmp_layer_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, vp]),
     "desco_shmp_layer_pool_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
     "desco_shmp_pool_tile_rows": (c_int, []),
-    "desco_degree_affine_f32": (c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i64, vp, i64, vp]),
+    "desco_degree_affine_f32": (c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i64, vp, i64, vp, vp]),
     "desco_gemm_bf16x6_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
                                       vp, i64, i64, vp]),
     "desco_gemm_bf16_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i32, vp, i32, vp, i32, vp, i32, f32,
@@ -53,7 +53,7 @@ SIGNATURES = {
     "desco_round_bf16_f32": (c_int, [vp, i64, vp, vp]),
     "desco_gemm_f16x3_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, f32,
                                      vp, i64, i64, vp, vp]),
-    "desco_row_scale_f16": (c_int, [vp, i64, i32, vp, i64, i32, i64, vp, vp]),
+    "desco_row_absmax_f32": (c_int, [vp, i64, i32, vp, i64, i32, i64, vp, vp]),
     "desco_split_f16x2_f32": (c_int, [vp, i64, vp, vp, vp]),
     "desco_segment_sum_f32": (c_int, [vp, i64, i32, vp, i64, vp, i64, vp, i64, vp]),
     "desco_segment_sum_layers_f32": (c_int, [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, vp]),

@@ -11,8 +11,9 @@
 //   * weights: ONE power of two per matrix (largest |w| -> [2^14, 2^15)), applied when the planes are made
 //     (desco_split_f16x2_f32), its inverse kept on the device next to the planes;
 //   * activations: one power of two PER ROW over the whole K extent (largest |a| of the row -> [2^14, 2^15)), so a
-//     row's products share one accumulator; found by a pre-pass over A (row_scale_kernel: HBM-bound, A once) and
-//     undone in the epilogue together with the weight scale (exact: powers of two).
+//     row's products share one accumulator; derived from a per-row bound that either a pre-pass over A provides
+//     (row_scale_kernel: HBM-bound, A once) or the kernel that wrote A, and undone in the epilogue together with the
+//     weight scale (exact: powers of two).
 // An element 2^-17 below its row maximum keeps 22 bits; smaller ones degrade gradually (lo subnormal) down to an
 // absolute error of 2^-40 of the row maximum -- below the fp32 rounding error of the row's dot products.
 //
@@ -42,7 +43,7 @@ struct GemmF16Args {
   float* c;
   int64_t ldc;
   int64_t m;
-  const float* row_scale;  // [m]
+  const float* row_scale;  // [m] bound of each row's largest |a| (desco_row_absmax_f32 or the producer of A)
 };
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -51,7 +52,9 @@ constexpr int FBK = 32, FST = 32;              // K chunk; plane row stride in h
 // same swizzle as gemm_split.hip: 16-byte chunk c of plane row r sits at chunk c ^ ((r >> 3) & 3)
 __device__ __forceinline__ int gf16_chunk(const int row, const int c) { return ((c ^ (row >> 3)) & 3) << 3; }
 
-// per-row scale of the A operand: s[i] * max_k |A[i, k]| in [2^14, 2^15).  16 lanes per row, float4 loads.
+// per-row bound of the A operand: max_k |A[i, k]| (the kernel turns it into the power of two s with s * bound in
+// [2^14, 2^15)).  16 lanes per row, float4 loads.  A kernel that WRITES A can leave the same array instead (the SHMP
+// layer's canonical launches do, for the anchor operand): any value >= the row's largest magnitude will do.
 __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ a1, int64_t lda1, int k1,
                                                         const float* __restrict__ a2, int64_t lda2, int k2,
                                                         int64_t m, float* __restrict__ out) {
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (lane16 == 0 && row < m) out[row] = f16_scale_for(mx);
+  if (lane16 == 0 && row < m) out[row] = mx;
 }
 
 // BM = 128 rows per block tile (4 waves, two blocks per CU), WN = 3, 2, 1 column tiles of 64
@@ -113,10 +116,11 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
   r1 = r1 < g.m ? r1 : mlast;
   r2 = r2 < g.m ? r2 : mlast;
   r3 = r3 < g.m ? r3 : mlast;
-  const float sc0 = g.row_scale[r0], sc1 = g.row_scale[r1], sc2 = g.row_scale[r2], sc3 = g.row_scale[r3];
+  const float sc0 = f16_scale_for(g.row_scale[r0]), sc1 = f16_scale_for(g.row_scale[r1]);
+  const float sc2 = f16_scale_for(g.row_scale[r2]), sc3 = f16_scale_for(g.row_scale[r3]);
   if (tid < BM) {
     const int64_t rr = m0 + tid < g.m ? m0 + tid : mlast;
-    rinv[tid] = pow2_inverse(g.row_scale[rr]) * g.w_scale[1];
+    rinv[tid] = pow2_inverse(f16_scale_for(g.row_scale[rr])) * g.w_scale[1];
   }
   const float* p10 = g.a1 + r0 * g.lda1 + 4 * ac4;
   const float* p11 = g.a1 + r1 * g.lda1 + 4 * ac4;
@@ -351,18 +355,18 @@ static int launch_gemm_f16x3(const GemmF16Args& g, hipStream_t stream) {
 
 using namespace desco;
 
-extern "C" int desco_row_scale_f16(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+extern "C" int desco_row_absmax_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
                                    int64_t m, float* row_scale, desco_stream_t stream) {
   if (m == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   if (m < 0 || !a1 || !row_scale || k1 <= 0 || k1 % 4 || k2 < 0 || k2 % 4 || (k2 > 0 && !a2) || lda1 % 4 ||
       (k2 > 0 && lda2 % 4) || mis16(a1) || (k2 > 0 && mis16(a2)))
-    return fail(DESCO_EINVAL, "desco_row_scale_f16: bad argument (k % 4, 16-byte alignment)");
+    return fail(DESCO_EINVAL, "desco_row_absmax_f32: bad argument (k % 4, 16-byte alignment)");
   const int64_t blocks = (m + 15) / 16;
-  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_row_scale_f16: m too large");
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_row_absmax_f32: m too large");
   hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a1, lda1, k1, a2,
                      lda2, k2, m, row_scale);
-  return launch_status("desco_row_scale_f16");
+  return launch_status("desco_row_absmax_f32");
 }
 
 extern "C" int desco_gemm_f16x3_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,

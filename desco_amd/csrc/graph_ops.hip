@@ -485,7 +485,8 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
                                                             float slope,
                                                             const float* __restrict__ extra,
                                                             int64_t ld_extra,
-                                                            float* __restrict__ out, int64_t ldo) {
+                                                            float* __restrict__ out, int64_t ldo,
+                                                            float* __restrict__ row_absmax) {
   const int c4 = 4 * (threadIdx.x & 15);
   float4 cf[DA_MAXS];
 #pragma unroll
@@ -531,6 +532,18 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
         acc.w += e.w;
       }
       *reinterpret_cast<float4*>(out + (row0 + i) * ldo + c4) = acc;
+      if (row_absmax) {          // (wave-uniform) the row's largest |value|: 16 lanes x 4 columns
+        uint32_t v_ = __float_as_uint(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+        uint32_t o_ = __builtin_amdgcn_update_dpp(0u, v_, 0xB1, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x4E, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x141, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x140, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        if ((threadIdx.x & 15) == 0) row_absmax[i] = __uint_as_float(v_);
+      }
     }
   }
 }
@@ -788,7 +801,7 @@ extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, cons
 extern "C" int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_rows,
                                        int slots, const float* coef, int act, float slope,
                                        const float* extra, int64_t ld_extra, float* out,
-                                       int64_t ldo, desco_stream_t stream) {
+                                       int64_t ldo, float* row_absmax, desco_stream_t stream) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
   if (!vrowptr || !coef || !out || row0 < 0 || num_rows < 0 || slots < 1 || slots > DA_MAXS ||
@@ -797,7 +810,7 @@ extern "C" int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int
   int64_t blocks = (num_rows + 15) / 16;
   if (blocks > 8 * 256) blocks = 8 * 256;
   hipLaunchKernelGGL(degree_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     vrowptr, row0, num_rows, slots, coef, act, slope, extra, ld_extra, out, ldo);
+                     vrowptr, row0, num_rows, slots, coef, act, slope, extra, ld_extra, out, ldo, row_absmax);
   return launch_status("desco_degree_affine_f32");
 }
 

@@ -22,6 +22,8 @@ struct ShmpArgs {
   int64_t ldo;
   float* out2;              // optional second copy of the output rows (row i - row0 of a [num_rows, *] view)
   int64_t ldo2;
+  float* row_absmax;        // optional (with out2): row_absmax[i - row0] = max(row_absmax[i - row0], max_c |out[i, c]|) -- the
+                            // per-row bound desco_gemm_f16x3_f32 wants for the operand these rows are a column block of
   int act;                  // DESCO_ACT_* of the epilogue (relu for the SHMP layer)
   float slope;
   // fused pooling (global_add_pool of the produced rows, gnn_model.py:107), optional: see

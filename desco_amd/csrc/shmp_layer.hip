@@ -803,7 +803,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                        float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream,
                        const uint32_t* pool_bits = nullptr, const int32_t* pool_slot = nullptr,
-                       float* pool_part = nullptr, const float* wscale = nullptr) {
+                       float* pool_part = nullptr, const float* wscale = nullptr, float* row_absmax = nullptr) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
@@ -850,6 +850,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              ldo,
              out2,
              ldo2,
+             row_absmax,
              act,
              slope,
              pool_bits,
@@ -927,12 +928,12 @@ extern "C" int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int
                                           const int16_t* wt_planes, const float* w_scale, const float* bias,
                                           const float* ytab, int64_t ldy, int64_t ytab_row0,
                                           float* out, int64_t ldo, float* out2, int64_t ldo2,
-                                          desco_stream_t stream) {
+                                          float* row_absmax, desco_stream_t stream) {
   if (!w_scale) return desco::fail(DESCO_EINVAL, "desco_shmp_layer_f16x3_f32: w_scale is null");
   return desco::shmp_launch("desco_shmp_layer_f16x3_f32", true, x, ldx, vrowptr, vcol, row0,
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
                             ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream, nullptr, nullptr,
-                            nullptr, w_scale);
+                            nullptr, w_scale, row_absmax);
 }
 
 extern "C" int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr,

@@ -762,6 +762,31 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
       q2[e] = apply_act(q2[e], g.act, g.slope);
       q3[e] = apply_act(q3[e], g.act, g.slope);
     }
+    if (g.row_absmax) {
+      // per-row bound of the produced rows for a later f16x3 GEMM over them (the anchor operand): still in the C/D
+      // layout -- lane (c, g) holds rows 4 g + e of columns 16 t + c --, so a row's maximum is 3 maxima over the tiles
+      // and 4 DPP steps over the quarter's 16 lanes; accumulated over the launches that fill the operand's columns
+      f32x4 m_ = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_abs(q0), __builtin_elementwise_abs(q1)),
+                                           __builtin_elementwise_max(__builtin_elementwise_abs(q2), __builtin_elementwise_abs(q3)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t v_ = __float_as_uint(m_[e]);
+        uint32_t o_ = __builtin_amdgcn_update_dpp(0u, v_, 0xB1, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x4E, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x141, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        o_ = __builtin_amdgcn_update_dpp(0u, v_, 0x140, 0xf, 0xf, true);
+        v_ = v_ > o_ ? v_ : o_;
+        const int r_ = 4 * (lane >> 4) + e;
+        if ((lane & 15) == 0 && r_ < nr_out) {
+          float* p_ = g.row_absmax + (grow_out - g.row0) + r_;
+          const float old_ = *p_;
+          *p_ = fmaxf(old_, __uint_as_float(v_));
+        }
+      }
+    }
     {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll

@@ -420,7 +420,7 @@ def _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev):
     return pk[ck]
 
 
-def _anchor_const_input(pk, gnn, canon):
+def _anchor_const_input(pk, gnn, canon, row_bound=None):
     """anchor_mlp (gnn_model.py:69-73) on emb["canonical"] when the input layer is constant (all-zero node
     features: x^0 of every canonical row is pre_mp's bias): the first 64-column block of the operand is the
     same row for every neighborhood, so its product is folded into the bias and the GEMM runs with
@@ -430,7 +430,8 @@ def _anchor_const_input(pk, gnn, canon):
         x0 = pk["pre"]["canonical"][1]
         _split = ops.split_f16_planes if GEMM_F16X3 else ops.split_bf16_planes
         pk["anchor_nk_const"] = (_split(w[:, H:].contiguous()), (b + _mv(w[:, :H], x0)).contiguous())
-    return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1)
+    kw = {"row_scale": row_bound} if (row_bound is not None and isinstance(pk["anchor_nk_const"][0], ops.F16Planes)) else {}
+    return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1, **kw)
 
 
 def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
@@ -481,6 +482,18 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     # column block directly (out2), so no concatenation pass is needed
     direct_canon = FUSED_SHMP_LAYER and isinstance(batch, NeighborhoodBatch)
     canon = torch.empty((B, P), device=dev) if direct_canon else None
+    # per-row bound of the anchor operand, left by the launches that write its column blocks (saves the f16x3 GEMM's
+    # pre-pass over the operand): only when every block comes from such a launch (constant input, fp16 layer form)
+    canon_max = None
+    if direct_canon and const_input and GEMM_BF16X6 and GEMM_F16X3 and SHMP_BF16X6 and SHMP_F16X3 and first == 1:
+        canon_max = torch.empty((B,), device=dev)
+    if direct_canon and const_input and first == 1:
+        # the closed-form first layer once more for the canonical rows, straight into its column block of the anchor
+        # operand (a 1/9-size launch of our own instead of a strided torch copy per pass); it WRITES the row bound the
+        # canonical launches below accumulate into, so it runs before them
+        t, r0, r1, su = groups[1]
+        ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev),
+                          ops.ACT_RELU, 0.0, canon[:, H:2 * H], out_row0=0, row_absmax=canon_max)
     # fused pooling: the count launches leave partial neighborhood sums, reduced after the anchor MLP
     fpool = (FUSED_POOLING and FUSED_SHMP_LAYER and SHMP_BF16X6 and GEMM_BF16X6
              and isinstance(batch, NeighborhoodBatch) and Nc > 0)
@@ -512,7 +525,9 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
                                    e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn,
                                    out2=(canon[:, (l + 1) * H:(l + 2) * H]
-                                         if direct_canon and t == "canonical" else None))
+                                         if direct_canon and t == "canonical" else None),
+                                   row_absmax=canon_max if (direct_canon and t == "canonical" and
+                                                            isinstance(e.get("wt_x6"), ops.F16Planes)) else None)
         else:
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
             for t, r0, r1, su in groups:
@@ -534,20 +549,13 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
             if not folded_x0:
                 canon[:, :H] = c0
             for l in range(1, first + 1):        # layers produced outside the fused launches
-                if const_input and l == 1:
-                    # the closed-form first layer once more for the canonical rows, straight into its column block of
-                    # the anchor operand (a 1/9-size launch of our own instead of a strided torch copy per pass)
-                    t, r0, r1, su = groups[1]
-                    ops.degree_affine(batch.vrowptr, r0, r1 - r0, S,
-                                      _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev), ops.ACT_RELU, 0.0,
-                                      canon[:, H:2 * H], out_row0=0)
-                else:
+                if not (const_input and l == 1):     # (that one was written above, before the layer loop)
                     canon[:, l * H:(l + 1) * H] = X[l][Nc:]
         else:
             canon = torch.cat([c0] + [xl[Nc:] for xl in X[1:]], dim=1)        # emb["canonical"] [B,P]
         aw, ab = pk["anchor"]
         if folded_x0:
-            anch = _anchor_const_input(pk, gnn, canon)
+            anch = _anchor_const_input(pk, gnn, canon, row_bound=canon_max)
         elif GEMM_BF16X6:
             anch = _gemm_planes(canon, *pk["anchor_nk"], act=ops.ACT_LEAKY, slope=0.1)
         else:

@@ -226,7 +226,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                num_rows: int, slots_stored: int, slots_mfma: int, wt: torch.Tensor,
                bias: torch.Tensor, out: Optional[torch.Tensor], ytab: Optional[torch.Tensor] = None,
                ytab_row0: int = 0, out2: Optional[torch.Tensor] = None,
-               pool: Optional[tuple] = None) -> Optional[torch.Tensor]:
+               pool: Optional[tuple] = None, row_absmax: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
     ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1.
     ``out2`` [num_rows, >=64] (optional): second copy of the produced rows (see desco_hip.h).
@@ -262,8 +262,11 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
         head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
                 slots_stored, slots_mfma, st)
         tail = (_dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0, op, ldo, o2p, ldo2, _stream())
+        if row_absmax is not None and not f16:
+            raise ValueError("shmp_layer: row_absmax is an output of the f16x3 form only")
         if f16:
-            rc = L.desco_shmp_layer_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16), _dev(wt.scale, "w_scale"), *tail)
+            rc = L.desco_shmp_layer_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16), _dev(wt.scale, "w_scale"),
+                                              *tail[:-1], _opt(row_absmax, "row_absmax"), tail[-1])
         else:
             fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
             rc = fn(*head, _dev(wt, "wt", wt.dtype), *tail)
@@ -368,7 +371,8 @@ def linear64(x: torch.Tensor, planes: torch.Tensor, bias: Optional[torch.Tensor]
 
 def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, coef: torch.Tensor,
                   act: int, slope: float, out: torch.Tensor,
-                  extra: Optional[torch.Tensor] = None, out_row0: Optional[int] = None) -> torch.Tensor:
+                  extra: Optional[torch.Tensor] = None, out_row0: Optional[int] = None,
+                  row_absmax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[row0+i] = act(coef[slots] + sum_s deg_s(i) * coef[s]) + extra[i]   (see desco_hip.h).
     ``out_row0``: row of ``out`` that receives row ``row0`` (default ``row0``: out is indexed like the CSR)."""
     assert coef.is_contiguous() and coef.shape == (slots + 1, 64)
@@ -382,7 +386,7 @@ def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, c
                 256.0 * num_rows + 4.0 * num_rows * (slots + 1)):
         _lib.check(L.desco_degree_affine_f32(_dev(vrowptr, "vrowptr", torch.int32), row0, num_rows,
                                              slots, _dev(coef, "coef"), act, slope, ep, lde, op, ldo,
-                                             _stream()), "degree_affine")
+                                             _opt(row_absmax, "row_absmax"), _stream()), "degree_affine")
     return out
 
 
@@ -440,14 +444,15 @@ def split_f16_planes(w: torch.Tensor) -> F16Planes:
 
 
 def row_scale_f16(a1: torch.Tensor, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[m] powers of two s_i with s_i * max_k |[a1 | a2][i, k]| in [2^14, 2^15) (1 for an all-zero row)."""
+    """[m] row bounds max_k |[a1 | a2][i, k]| (the per-row operand of ``gemm_f16x3``, which derives its power-of-two
+    scales from them)."""
     m, k1 = a1.shape
     k2 = 0 if a2 is None else a2.shape[1]
     out = torch.empty((m,), device=a1.device, dtype=torch.float32)
     a1p, lda1 = _rows(a1, "a1")
     a2p, lda2 = (None, 0) if a2 is None else _rows(a2, "a2")
     with _Timed("row_scale_kernel", 0.0, 4.0 * m * (k1 + k2 + 1)):
-        _lib.check(_lib.lib().desco_row_scale_f16(a1p, lda1, k1, a2p, lda2, k2, m, _dev(out, "row_scale"),
+        _lib.check(_lib.lib().desco_row_absmax_f32(a1p, lda1, k1, a2p, lda2, k2, m, _dev(out, "row_scale"),
                                                   _stream()), "row_scale_f16")
     return out
 

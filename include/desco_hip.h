@@ -198,13 +198,14 @@ int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco
  *   w_planes[2][n][k1+k2]: (hi, lo) fp16 bit patterns of scale * W, N-MAJOR, and w_scale[2] = {scale, 1/scale} on
  *     the DEVICE, both produced once per weight version by desco_split_f16x2_f32 (one power of two per matrix:
  *     largest |w| -> [2^14, 2^15));
- *   row_scale[m]: one power of two per row of [A1 | A2] (largest |a| of the row -> [2^14, 2^15)), produced by
- *     desco_row_scale_f16 on the same operands (or by the kernel that wrote A). */
+ *   row_scale[m]: a bound of every row's largest |a| over [A1 | A2] (the kernel derives the power of two that puts it
+ *     into [2^14, 2^15)): desco_row_absmax_f32 on the same operands, or left by the kernel that wrote A
+ *     (desco_degree_affine_f32 / desco_shmp_layer_f16x3_f32 with row_absmax). */
 int desco_gemm_f16x3_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
                          const int16_t* w_planes, const float* w_scale, int n, const float* bias,
                          int bias_rows, const float* s, int ns, const float* ws, int act, float slope,
                          float* c, int64_t ldc, int64_t m, const float* row_scale, desco_stream_t stream);
-int desco_row_scale_f16(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
+int desco_row_absmax_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
                         int64_t m, float* row_scale, desco_stream_t stream);
 int desco_split_f16x2_f32(const float* w, int64_t count, int16_t* planes, float* scale, desco_stream_t stream);
 
@@ -275,7 +276,10 @@ int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowp
                                int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
                                int slots_table, const int16_t* wt_planes, const float* w_scale,
                                const float* bias, const float* ytab, int64_t ldy, int64_t ytab_row0,
-                               float* out, int64_t ldo, float* out2, int64_t ldo2, desco_stream_t stream);
+                               float* out, int64_t ldo, float* out2, int64_t ldo2, float* row_absmax,
+                               desco_stream_t stream);
+/* row_absmax (optional, [num_rows]): row_absmax[i - row0] = max(row_absmax[i - row0], max_c |out[i, c]|) is ACCUMULATED
+ * over the launches that fill the column blocks of one operand (out2): its per-row bound for desco_gemm_f16x3_f32. */
 int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
                                     int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
                                     int slots_table, const int16_t* wt_planes, const float* w_scale,
@@ -305,7 +309,10 @@ int desco_linear64_bf16x6_f32(const float* x, int64_t ldx, const int16_t* w_plan
  * mathematically identical to desco_shmp_layer_f32 on the constant input; no gather, no GEMM. */
 int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_rows, int slots,
                             const float* coef, int act, float slope, const float* extra,
-                            int64_t ld_extra, float* out, int64_t ldo, desco_stream_t stream);
+                            int64_t ld_extra, float* out, int64_t ldo, float* row_absmax,
+                            desco_stream_t stream);
+/* row_absmax (optional, [num_rows]): row_absmax[i - row0] = max_c |out[i, c]| is WRITTEN -- the start of the per-row
+ * bound desco_gemm_f16x3_f32 takes when these rows are the first column block of its operand. */
 
 /* Indices of the backward pass, built on the device (replaces the per-batch host transposes):
  *  desco_vcsr_transpose_sym: the transposed index of a SYMMETRIC virtual-row CSR (every edge

@@ -416,6 +416,37 @@ def test_degree_affine():
                       extra=extra.to(DEV)[:, 64:128])
     _close(out[row0:], ref, atol=1e-4)
     assert (out[:row0] == -3.0).all()
+    # the optional row bound (start of the anchor operand's per-row bound): exactly the row maxima of what was stored
+    bound = torch.full((n + 3,), -1.0, device=DEV)
+    out2 = torch.empty((n, 64), device=DEV)
+    ops.degree_affine(ptr.to(DEV), row0, n, S, coef.to(DEV), ops.ACT_LEAKY, 0.1, out2, out_row0=0, row_absmax=bound)
+    assert torch.equal(bound[:n], out2.abs().amax(1)) and (bound[n:] == -1.0).all()
+
+
+@pytest.mark.parametrize("num_rows,row0", [(1, 0), (4099, 5), (70001, 0)])
+def test_fused_shmp_layer_f16x3_accumulates_the_row_bound(num_rows, row0):
+    """Canonical launches (second output = a column block of the anchor operand) raise row_absmax[i - row0] to the
+    row's largest stored |value| and never lower it (desco_hip.h: accumulated over the launches of one operand)."""
+    S, sm = 2, 2
+    g = torch.Generator().manual_seed(num_rows)
+    n_all = row0 + num_rows + 3
+    x = torch.randn(n_all, 64, generator=g) * (torch.rand(n_all, 1, generator=g) * 50)
+    ptr, col, cnt = _random_vcsr(n_all, S, 5, n_all, g)
+    wt = torch.randn((sm + 1) * 64, 64, generator=g) / 12
+    bias = torch.randn(64, generator=g)
+    out = torch.empty((n_all, 64), device=DEV)
+    canon = torch.zeros((num_rows, 192), device=DEV)
+    prior = torch.rand(num_rows + 2, generator=g).to(DEV) * 40
+    bound = prior.clone()
+    ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm,
+                   ops.split_f16_planes(wt.t().contiguous().to(DEV)), bias.to(DEV), out, out2=canon[:, 64:128],
+                   row_absmax=bound)
+    assert torch.equal(canon[:, 64:128], out[row0:row0 + num_rows])
+    assert torch.equal(bound[:num_rows], torch.maximum(prior[:num_rows], canon.abs().amax(1)))
+    assert torch.equal(bound[num_rows:], prior[num_rows:])
+    with pytest.raises(ValueError):
+        ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, wt.to(DEV), bias.to(DEV), out,
+                       row_absmax=bound)
 
 
 @pytest.mark.parametrize("m,k1,k2,n", [(1, 64, 0, 64), (129, 128, 64, 64), (1000, 576, 0, 576), (4097, 64, 0, 256),
