@@ -355,16 +355,15 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     rows = sum(b.num_rows for b in batches)
     # the same steps replayed from hipGraphs (what Trainer(graph_capture=True) / main.py --graph_capture do:
     # shuffle=False makes every epoch the same batch stream, so a batch's whole step -- forward, backward,
-    # Adam with capturable state -- is captured once and replayed): the eager step is host-bound
+    # Adam -- is captured once and replayed): the eager step is host-bound
     # (~216 launches + autograd bookkeeping around ~5 ms of kernels)
-    lr0 = float(opt.param_groups[0]["lr"])
-    del opt
-    opt = torch.optim.Adam(nm.parameters(), lr=torch.tensor(lr0, device=device), capturable=True)
+    # (desco_amd.optim.Adam keeps its state on the device and its step is one capturable launch: the same optimizer
+    #  object goes on)
     side = torch.cuda.Stream(device)
     side.wait_stream(torch.cuda.current_stream(device))
     graphs = []
     with torch.cuda.stream(side):
-        for b in batches[:2]:          # Adam's (device-resident, capturable) state is created by eager steps
+        for b in batches[:2]:          # autograd's AccumulateGrad nodes must have been created on this stream
             opt.zero_grad(set_to_none=True)
             nm.train_forward(b, 0).backward()
             opt.step()
@@ -388,6 +387,7 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     dt_eager, dt = dt, dt_graph
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     peak = {"gemm_f32_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": PEAK_F32_MFMA_TFLOPS,
+            "gemm_f32_multi_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_multi_kernel": PEAK_F32_MFMA_TFLOPS,
             "gemm_tn_partial_kernel": PEAK_F32_MFMA_TFLOPS, "gemm_bf16_kernel": PEAK_BF16_MFMA_TFLOPS,
             "gemm_split_kernel": PEAK_X6_TFLOPS}.get(name)
     if peak:
@@ -405,7 +405,7 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
         "value": n / dt, "unit": "neighborhoods/s", "ms_per_step": 1e3 * dt / len(batches),
         "rows_per_s": rows / dt, "steps": len(batches), "rows_per_step": rows / len(batches),
         "max_rows_per_step": max(b.num_rows for b in batches), "kernel_ms_per_step": tot / len(batches),
-        "launches_per_step": sum(v["calls"] for v in summ.values()) / len(batches),
+        "launches_per_step": sum(v["launches"] for v in summ.values()) / len(batches),
         "launch_mode": "hipGraph replay per batch",
         "eager": {"value": n / dt_eager, "ms_per_step": 1e3 * dt_eager / len(batches),
                   "note": "same steps as eager launches with per-launch HIP events (host-bound)"},
@@ -413,10 +413,10 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
         "loss_first_pass_first_batch": float(first), "loss_last_batch": float(last),
         "config": {"workload": f"Syn_1827-shaped synthetic, all {gs.num_graphs} graphs ({part.num_neigh} neighborhoods, "
                                f"{part.num_rows} rows), batch {batch_size} neighborhoods, every {stride}-th batch of the "
-                               f"epoch, 29 queries, exact canonical-count labels, Adam (torch)",
+                               f"epoch, 29 queries, exact canonical-count labels, Adam (desco_adam_step_f32)",
                    "prep_s": round(t_prep, 2)},
         "roofline": roof,
-        "kernels": {k: {"launches_per_step": round(v["calls"] / len(batches), 1),
+        "kernels": {k: {"launches_per_step": round(v["launches"] / len(batches), 1),
                         "ms_per_step": round(v["ms"] / len(batches), 3)}
                     for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]},
     }
@@ -477,6 +477,7 @@ def train_gossip_leg(device, batch_graphs=256):
     nodes = 2 * sum(b.num_nodes for b in batches)
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     peak = {"gemm_f32_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": PEAK_F32_MFMA_TFLOPS,
+            "gemm_f32_multi_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_multi_kernel": PEAK_F32_MFMA_TFLOPS,
             "gemm_tn_partial_kernel": PEAK_F32_MFMA_TFLOPS}.get(name)
     if peak:
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -491,13 +492,13 @@ def train_gossip_leg(device, batch_graphs=256):
         "metric": "nodes/s (gossip-model training step: forward, backward, Adam; 29 queries per node)",
         "value": nodes / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
         "node_query_rows_per_s": 29.0 * nodes / dt, "kernel_ms_per_step": tot / steps,
-        "launches_per_step": sum(v["calls"] for v in summ.values()) / steps, "launch_mode": "eager launches",
+        "launches_per_step": sum(v["launches"] for v in summ.values()) / steps, "launch_mode": "eager launches",
         "dtype": "f32", "data": "synthetic", "loss_first_batch": float(first), "loss_last_batch": float(last),
         "config": {"workload": f"Syn_1827-shaped synthetic, all {gs.num_graphs} graphs ({gs.num_nodes} nodes), batch "
                                f"{batch_graphs} graphs, 29 queries, inputs = exact canonical counts +-10 %, labels = exact "
-                               f"counts, Adam (torch)", "prep_s": round(t_prep, 2)},
+                               f"counts, Adam (desco_adam_step_f32)", "prep_s": round(t_prep, 2)},
         "roofline": roof,
-        "kernels": {k: {"launches_per_step": round(v["calls"] / steps, 1), "ms_per_step": round(v["ms"] / steps, 3)}
+        "kernels": {k: {"launches_per_step": round(v["launches"] / steps, 1), "ms_per_step": round(v["ms"] / steps, 3)}
                     for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]},
     }
 

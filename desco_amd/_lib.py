@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_libs.sh)
@@ -17,8 +17,21 @@ ABI_VERSION = 4
 
 _lib = None
 
-i64, i32, f32 = c_int64, c_int, c_float
+i64, i32, f32, f64 = c_int64, c_int, c_float, c_double
 vp = c_void_p
+
+class GemmDesc(ctypes.Structure):
+    """desco_gemm_desc (include/desco_hip.h)"""
+    _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32), ("a2", vp), ("lda2", i64), ("k2", i32), ("wt", vp), ("n", i32),
+                ("bias", vp), ("bias_rows", i32), ("s", vp), ("ns", i32), ("ws", vp), ("act", i32), ("slope", f32),
+                ("c", vp), ("ldc", i64), ("m", i64)]
+
+
+class BwdWDesc(ctypes.Structure):
+    """desco_bwd_w_desc (include/desco_hip.h)"""
+    _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32), ("a2", vp), ("lda2", i64), ("k2", i32), ("dz", vp),
+                ("lddz", i64), ("m", i64), ("n", i32), ("dwt", vp), ("dbias", vp)]
+
 
 # name -> (restype, argtypes); mirrors include/desco_hip.h one to one
 SIGNATURES = {
@@ -81,6 +94,10 @@ SIGNATURES = {
     "desco_linear_bwd_w_workspace": (ctypes.c_size_t, [i64, i32, i32]),
     "desco_linear_bwd_w_f32": (c_int, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i32, vp, i64, vp, vp, vp]),
     "desco_colsum_f32": (c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "desco_gemm_f32_multi": (c_int, [i32, POINTER(GemmDesc), vp]),
+    "desco_linear_bwd_w_multi_workspace": (ctypes.c_size_t, [i32, POINTER(BwdWDesc)]),
+    "desco_linear_bwd_w_multi_f32": (c_int, [i32, POINTER(BwdWDesc), vp, vp]),
+    "desco_adam_step_f32": (c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp]),
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),
     "desco_count_head_bwd_workspace": (ctypes.c_size_t, [i64, i32, i32]),
     "desco_count_head_bwd_f32": (c_int, [vp, i64, vp, i64, i32, vp, f32, vp, i64, i64, i32, vp, i64,

@@ -143,9 +143,14 @@ class ShmpTrunk(torch.autograd.Function):
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
             xn = xall[l]
-            for g, (t, r0, r1, su) in enumerate(groups):
-                if r1 > r0:
-                    _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], Wt[g][l], Bs[g][l], ops.ACT_RELU, 0.0, out=xn[r0:r1])
+            if PRECISION == "fp32" and len(groups) > 1:
+                # the row types' products of one layer are independent: one launch (desco_gemm_f32_multi)
+                ops.gemm_multi([dict(a1=agg[r0:r1, :su * H], a2=X[-1][r0:r1], wt=Wt[g][l], bias=Bs[g][l],
+                                     act=ops.ACT_RELU, out=xn[r0:r1]) for g, (t, r0, r1, su) in enumerate(groups)])
+            else:
+                for g, (t, r0, r1, su) in enumerate(groups):
+                    if r1 > r0:
+                        _mm_fwd(agg[r0:r1, :su * H], X[-1][r0:r1], Wt[g][l], Bs[g][l], ops.ACT_RELU, 0.0, out=xn[r0:r1])
             AGG.append(agg)
             X.append(xn)
         pooled = torch.empty((B, P), device=dev)
@@ -211,16 +216,26 @@ class ShmpTrunk(torch.autograd.Function):
                              dpooled[:, L * H:(L + 1) * H], ti["seg_id"],
                              None if dcanon is None else dcanon[:, L * H:(L + 1) * H], X[L])
         D = torch.empty((N, (S + 1) * H), device=dev)
-        for l in range(L - 1, -1, -1):
-            for g, (t, r0, r1, su) in enumerate(groups):
-                if r1 <= r0:
-                    grads[k + 2 * g][l].zero_()
-                    grads[k + 2 * g + 1][l].zero_()
-                    continue
-                ops.linear_bwd_w(AGG[l][r0:r1, :su * H], X[l][r0:r1], dz[r0:r1], True,
-                                 dwt=grads[k + 2 * g][l], dbias=grads[k + 2 * g + 1][l])
-                _mm_bwd_da(dz[r0:r1], Wt[g][l], out=D[r0:r1, :(su + 1) * H])
+        fp32 = PRECISION == "fp32"
+        # transposed weights of all layers in one copy per row type (dA = dZ Wt^T wants the n-major operand)
+        WtT = [w_.transpose(1, 2).contiguous() for w_ in Wt] if fp32 else None
+        wgrad = []                     # the weight / bias gradients feed nothing but the optimizer: formed together,
+        for l in range(L - 1, -1, -1):  # 16 per launch pair, after the chain of input gradients
+            live = [(g, r0, r1, su) for g, (t, r0, r1, su) in enumerate(groups)]
+            for g, r0, r1, su in live:
+                wgrad.append(dict(a1=AGG[l][r0:r1, :su * H], a2=X[l][r0:r1], dz=dz[r0:r1], dwt=grads[k + 2 * g][l],
+                                  dbias=grads[k + 2 * g + 1][l]))
+            if fp32 and len(groups) > 1:
+                ops.gemm_multi([dict(a1=dz[r0:r1], wt=WtT[g][l], out=D[r0:r1, :(su + 1) * H]) for g, r0, r1, su in live])
+            else:
+                for g, r0, r1, su in live:
+                    if r1 > r0:
+                        _mm_bwd_da(dz[r0:r1], Wt[g][l], out=D[r0:r1, :(su + 1) * H])
             dz = dx(l, D, X[l] if l > 0 else None)        # (l == 0: the gradient of x0 itself)
+        for i in range(0, len(wgrad), 16):
+            ops.linear_bwd_w_multi(wgrad[i:i + 16])
+        del wgrad
+        for l in range(L):
             AGG[l] = None
         dxn = dz
         return (dxn, None, None, None) + tuple(grads)

@@ -40,14 +40,11 @@ struct GemmArgs {
 
 constexpr int BM = 128, BN = 64, BK = 32, ASTR = 33;
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ float lds[2 * BM * ASTR + 2 * BK * BN];
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, float* lds, const int64_t m0, const int n0) {
   float* As = lds;
   float* Bs = lds + 2 * BM * ASTR;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
   const int nchunks = (g.k1 + g.k2) / BK;
 
   const int arow = tid >> 3, ac4 = tid & 7;    // A: 8 threads x float4 cover one 32-float row
@@ -164,7 +161,71 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ float lds[2 * BM * ASTR + 2 * BK * BN];
+  gemm_f32_tile(g, lds, (int64_t)blockIdx.x * BM, blockIdx.y * BN);
+}
+
+// Several independent products in ONE launch (desco_gemm_f32_multi): the count-row and canonical-row halves of a
+// training layer -- different row ranges, different weights, nothing to wait for between them -- were two launches
+// of a few microseconds each, forty of them per step.  Workgroups [blk_end[i-1], blk_end[i]) belong to product i.
+constexpr int kGemmMulti = 4;
+struct GemmMulti {
+  GemmArgs g[kGemmMulti];
+  int blk_end[kGemmMulti];
+  int num;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mg) {
+  __shared__ float lds[2 * BM * ASTR + 2 * BK * BN];
+  int b = blockIdx.x, i = 0;
+  while (i < mg.num - 1 && b >= mg.blk_end[i]) ++i;
+  b -= i ? mg.blk_end[i - 1] : 0;
+  const GemmArgs& g = mg.g[i];                       // (uniform index: scalar loads from the kernel arguments)
+  const int gm = (int)((g.m + BM - 1) / BM);
+  gemm_f32_tile(g, lds, (int64_t)(b % gm) * BM, (b / gm) * BN);
+}
+
 }  // namespace desco
+
+static const char* gemm_f32_check(const desco::GemmArgs& g) {
+  using namespace desco;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (g.m < 0 || !g.a1 || !g.wt || !g.c || g.k1 <= 0 || g.k1 % BK || g.k2 < 0 || g.k2 % BK || g.n <= 0 || g.n % BN ||
+      (g.k2 > 0 && !g.a2) || g.ns < 0 || g.ns > 4 || (g.ns > 0 && (!g.s || !g.ws)) || (g.bias && g.bias_rows < 1) ||
+      g.lda1 % 4 || (g.k2 > 0 && g.lda2 % 4) || mis16(g.a1) || (g.k2 > 0 && mis16(g.a2)) || mis16(g.wt))
+    return "bad argument (k%32, n%64, 16-byte alignment)";
+  if ((g.m + BM - 1) / BM * (g.n / BN) > INT32_MAX / 2) return "m too large";
+  return nullptr;
+}
+
+extern "C" int desco_gemm_f32_multi(int num, const desco_gemm_desc* d, desco_stream_t stream) {
+  using namespace desco;
+  if (num < 0 || num > kGemmMulti || (num > 0 && !d))
+    return fail(DESCO_EINVAL, "desco_gemm_f32_multi: 0..4 products per launch");
+  GemmMulti mg;
+  mg.num = 0;
+  int blocks = 0;
+  for (int i = 0; i < num; ++i) {
+    if (d[i].m == 0) continue;
+    GemmArgs g{d[i].a1, d[i].lda1, d[i].k1, d[i].a2, d[i].lda2, d[i].k2, d[i].wt, d[i].n, d[i].bias,
+               d[i].bias ? d[i].bias_rows : 1, d[i].s, d[i].ns, d[i].ws, d[i].act, d[i].slope, d[i].c, d[i].ldc, d[i].m};
+    if (const char* why = gemm_f32_check(g)) {
+      std::string msg = std::string("desco_gemm_f32_multi: ") + why;
+      return fail(DESCO_EINVAL, msg.c_str());
+    }
+    blocks += (int)((g.m + BM - 1) / BM) * (g.n / BN);
+    mg.g[mg.num] = g;
+    mg.blk_end[mg.num++] = blocks;
+  }
+  if (mg.num == 0) return 0;
+  for (int i = mg.num; i < kGemmMulti; ++i) {
+    mg.g[i] = mg.g[0];
+    mg.blk_end[i] = blocks;
+  }
+  hipLaunchKernelGGL(gemm_f32_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mg);
+  return launch_status("desco_gemm_f32_multi");
+}
 
 extern "C" int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2,
                               int k2, const float* wt, int n, const float* bias, int bias_rows,

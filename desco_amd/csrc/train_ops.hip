@@ -71,18 +71,18 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(const float* __res
 //   partial[s][K][n0:n0+64]        = sum over slab s of dZ[m,n]                      (k tile K/64: the bias row)
 // A1 [M,k1] and A2 [M,k2] are the two operands of the forward GEMM (aggregate | x); the bias row rides
 // in the same workspace, so ONE reduce finishes dWt and db -- six launches of the step become two.
-__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
+__device__ __forceinline__ void linear_bwd_w_partial_tile(
+    float* lds, const int bx, const int by, const int bz,
     const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
     const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
     float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias) {
   // direct_dwt != NULL (one slab): the block's tile IS the result -- written to dwt / dbias, no reduce launch
-  __shared__ float lds[2 * TMC * 64];
   float* As = lds;              // [32 m][64 k]
   float* Bs = lds + TMC * 64;   // [32 m][64 n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int k0 = blockIdx.x * TK, n0 = blockIdx.y * TN;
-  const int64_t m_beg = (int64_t)blockIdx.z * slab;
+  const int k0 = bx * TK, n0 = by * TN;
+  const int64_t m_beg = (int64_t)bz * slab;
   const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
   const int64_t rows = (int64_t)K + 1;                      // partial rows per slab (K weight rows + bias)
   if (k0 >= K) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
       if (direct_dwt) {
         if (direct_dbias) direct_dbias[n0 + tid] = t;
       } else {
-        partial[((int64_t)blockIdx.z * rows + K) * N + n0 + tid] = t;
+        partial[((int64_t)bz * rows + K) * N + n0 + tid] = t;
       }
     }
     return;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     for (int mm = 0; mm < TMC / 2; ++mm)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * mm * 64], bs[2 * mm * 64], acc, 0, 0, 0);
   }
-  float* out = direct_dwt ? direct_dwt + (int64_t)k0 * lddw + n0 : partial + ((int64_t)blockIdx.z * rows + k0) * N + n0;
+  float* out = direct_dwt ? direct_dwt + (int64_t)k0 * lddw + n0 : partial + ((int64_t)bz * rows + k0) * N + n0;
   const int64_t ldout = direct_dwt ? lddw : N;
   const int col = wc * 32 + (lane & 31);
 #pragma unroll
@@ -143,6 +143,64 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     const int row = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
     out[(int64_t)row * ldout + col] = acc[reg];
   }
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
+    const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
+    const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
+    float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias) {
+  __shared__ float lds[2 * TMC * 64];
+  linear_bwd_w_partial_tile(lds, blockIdx.x, blockIdx.y, blockIdx.z, a1, lda1, k1, a2, lda2, b, ldb, M, K, N, slab,
+                            partial, direct_dwt, lddw, direct_dbias);
+}
+
+// Up to 16 independent weight/bias gradients in ONE partial launch and ONE reduce launch (desco_linear_bwd_w_multi_f32):
+// the 16 (layer, row type) gradients of a training step's trunk are off its critical path -- nothing downstream waits
+// for them but the optimizer -- so they are formed together after the last layer's input gradient.
+constexpr int kBwdWMulti = 16;
+struct BwdWMulti {
+  const float* a1[kBwdWMulti];
+  const float* a2[kBwdWMulti];
+  const float* dz[kBwdWMulti];
+  float* dwt[kBwdWMulti];
+  float* dbias[kBwdWMulti];
+  int64_t lda1[kBwdWMulti], lda2[kBwdWMulti], lddz[kBwdWMulti], m[kBwdWMulti], slab[kBwdWMulti];
+  int64_t ws_off[kBwdWMulti];        // floats: start of the problem's partials in the workspace
+  int k1[kBwdWMulti], k[kBwdWMulti], n[kBwdWMulti], splits[kBwdWMulti];
+  int blk_end[kBwdWMulti];           // partial launch: running workgroup count
+  int red_end[kBwdWMulti];           // reduce launch: running workgroup count
+  int num;
+};
+
+__global__ __launch_bounds__(256) void linear_bwd_w_multi_partial_kernel(const BwdWMulti q, float* __restrict__ ws) {
+  __shared__ float lds[2 * TMC * 64];
+  int b = blockIdx.x, i = 0;
+  while (i < q.num - 1 && b >= q.blk_end[i]) ++i;
+  b -= i ? q.blk_end[i - 1] : 0;
+  const int gx = q.k[i] / TK + 1, gy = q.n[i] / TN;
+  const int bx = b % gx, by = (b / gx) % gy, bz = b / (gx * gy);
+  const bool direct = q.splits[i] == 1;
+  linear_bwd_w_partial_tile(lds, bx, by, bz, q.a1[i], q.lda1[i], q.k1[i], q.a2[i], q.lda2[i], q.dz[i], q.lddz[i],
+                            q.m[i], q.k[i], q.n[i], q.slab[i], ws + q.ws_off[i], direct ? q.dwt[i] : nullptr,
+                            (int64_t)q.n[i], direct ? q.dbias[i] : nullptr);
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_w_multi_reduce_kernel(const BwdWMulti q, const float* __restrict__ ws) {
+  int b = blockIdx.x, i = 0;
+  while (i < q.num - 1 && b >= q.red_end[i]) ++i;
+  b -= i ? q.red_end[i - 1] : 0;
+  const int K = q.k[i], N = q.n[i], splits = q.splits[i];
+  const int64_t e = (int64_t)b * blockDim.x + threadIdx.x;
+  const int64_t count = (int64_t)(K + 1) * N;
+  if (e >= count) return;
+  const float* partial = ws + q.ws_off[i];
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * count + e];
+  const int64_t row = e / N, col = e % N;
+  if (row < K)
+    q.dwt[i][row * N + col] = s;
+  else if (q.dbias[i])
+    q.dbias[i][col] = s;
 }
 
 // dwt[k][n] = sum_s partial[s][k][n] (k < K), dbias[n] = sum_s partial[s][K][n]   (fixed order)
@@ -387,6 +445,51 @@ extern "C" int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, con
   hipLaunchKernelGGL(linear_bwd_w_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                      workspace, k, n, splits, dwt, lddw, dbias);
   return launch_status("desco_linear_bwd_w_f32");
+}
+
+extern "C" size_t desco_linear_bwd_w_multi_workspace(int num, const desco_bwd_w_desc* d) {
+  size_t total = 0;
+  for (int i = 0; i < num; ++i) total += desco_linear_bwd_w_workspace(d[i].m, d[i].k1 + d[i].k2, d[i].n);
+  return total;
+}
+
+extern "C" int desco_linear_bwd_w_multi_f32(int num, const desco_bwd_w_desc* d, float* workspace,
+                                            desco_stream_t stream) {
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (num < 0 || num > kBwdWMulti || (num > 0 && (!d || !workspace)))
+    return fail(DESCO_EINVAL, "desco_linear_bwd_w_multi_f32: 0..16 problems per call, workspace required");
+  BwdWMulti q;
+  q.num = 0;
+  int blocks = 0, rblocks = 0;
+  int64_t off = 0;
+  for (int i = 0; i < num; ++i) {
+    const desco_bwd_w_desc& e = d[i];
+    const int k = e.k1 + e.k2;
+    if (!e.a1 || !e.dz || !e.dwt || e.m < 0 || e.k1 <= 0 || e.k1 % TK || e.k2 < 0 || e.k2 % TK || e.n <= 0 ||
+        e.n % TN || (e.k2 > 0 && (!e.a2 || e.lda2 % 4 || mis16(e.a2))) || e.lda1 % 4 || e.lddz % 4 || mis16(e.a1) ||
+        mis16(e.dz))
+      return fail(DESCO_EINVAL, "desco_linear_bwd_w_multi_f32: bad argument (k%64, n%64, 16-byte alignment)");
+    const int splits = linear_bwd_w_splits(e.m, k, e.n);
+    int64_t slab = (e.m + splits - 1) / splits;
+    slab = (slab + TMC - 1) / TMC * TMC;
+    if (slab < TMC) slab = TMC;
+    const int j = q.num++;
+    q.a1[j] = e.a1; q.a2[j] = e.k2 ? e.a2 : e.a1; q.dz[j] = e.dz; q.dwt[j] = e.dwt; q.dbias[j] = e.dbias;
+    q.lda1[j] = e.lda1; q.lda2[j] = e.k2 ? e.lda2 : e.lda1; q.lddz[j] = e.lddz; q.m[j] = e.m; q.slab[j] = slab;
+    q.ws_off[j] = off;
+    q.k1[j] = e.k1; q.k[j] = k; q.n[j] = e.n; q.splits[j] = splits;
+    blocks += (k / TK + 1) * (e.n / TN) * splits;
+    q.blk_end[j] = blocks;
+    if (splits > 1) rblocks += (int)(((int64_t)(k + 1) * e.n + 255) / 256);
+    q.red_end[j] = rblocks;
+    off += (int64_t)splits * (k + 1) * e.n;
+  }
+  if (q.num == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_bwd_w_multi_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q, workspace);
+  if (rblocks > 0)
+    hipLaunchKernelGGL(linear_bwd_w_multi_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, q, workspace);
+  return launch_status("desco_linear_bwd_w_multi_f32");
 }
 
 extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out,

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .optim import Adam
 from .batch import GossipBatch, NeighborhoodBatch, QueryBatch
 from .data import graph_atlas_plus
 from .gnn_model import (BaseGNN, H, QUERY_EDGE_TYPES_TCONV, QUERY_EDGE_TYPES_UNION,
@@ -321,7 +322,7 @@ class NeighborhoodCountingModel(_LightningLike):
         return self.criterion(F.relu(2 ** (logits - 1)), y)
 
     def configure_optimizers(self):                                          # :160-173
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        optimizer = Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)   # (desco_adam_step_f32)
         sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,
                                                            patience=20, min_lr=1e-5)
         return {"optimizer": optimizer, "lr_scheduler": sched,
@@ -390,7 +391,7 @@ class GossipCountingModel(_LightningLike):
                                 for layer in self.emb_model.gnn_core.convs], dim=0)
 
     def configure_optimizers(self):                                         # :570-583
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        optimizer = Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)   # (desco_adam_step_f32)
         sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5,
                                                            patience=20, min_lr=1e-5)
         return {"optimizer": optimizer, "lr_scheduler": sched, "monitor": "gossip_counting_val_loss"}

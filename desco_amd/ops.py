@@ -18,23 +18,24 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 class LaunchProfiler:
     """Optional per-launch HIP-event timing on the launch stream (used by bench.py's roofline leg).
 
-    When enabled every wrapper brackets its single kernel launch with two events recorded on the
-    current stream and notes the launch's algorithmic flops / bytes."""
+    When enabled every wrapper brackets its C-ABI call (one kernel launch; the few calls that are two to four
+    launches say so) with two events recorded on the current stream and notes its algorithmic flops / bytes."""
 
     def __init__(self):
         self.enabled = False
         self.by_shape = False  # tools: key GEMM launches by shape as well ("kernel[m x k x n]")
-        self.records = []      # (kernel, flops, bytes, start_event, end_event)
+        self.records = []      # (kernel, flops, bytes, start_event, end_event, launches)
 
     def reset(self):
         self.records = []
 
     def summary(self):
-        """kernel -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        """kernel -> dict(calls, launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
         out = {}
-        for name, fl, by, e0, e1 in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, fl, by, e0, e1, nl in self.records:
+            d = out.setdefault(name, {"calls": 0, "launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["calls"] += 1
+            d["launches"] += nl
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += by
@@ -45,12 +46,12 @@ PROFILER = LaunchProfiler()
 
 
 class _Timed:
-    __slots__ = ("name", "flops", "bytes", "e0")
+    __slots__ = ("name", "flops", "bytes", "e0", "launches")
 
-    def __init__(self, name, flops=0.0, nbytes=0.0, shape=None):
+    def __init__(self, name, flops=0.0, nbytes=0.0, shape=None, launches=1):
         if shape is not None and PROFILER.by_shape:
             name = f"{name}[{'x'.join(str(v) for v in shape)}]"
-        self.name, self.flops, self.bytes = name, flops, nbytes
+        self.name, self.flops, self.bytes, self.launches = name, flops, nbytes, launches
 
     def __enter__(self):
         if PROFILER.enabled:
@@ -62,7 +63,7 @@ class _Timed:
         if PROFILER.enabled:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILER.records.append((self.name, self.flops, self.bytes, self.e0, e1))
+            PROFILER.records.append((self.name, self.flops, self.bytes, self.e0, e1, self.launches))
         return False
 
 
@@ -220,6 +221,66 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
                                     _opt(bias, "bias"), bias_rows, _opt(s, "s"), ns,
                                     _opt(ws, "ws"), act, slope, op, ldo, m, _stream()), "gemm")
     return out
+
+
+def gemm_multi(problems) -> None:
+    """Up to four independent ``gemm`` problems in one launch (desco_gemm_f32_multi).  ``problems``: dicts with the
+    keyword arguments of ``gemm`` (a1, wt, bias, a2, act, slope, out -- ``out`` required); empty ones (no rows) are
+    skipped."""
+    descs = (_lib.GemmDesc * len(problems))()
+    flops = nbytes = 0.0
+    for d, pr in zip(descs, problems):
+        a1, wt, out, a2, bias = pr["a1"], pr["wt"], pr["out"], pr.get("a2"), pr.get("bias")
+        m, k1 = a1.shape
+        k2 = 0 if a2 is None else a2.shape[1]
+        n = wt.shape[1]
+        assert wt.shape[0] == k1 + k2 and wt.is_contiguous() and tuple(out.shape) == (m, n)
+        d.m = m
+        if m == 0:
+            continue
+        d.a1, d.lda1 = _rows(a1, "a1")
+        d.k1, d.k2 = k1, k2
+        if a2 is not None:
+            d.a2, d.lda2 = _rows(a2, "a2")
+        d.wt, d.n = _dev(wt, "wt"), n
+        if bias is not None:
+            assert bias.is_contiguous() and bias.dim() == 1
+            d.bias, d.bias_rows = _dev(bias, "bias"), 1
+        d.act, d.slope = pr.get("act", ACT_NONE), pr.get("slope", 0.0)
+        d.c, d.ldc = _rows(out, "out")
+        flops += 2.0 * m * (k1 + k2) * n
+        nbytes += 4.0 * (m * (k1 + k2) + (k1 + k2) * n + m * n)
+    L = _lib.lib()
+    with _Timed("gemm_f32_multi_kernel", flops, nbytes):
+        _lib.check(L.desco_gemm_f32_multi(len(problems), descs, _stream()), "gemm_multi")
+
+
+def linear_bwd_w_multi(problems) -> None:
+    """Up to 16 independent ``linear_bwd_w`` problems in two launches (desco_linear_bwd_w_multi_f32).  ``problems``:
+    dicts a1, a2 (or None), dz, dwt (contiguous [(k1+k2), n]), dbias ([n] or None)."""
+    descs = (_lib.BwdWDesc * len(problems))()
+    flops = nbytes = 0.0
+    for d, pr in zip(descs, problems):
+        a1, a2, dz, dwt, dbias = pr["a1"], pr.get("a2"), pr["dz"], pr["dwt"], pr.get("dbias")
+        m, k1 = a1.shape
+        k2 = 0 if a2 is None else a2.shape[1]
+        n = dz.shape[1]
+        assert dwt.is_contiguous() and tuple(dwt.shape) == (k1 + k2, n) and dz.shape[0] == m
+        assert dbias is None or (dbias.is_contiguous() and dbias.numel() == n)
+        d.a1, d.lda1 = _rows(a1, "a1")
+        d.k1, d.k2 = k1, k2
+        if a2 is not None:
+            d.a2, d.lda2 = _rows(a2, "a2")
+        d.dz, d.lddz = _rows(dz, "dz")
+        d.m, d.n = m, n
+        d.dwt, d.dbias = _dev(dwt, "dwt"), _opt(dbias, "dbias")
+        flops += 2.0 * m * (k1 + k2) * n
+        nbytes += 4.0 * (m * (k1 + k2) + 2 * m * n)
+    L = _lib.lib()
+    nb = L.desco_linear_bwd_w_multi_workspace(len(problems), descs)
+    ws = torch.empty((max(nb // 4, 1),), device=problems[0]["dz"].device, dtype=torch.float32)
+    with _Timed("linear_bwd_w_multi_kernel", flops, nbytes, launches=2):
+        _lib.check(L.desco_linear_bwd_w_multi_f32(len(problems), descs, _dev(ws, "ws"), _stream()), "linear_bwd_w_multi")
 
 
 def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0: int,
@@ -808,7 +869,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     splits = ctypes.c_int(0)
     nbytes = L.desco_gemm_tn_workspace(m, k, n, ctypes.byref(splits))
     ws = torch.empty((max(nbytes // 4, 1),), device=a.device, dtype=torch.float32)
-    with _Timed("gemm_tn_partial_kernel", 2.0 * m * k * n, 4.0 * (m * k + m * n)):
+    with _Timed("gemm_tn_partial_kernel", 2.0 * m * k * n, 4.0 * (m * k + m * n), launches=2):
         _lib.check(L.desco_gemm_tn_f32(ap, lda, bp, ldb, m, k, n, op, ldo, int(accumulate),
                                        _dev(ws, "ws"), _stream()), "gemm_tn")
     return out
@@ -835,7 +896,8 @@ def linear_bwd_w(a1: torch.Tensor, a2: Optional[torch.Tensor], dz: torch.Tensor,
     L = _lib.lib()
     nbytes = L.desco_linear_bwd_w_workspace(m, k1 + k2, n)
     ws = torch.empty((max(nbytes // 4, 1),), device=dz.device, dtype=torch.float32)
-    with _Timed("linear_bwd_w_kernel", 2.0 * m * (k1 + k2) * n, 4.0 * (m * (k1 + k2) + 2 * m * n)):
+    with _Timed("linear_bwd_w_kernel", 2.0 * m * (k1 + k2) * n, 4.0 * (m * (k1 + k2) + 2 * m * n),
+                launches=1 if nbytes <= 4 * (k1 + k2 + 1) * n else 2):        # (one M slab: results written in place)
         _lib.check(L.desco_linear_bwd_w_f32(a1p, lda1, k1, a2p, lda2, k2, zp, ldz, m, n, _dev(dwt, "dwt"), n,
                                             _opt(dbias, "dbias"), _dev(ws, "ws"), _stream()), "linear_bwd_w")
     return dwt, dbias
@@ -850,7 +912,7 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     xp, ldx = _rows(x, "x")
     ws = torch.empty((512 * n,), device=x.device, dtype=torch.float32)
     L = _lib.lib()
-    with _Timed("colsum_partial_kernel", float(m) * n, 4.0 * m * n):
+    with _Timed("colsum_partial_kernel", float(m) * n, 4.0 * m * n, launches=2):
         _lib.check(L.desco_colsum_f32(xp, ldx, m, n, _dev(out, "out"), int(accumulate),
                                       _dev(ws, "ws"), _stream()), "colsum")
     return out
@@ -882,7 +944,7 @@ def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: f
     ws = torch.empty((L.desco_count_head_bwd_workspace(B, Q, hid) // 4,), device=t.device, dtype=torch.float32)
     tp, ldt = _rows(t, "t")
     qp, ldq = _rows(qh, "qh")
-    with _Timed("count_head_bwd", 6.0 * B * Q * hid, 4.0 * (2 * B * hid + Q * hid + B * Q)):
+    with _Timed("count_head_bwd", 6.0 * B * Q * hid, 4.0 * (2 * B * hid + Q * hid + B * Q), launches=4):
         _lib.check(L.desco_count_head_bwd_f32(tp, ldt, qp, ldq, hid, _dev(w2.contiguous(), "w2"),
                                               slope, _dev(dl, "dl"), Q, B, Q, _dev(dt, "dt"), hid,
                                               _dev(dqh, "dqh"), _dev(dw2, "dw2"), _dev(ws, "ws"),
@@ -915,7 +977,7 @@ def affine_rows_bwd(c: torch.Tensor, dz: torch.Tensor, qv: int) -> torch.Tensor:
     dv = torch.empty((qv, ks, 64), device=c.device, dtype=torch.float32)
     ws = torch.empty((64 * qv * ks * 64,), device=c.device, dtype=torch.float32)
     L = _lib.lib()
-    with _Timed("affine_rows_bwd_kernel", 2.0 * R * ks * 64, 4.0 * R * (ks + 64)):
+    with _Timed("affine_rows_bwd_kernel", 2.0 * R * ks * 64, 4.0 * R * (ks + 64), launches=2):
         _lib.check(L.desco_affine_rows_bwd_f32(_dev(c, "c"), ks, _dev(dz, "dz"), qv, R,
                                                _dev(dv, "dv"), _dev(ws, "ws"), _stream()),
                    "affine_rows_bwd")

@@ -138,10 +138,6 @@ class Trainer:
         # capture happens on a side stream, and autograd's AccumulateGrad nodes must have been created
         # on that same stream: with graph_capture the whole training loop runs on it
         side = torch.cuda.Stream(self.device) if use_graphs else None
-        if use_graphs:
-            for g_ in opt.param_groups:       # Adam state and lr as device tensors: capturable
-                g_["capturable"] = True
-                g_["lr"] = torch.tensor(float(g_["lr"]), device=self.device)
         for epoch in range(self.max_epochs):
             model.train()
             if use_graphs:
@@ -162,16 +158,9 @@ class Trainer:
                     opt.step()
             model.eval()
             val = self._mean_loss(model, datamodule.val_dataloader(), "validation_step")
-            if use_graphs:       # keep the captured graphs' lr tensor; the scheduler works on floats
-                lr_t = [g_["lr"] for g_ in opt.param_groups]
-                for g_, t_ in zip(opt.param_groups, lr_t):
-                    g_["lr"] = float(t_)
-                sched.step(val)
-                for g_, t_ in zip(opt.param_groups, lr_t):
-                    t_.fill_(float(g_["lr"]))
-                    g_["lr"] = t_
-            else:
-                sched.step(val)
+            sched.step(val)
+            if hasattr(opt, "sync_lr"):      # replayed steps read the rate from device memory (optim.Adam)
+                opt.sync_lr()
             self.history.append({"epoch": epoch, cfg["monitor"]: val, "lr": float(opt.param_groups[0]["lr"])})
             if self._rank0() and self.verbose:
                 print(f"epoch {epoch}: {cfg['monitor']} = {val:.6g}  lr = {float(opt.param_groups[0]['lr']):.3g}",

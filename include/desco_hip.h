@@ -180,6 +180,20 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
                    int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
                    int64_t m, desco_stream_t stream);
 
+/* Up to four INDEPENDENT products of desco_gemm_f32's form in one launch (the count-row and canonical-row halves of a
+ * training layer, lightning_model.py:228-254 through gnn_model.py:253-277: same step, disjoint rows, different
+ * weights).  Field meaning as the arguments of desco_gemm_f32; descriptors with m == 0 are skipped. */
+typedef struct desco_gemm_desc {
+  const float* a1; int64_t lda1; int k1;
+  const float* a2; int64_t lda2; int k2;
+  const float* wt; int n;
+  const float* bias; int bias_rows;
+  const float* s; int ns; const float* ws;
+  int act; float slope;
+  float* c; int64_t ldc; int64_t m;
+} desco_gemm_desc;
+int desco_gemm_f32_multi(int num, const desco_gemm_desc* descs, desco_stream_t stream);
+
 /* Same contract as desco_gemm_f32 but computed on the bf16 matrix pipe with fp32-level accuracy
  * ("bf16x6": each fp32 operand is split into three bf16 terms, the six products of weight >= 2^-16
  * are accumulated in fp32; error ~2^-23 per product).  The weight is passed N-MAJOR and already
@@ -478,9 +492,33 @@ int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, const float* a
                            const float* dz, int64_t lddz, int64_t m, int n, float* dwt, int64_t lddw,
                            float* dbias, float* workspace, desco_stream_t stream);
 
+/* Up to 16 independent problems of desco_linear_bwd_w_f32's form (contiguous dwt: lddw = n) in one partial launch and
+ * one reduce launch: the (layer, row type) weight gradients of a training step's trunk, which nothing but the optimizer
+ * waits for.  m == 0 gives zero gradients.  workspace: desco_linear_bwd_w_multi_workspace(num, descs) bytes. */
+typedef struct desco_bwd_w_desc {
+  const float* a1; int64_t lda1; int k1;
+  const float* a2; int64_t lda2; int k2;
+  const float* dz; int64_t lddz; int64_t m; int n;
+  float* dwt; float* dbias;
+} desco_bwd_w_desc;
+size_t desco_linear_bwd_w_multi_workspace(int num, const desco_bwd_w_desc* descs);
+int desco_linear_bwd_w_multi_f32(int num, const desco_bwd_w_desc* descs, float* workspace, desco_stream_t stream);
+
 /* bias gradient: out[n] (+)= sum_m x[m, n];  workspace: 512 * n floats */
 int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out, int accumulate,
                      float* workspace, desco_stream_t stream);
+
+/* torch.optim.Adam's step (both models' configure_optimizers, reference lightning_model.py:160-173, 570-583:
+ * Adam(lr, weight_decay), default betas / eps, L2 decay, no amsgrad) for a LIST of tensors, one launch per 128 tensors:
+ *   g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;
+ *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)              (bias corrections and 1 - beta in double, as torch forms them)
+ * params / grads / sizes: HOST arrays of `num` device pointers / element counts; grads[i] == NULL skips tensor i (value,
+ * moments and age untouched, as torch skips parameters without gradient).  m, v: device, flat, tensor i at offset
+ * sum(sizes[:i]); steps [num] float (per-tensor step count t, advanced by the launch), arrivals [num] uint32 (zero
+ * before the first call; scratch), lr [1] float: all device memory, so a captured launch replays without host work. */
+int desco_adam_step_f32(int num, float* const* params, const float* const* grads, const int64_t* sizes, float* m,
+                        float* v, float* steps, uint32_t* arrivals, const float* lr, double beta1, double beta2,
+                        double eps, double weight_decay, desco_stream_t stream);
 
 /* dz = dc * act'(c) for c = act(z) (contiguous, count elements) */
 int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,

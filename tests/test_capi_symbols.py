@@ -73,3 +73,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DescoLibraryError, match="no CPU or PyTorch fallback"):
         _lib.lib()
+
+
+def test_adam_refuses_cpu_parameters():
+    from desco_amd.optim import Adam
+    import torch
+    p = torch.zeros(4, requires_grad=True)
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Adam([p]).step()

@@ -594,3 +594,47 @@ def test_fused_shmp_layer_f16x3_is_fp32_accurate_over_the_fp32_range(kind):
     print(f"[accuracy] shmp layer {kind}: max err / sum|a||w|  f16x3 {errs['f16x3']:.2e}  bf16x6 {errs['bf16x6']:.2e}  "
           f"f32-MFMA {errs['f32']:.2e}")
     assert errs["f16x3"] <= 2.0 * max(errs["f32"], errs["bf16x6"])
+
+
+# ---- the optimizer launch (csrc/adam.hip, desco_amd/optim.py) -----------------------------------------------------------
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_matches_torch_adam(wd):
+    """desco_amd.optim.Adam against torch.optim.Adam (the reference's optimizer, lightning_model.py:160-173) on a
+    ragged parameter list: unaligned sizes, one tensor > one workgroup's 1024 elements, one parameter that never gets a
+    gradient (skipped, not aged), one that gets one only on some steps, > 128 tensors (two launches)."""
+    from desco_amd.optim import Adam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 64), (7,), (1,), (300, 17), (64,), (5, 3)] + [(3 + i % 11, 1 + i % 5) for i in range(140)]
+    ref = [torch.randn(*s, generator=g).to(DEV).requires_grad_() for s in shapes]
+    own = [p.detach().clone().requires_grad_() for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=3e-3, weight_decay=wd)
+    o_own = Adam(own, lr=3e-3, weight_decay=wd)
+    for step in range(7):
+        if step == 4:          # a scheduler halves the rate (ReduceLROnPlateau writes param_groups[i]["lr"])
+            for o in (o_ref, o_own):
+                o.param_groups[0]["lr"] *= 0.5
+        for i, (a, b) in enumerate(zip(ref, own)):
+            if i == 1 or (i == 4 and step % 2):
+                a.grad = b.grad = None
+                continue
+            gr = (torch.randn(a.shape, generator=g) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=g)))).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o_ref.step()
+        o_own.step()
+    worst = 0.0
+    for a, b in zip(ref, own):
+        worst = max(worst, float(((a - b).abs() / (1e-3 + a.abs())).max()))
+    print(f"[parity] Adam, 7 steps: max |p_own - p_torch| / (1e-3 + |p|) = {worst:.2e}")
+    assert worst < 2e-6
+    assert torch.equal(ref[1], own[1]) and own[1]._version == ref[1]._version      # never updated
+    assert own[0]._version >= 7          # updated through raw pointers, but torch is told (caches key on _version)
+    sd = o_own.state_dict()
+    assert float(sd["state"][4]["step"]) == 4 and float(sd["state"][0]["step"]) == 7 and float(sd["state"][1]["step"]) == 0
+    tsd = o_ref.state_dict()["state"]
+    torch.testing.assert_close(sd["state"][3]["exp_avg_sq"], tsd[3]["exp_avg_sq"], rtol=1e-5, atol=1e-30)
+    # state round trip
+    o2 = Adam([p.detach().clone().requires_grad_() for p in own], lr=1.0)
+    o2.load_state_dict(sd)
+    sd2 = o2.state_dict()
+    assert all(torch.equal(sd2["state"][k]["exp_avg"], sd["state"][k]["exp_avg"]) for k in sd["state"])
+    assert o2.param_groups[0]["lr"] == o_own.param_groups[0]["lr"]

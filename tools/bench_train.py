@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-step throughput of the neighborhood model (config C3 shape: Syn_1827-shaped
 neighborhoods, batch 512, fp32) and of the gossip model (batch 256 graphs) -- developer tool.
-Forward and backward run on the C-ABI kernels via desco_amd.autograd; Adam is torch's."""
+Forward and backward run on the C-ABI kernels via desco_amd.autograd; Adam is desco_adam_step_f32 (desco_amd.optim)."""
 import argparse
 import os
 import sys
@@ -56,9 +56,6 @@ def main():
         opt.step()
         return loss
     if args.graph:
-        for g_ in opt.param_groups:
-            g_["capturable"] = True
-            g_["lr"] = torch.tensor(float(g_["lr"]), device=dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         graphs = {}
@@ -105,7 +102,7 @@ def main():
                "rows_per_s": rows / dt, "steps": len(batches) - 2, "dtype": "f32" if args.precision == "fp32" else "bf16 products, fp32 accumulate",
                "data": "synthetic",
                "config": {"workload": f"{args.workload}-shaped synthetic, first {gs.num_graphs} graphs, batch {args.batch} "
-                                      f"neighborhoods, 29 queries, surrogate labels, Adam (torch)",
+                                      f"neighborhoods, 29 queries, surrogate labels, Adam (desco_adam_step_f32)",
                           "launch_mode": "hipGraph replay per batch" if args.graph else "eager launches",
                           "rows_per_step": rows / (len(batches) - 2)}}
         if args.profile:

@@ -23,7 +23,7 @@ nm = nm.to(DEV); nm.set_queries(qids); nm.train()
 part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=41)[:12]), 4)
 y = torch.floor(torch.rand(part.num_neigh, len(queries)) ** 3 * 40)
 batch = NeighborhoodBatch(part, DEV, y=y)
-opt = torch.optim.Adam(nm.parameters(), lr=1e-3, capturable=True)
+opt = nm.configure_optimizers()["optimizer"]
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):          # AccumulateGrad nodes must be born on the capture stream
