@@ -24,7 +24,8 @@ class GemmDesc(ctypes.Structure):
     """desco_gemm_desc (include/desco_hip.h)"""
     _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32), ("a2", vp), ("lda2", i64), ("k2", i32), ("wt", vp), ("n", i32),
                 ("bias", vp), ("bias_rows", i32), ("s", vp), ("ns", i32), ("ws", vp), ("act", i32), ("slope", f32),
-                ("c", vp), ("ldc", i64), ("m", i64)]
+                ("c", vp), ("ldc", i64), ("m", i64), ("gate", vp), ("ldg", i64), ("gate_act", i32), ("gate_slope", f32),
+                ("accum", i32)]
 
 
 class BwdWDesc(ctypes.Structure):
@@ -97,6 +98,7 @@ SIGNATURES = {
     "desco_gemm_f32_multi": (c_int, [i32, POINTER(GemmDesc), vp]),
     "desco_linear_bwd_w_multi_workspace": (ctypes.c_size_t, [i32, POINTER(BwdWDesc)]),
     "desco_linear_bwd_w_multi_f32": (c_int, [i32, POINTER(BwdWDesc), vp, vp]),
+    "desco_rowdot_bwd_f32": (c_int, [vp, i64, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "desco_adam_step_f32": (c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp]),
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),
     "desco_count_head_bwd_workspace": (ctypes.c_size_t, [i64, i32, i32]),

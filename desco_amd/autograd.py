@@ -333,3 +333,73 @@ class GossipGather(torch.autograd.Function):
             d = ops.gossip_gather(h.contiguous(), rowptr, col, ctx.n, ctx.q, None)
             dg = ops.colsum(ops.rowdot2(dout, d).view(ctx.n, ctx.q))
         return dh, None, None, None, None, dg
+
+
+class GossipTrunk(torch.autograd.Function):
+    """The gossip model's per-(node, query) pipeline -- GossipConv x 2 with the closed-form first layer, post_mp
+    (gnn_model.py:58-103, 303-350 of the reference; algebra in DESIGN.md 4.2) -- as ONE autograd node, like ShmpTrunk:
+    forward and backward are C-ABI launches on buffers this node owns; torch sees the folded operands going in and the
+    correction coming out.  (As separate autograd Functions the step spent a tenth of its GPU time in torch's gradient
+    accumulations, strided copies and zero fills between our kernels, and the activation derivatives were five extra
+    passes over [N Q, 64..256] tensors: here they ride in the epilogue of the GEMM that produces the gradient.)
+
+    args: batch (rowptr / col), num_nodes, num_q, C6 [R,6], C3 [R,3], C2 [R,2] (constants), then tensors with
+    gradients: V0 [Q,6,64], g1 [Q], wt1 [128,64], V1 [Q,3,64], wtp [128,64], Vp [Q,2,64], w3t [64,64], b3 [64],
+    w5t [64,256], b5 [256], w7 [256].  Returns corr0 [R] = post_mp.7's product WITHOUT its bias."""
+
+    @staticmethod
+    def forward(ctx, rowptr, col, n, q, C6, C3, C2, V0, g1, wt1, V1, wtp, Vp, w3t, b3, w5t, b5, w7):
+        V0, V1, Vp = V0.contiguous(), V1.contiguous(), Vp.contiguous()
+        wt1, wtp, w3t, w5t = wt1.contiguous(), wtp.contiguous(), w3t.contiguous(), w5t.contiguous()
+        g1, b3, b5, w7 = g1.contiguous(), b3.contiguous(), b5.contiguous(), w7.contiguous()
+        h1 = ops.affine_rows(None, C6, V0, ops.ACT_RELU, 0.0)                       # layer 0 (closed form)
+        hh = ops.gossip_gather(h1, rowptr, col, n, q, g1)                           # layer 1 aggregate
+        h2 = ops.affine_rows(ops.gemm(hh, wt1, a2=h1), C3, V1, ops.ACT_RELU, 0.0)
+        y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1)   # post_mp.0 + .2
+        y3 = ops.gemm(y, w3t, b3, act=ops.ACT_RELU)
+        y5 = ops.gemm(y3, w5t, b5, act=ops.ACT_RELU)
+        corr = ops.rowdot_add(y5, w7, 0.0, None)
+        ctx.save_for_backward(rowptr, col, C6, C3, C2, g1, wt1, wtp, w3t, w5t, w7, h1, hh, h2, y, y3, y5)
+        ctx.n, ctx.q = n, q
+        return corr
+
+    @staticmethod
+    def backward(ctx, dcorr):
+        rowptr, col, C6, C3, C2, g1, wt1, wtp, w3t, w5t, w7, h1, hh, h2, y, y3, y5 = ctx.saved_tensors
+        n, q = ctx.n, ctx.q
+        R = h1.shape[0]
+        dev = h1.device
+        dz5, dwb7 = ops.rowdot_bwd(y5, w7, dcorr.contiguous())                      # [R,256], (dw7 | .)
+        # dA = dZ W^T wants W itself as the [K = out, N = in] operand: the transposes of the (tiny) folded weights
+        w5 = w5t.t().contiguous()                                                    # [256, 64]
+        w3 = w3t.t().contiguous()
+        wp = wtp.view(2, 64, 64).transpose(1, 2).contiguous()                        # [(h1 | h2) block][out][in]
+        w1 = wt1.view(2, 64, 64).transpose(1, 2).contiguous()                        # [(hh | h1) block][out][in]
+        dz3 = torch.empty((R, 64), device=dev)
+        ops.gemm_multi([dict(a1=dz5, wt=w5, out=dz3, gate=y3, gate_act=ops.ACT_RELU)])
+        dzp = torch.empty((R, 64), device=dev)
+        ops.gemm_multi([dict(a1=dz3, wt=w3, out=dzp, gate=y, gate_act=ops.ACT_LEAKY, gate_slope=0.1)])
+        dVp = ops.affine_rows_bwd(C2, dzp, q)
+        dh1 = torch.empty((R, 64), device=dev)
+        dz1 = torch.empty((R, 64), device=dev)
+        ops.gemm_multi([dict(a1=dzp, wt=wp[0], out=dh1),
+                        dict(a1=dzp, wt=wp[1], out=dz1, gate=h2, gate_act=ops.ACT_RELU)])
+        dV1 = ops.affine_rows_bwd(C3, dz1, q)
+        dhh = torch.empty((R, 64), device=dev)
+        ops.gemm_multi([dict(a1=dz1, wt=w1[0], out=dhh),
+                        dict(a1=dz1, wt=w1[1], out=dh1, accum=True)])
+        # transpose of the gated sum: the same kernel with 1 - g (GossipGather.backward)
+        ops.add_rows(dh1, ops.gossip_gather(dhh, rowptr, col, n, q, (1.0 - g1).contiguous()))
+        dsig = ops.gossip_gather(h1, rowptr, col, n, q, None)                       # d out / d g1
+        dg1 = ops.colsum(ops.rowdot2(dhh, dsig).view(n, q))
+        dz0 = ops.act_grad(dh1, h1, ops.ACT_RELU, 0.0)
+        dV0 = ops.affine_rows_bwd(C6, dz0, q)
+        # the four weight / bias gradients wait for nothing and nothing but the optimizer waits for them: one launch pair
+        dw5t, db5 = torch.empty_like(w5t), torch.empty((256,), device=dev)
+        dw3t, db3 = torch.empty_like(w3t), torch.empty((64,), device=dev)
+        dwtp, dwt1 = torch.empty_like(wtp), torch.empty_like(wt1)
+        ops.linear_bwd_w_multi([dict(a1=y3, dz=dz5, dwt=dw5t, dbias=db5), dict(a1=y, dz=dz3, dwt=dw3t, dbias=db3),
+                                dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
+        return (None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp, dw3t, db3, dw5t, db5,
+                dwb7[:256])
+

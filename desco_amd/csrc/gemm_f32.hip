@@ -36,6 +36,13 @@ struct GemmArgs {
   float* c;
   int64_t ldc;
   int64_t m;
+  // training backward (desco_gemm_f32_multi only): c = v * act'(gate) with gate the saved activation OUTPUT the
+  // produced gradient belongs to (the act_grad pass fused into the epilogue), and c += instead of c = (accum)
+  const float* gate;
+  int64_t ldg;
+  int gate_act;
+  float gate_slope;
+  int accum;
 };
 
 constexpr int BM = 128, BN = 64, BK = 32, ASTR = 33;
@@ -155,7 +162,13 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, float* lds, con
             v += g.bias[(grow % g.bias_rows) * g.n + gcol];
         }
         for (int j = 0; j < g.ns; ++j) v += g.s[grow * g.ns + j] * wsv[j];
-        g.c[grow * g.ldc + gcol] = apply_act(v, g.act, g.slope);
+        v = apply_act(v, g.act, g.slope);
+        if (g.gate) {
+          const float o_ = g.gate[grow * g.ldg + gcol];
+          v = o_ > 0.f ? v : (g.gate_act == DESCO_ACT_RELU ? 0.f : g.gate_act == DESCO_ACT_LEAKY ? v * g.gate_slope : v);
+        }
+        if (g.accum) v += g.c[grow * g.ldc + gcol];
+        g.c[grow * g.ldc + gcol] = v;
       }
     }
   }
@@ -209,7 +222,8 @@ extern "C" int desco_gemm_f32_multi(int num, const desco_gemm_desc* d, desco_str
   for (int i = 0; i < num; ++i) {
     if (d[i].m == 0) continue;
     GemmArgs g{d[i].a1, d[i].lda1, d[i].k1, d[i].a2, d[i].lda2, d[i].k2, d[i].wt, d[i].n, d[i].bias,
-               d[i].bias ? d[i].bias_rows : 1, d[i].s, d[i].ns, d[i].ws, d[i].act, d[i].slope, d[i].c, d[i].ldc, d[i].m};
+               d[i].bias ? d[i].bias_rows : 1, d[i].s, d[i].ns, d[i].ws, d[i].act, d[i].slope, d[i].c, d[i].ldc, d[i].m,
+               d[i].gate, d[i].ldg, d[i].gate_act, d[i].gate_slope, d[i].accum};
     if (const char* why = gemm_f32_check(g)) {
       std::string msg = std::string("desco_gemm_f32_multi: ") + why;
       return fail(DESCO_EINVAL, msg.c_str());
@@ -239,7 +253,7 @@ extern "C" int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float
       lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) || (k2 > 0 && mis16(a2)) || mis16(wt))
     return fail(DESCO_EINVAL, "desco_gemm_f32: bad argument (k%32, n%64, 16-byte alignment)");
   GemmArgs g{a1, lda1, k1, a2, lda2, k2, wt, n, bias, bias ? bias_rows : 1, s, ns, ws, act, slope,
-             c, ldc, m};
+             c, ldc, m, nullptr, 0, 0, 0.f, 0};
   const int64_t gm = (m + BM - 1) / BM;
   if (gm > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_f32: m too large");
   dim3 grid((unsigned)gm, (unsigned)(n / BN));

@@ -512,6 +512,71 @@ extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, f
   return launch_status("desco_colsum_f32");
 }
 
+// dz = (dout x w) * relu'(y), per-block partials of dw = y^T dout and db = sum dout (desco_rowdot_bwd_f32)
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ y, int64_t ldy, int n,
+                                                        const float* __restrict__ w, const float* __restrict__ dout,
+                                                        int64_t R, int64_t slab, float* __restrict__ dz, int64_t lddz,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[256 * 4 + 64];
+  const int tpr = n >> 2, rpi = 256 / tpr;                // threads per row, rows per iteration
+  const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+  const int64_t r_beg = (int64_t)blockIdx.x * slab;
+  const int64_t r_end = (r_beg + slab) < R ? (r_beg + slab) : R;
+  const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * tc);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sb = 0.f;
+  for (int64_t r = r_beg + tr; r < r_end; r += rpi) {
+    const float d = dout[r];
+    const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + 4 * tc);
+    float4 o;
+    o.x = v.x > 0.f ? d * w4.x : 0.f;
+    o.y = v.y > 0.f ? d * w4.y : 0.f;
+    o.z = v.z > 0.f ? d * w4.z : 0.f;
+    o.w = v.w > 0.f ? d * w4.w : 0.f;
+    *reinterpret_cast<float4*>(dz + r * lddz + 4 * tc) = o;
+    s.x += d * v.x; s.y += d * v.y; s.z += d * v.z; s.w += d * v.w;
+    if (tc == 0) sb += d;
+  }
+  // fold the row groups in a fixed order
+  *reinterpret_cast<float4*>(red + 4 * threadIdx.x) = s;
+  if (tc == 0) red[1024 + tr] = sb;
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * (n + 1);
+  if (threadIdx.x < tpr) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < rpi; ++g) {
+      const float4 q = *reinterpret_cast<const float4*>(red + 4 * (g * tpr + threadIdx.x));
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * threadIdx.x) = t;
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int g = 0; g < rpi; ++g) t += red[1024 + g];
+    out[n] = t;
+  }
+}
+
+extern "C" int desco_rowdot_bwd_f32(const float* y, int64_t ldy, int n, const float* w, const float* dout,
+                                    int64_t num_rows, float* dz, int64_t lddz, float* dwb, float* workspace,
+                                    desco_stream_t stream) {
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (!y || !w || !dout || !dz || !dwb || !workspace || num_rows < 0 || n < 4 || n > 1024 || n % 4 || 256 % (n / 4) ||
+      ldy % 4 || lddz % 4 || mis16(y) || mis16(w) || mis16(dz) || mis16(workspace))
+    return fail(DESCO_EINVAL, "desco_rowdot_bwd_f32: bad argument (n = 4 * a divisor of 256, 16-byte alignment)");
+  int64_t splits = (num_rows + 255) / 256;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  const int64_t slab = (num_rows + splits - 1) / splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((unsigned)splits), dim3(256), 0, st, y, ldy, n, w, dout, num_rows,
+                     slab > 0 ? slab : 1, dz, lddz, workspace);
+  // partial rows are n + 1 floats: columns 0..n-1 -> dw, column n -> db
+  hipLaunchKernelGGL(reduce_strided_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, workspace,
+                     (int64_t)(n + 1), (int64_t)0, (int64_t)(n + 1), (int)splits, dwb);
+  return launch_status("desco_rowdot_bwd_f32");
+}
+
 extern "C" int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,
                                   int64_t count, desco_stream_t stream) {
   if (count == 0) return 0;

@@ -814,18 +814,23 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     C1, cb1, D1, db1 = c1.lin_com.weight, c1.lin_com.bias, c1.lin_update.weight, c1.lin_update.bias
     g0 = c0._gate_value(E).reshape(-1)
     g1 = c1._gate_value(E).reshape(-1)
-    # ---- constants per (node, query): deg_lo, deg_hi, s_lo, s_hi, x ------------------------------
-    with torch.no_grad():
-        ones, zeros = torch.ones(Q, device=dev), torch.zeros(Q, device=dev)
-        sa = ops.gossip_scalars(x, batch.rowptr, batch.col, ones, zeros)    # (deg_lo, s_lo, deg_hi, x)
-        sb = ops.gossip_scalars(x, batch.rowptr, batch.col, zeros, zeros)   # (deg_hi, s_hi, deg_hi, x)
-        deg_lo, s_lo, deg_hi, xr = sa[:, 0], sa[:, 1], sa[:, 2], sa[:, 3]
-        s_hi = sb[:, 1]
-        one = torch.ones_like(xr)
-        C6 = torch.stack([deg_hi, deg_lo - deg_hi, s_hi, s_lo - s_hi, xr, one], 1).contiguous()
-        C3 = torch.stack([deg_hi, deg_lo - deg_hi, one], 1).contiguous()
-        C2 = torch.stack([xr, one], 1).contiguous()
-    # ---- layer 0 (closed form) -----------------------------------------------------
+    # ---- constants per (node, query): deg_lo, deg_hi, s_lo, s_hi, x (functions of the batch alone: cached on it) ----
+    ck = (x.data_ptr(), x._version)
+    cc = batch.__dict__.get("_train_consts")
+    if cc is None or cc[0] != ck:
+        with torch.no_grad():
+            ones, zeros = torch.ones(Q, device=dev), torch.zeros(Q, device=dev)
+            sa = ops.gossip_scalars(x, batch.rowptr, batch.col, ones, zeros)    # (deg_lo, s_lo, deg_hi, x)
+            sb = ops.gossip_scalars(x, batch.rowptr, batch.col, zeros, zeros)   # (deg_hi, s_hi, deg_hi, x)
+            deg_lo, s_lo, deg_hi, xr = sa[:, 0], sa[:, 1], sa[:, 2], sa[:, 3]
+            s_hi = sb[:, 1]
+            one = torch.ones_like(xr)
+            C6 = torch.stack([deg_hi, deg_lo - deg_hi, s_hi, s_lo - s_hi, xr, one], 1).contiguous()
+            C3 = torch.stack([deg_hi, deg_lo - deg_hi, one], 1).contiguous()
+            C2 = torch.stack([xr, one], 1).contiguous()
+        cc = batch.__dict__["_train_consts"] = (ck, C6, C3, C2)
+    _, C6, C3, C2 = cc
+    # ---- operands folded from the parameters (tiny differentiable torch ops: DESIGN.md 4.2) ---------------------------
     a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + cb0)
     v = _mv(C0[:, H:], w_pre)
     D0a, D0b, D0c = D0[:, :H], D0[:, H:2 * H], D0[:, 2 * H:]
@@ -834,32 +839,30 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     t = _mv(D0c, w_pre).expand(Q, H)
     z = E @ D0b.t() + (_mv(D0c, b_pre) + db0)
     V0 = torch.stack([p, g0[:, None] * p, r, g0[:, None] * r, t, z], 1)          # [Q,6,64]
-    h1 = AG.AffineRows.apply(None, C6, V0, ops.ACT_RELU, 0.0)
-    drop = gnn.training and core.dropout > 0
-    if drop:
-        h1 = F.dropout(h1, p=core.dropout, training=True)                           # :274
-    # ---- layer 1 ------------------------------------------------------------------------------------
-    hh = AG.GossipGather.apply(h1, batch.rowptr, batch.col, N, Q, g1)
     D1a, D1b = D1[:, :H], D1[:, H:]
     wt1 = torch.cat([(D1a @ C1).t(), D1b.t()], 0)
-    lin1 = AG.Linear.apply(hh, h1, wt1, None, ops.ACT_NONE, 0.0)
     u = _mv(D1a, cb1).expand(Q, H)
     V1 = torch.stack([u, g1[:, None] * u, db1.expand(Q, H)], 1)                     # [Q,3,64]
-    h2 = AG.AffineRows.apply(lin1, C3, V1, ops.ACT_RELU, 0.0)
-    if drop:
-        h2 = F.dropout(h2, p=core.dropout, training=True)
-    # ---- post_mp ---------------------------------------------------------------------------------------
     P0, p0 = gnn.post_mp[0].weight, gnn.post_mp[0].bias
     wtp = torch.cat([P0[:, 2 * H:3 * H].t(), P0[:, 3 * H:4 * H].t()], 0)
-    linp = AG.Linear.apply(h1, h2, wtp, None, ops.ACT_NONE, 0.0)
     tp = _mv(P0[:, H:2 * H], w_pre).expand(Q, H)
     zp = E @ P0[:, :H].t() + (_mv(P0[:, H:2 * H], b_pre) + p0)
     Vp = torch.stack([tp, zp], 1)                                                   # [Q,2,64]
-    if drop:                                                                        # post_mp.1 Dropout
-        y = AG.AffineRows.apply(linp, C2, Vp, ops.ACT_NONE, 0.0)
-        y = F.leaky_relu(F.dropout(y, p=gnn.post_mp[1].p, training=True), 0.1)
-    else:
-        y = AG.AffineRows.apply(linp, C2, Vp, ops.ACT_LEAKY, 0.1)
+    drop = gnn.training and core.dropout > 0
+    if not drop:
+        # the whole per-(node, query) pipeline and its backward as one autograd node (autograd.GossipTrunk)
+        corr = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, V0, g1, wt1, V1, wtp, Vp,
+                                    gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias, gnn.post_mp[5].weight.t(),
+                                    gnn.post_mp[5].bias, gnn.post_mp[7].weight[0]) + gnn.post_mp[7].bias
+        return (x.reshape(-1) + corr).view(N, Q)
+    # ---- dropout (--gossip_dropout > 0): op-by-op autograd Functions, F.dropout where the reference applies it --------
+    h1 = F.dropout(AG.AffineRows.apply(None, C6, V0, ops.ACT_RELU, 0.0), p=core.dropout, training=True)        # :274
+    hh = AG.GossipGather.apply(h1, batch.rowptr, batch.col, N, Q, g1)
+    lin1 = AG.Linear.apply(hh, h1, wt1, None, ops.ACT_NONE, 0.0)
+    h2 = F.dropout(AG.AffineRows.apply(lin1, C3, V1, ops.ACT_RELU, 0.0), p=core.dropout, training=True)
+    linp = AG.Linear.apply(h1, h2, wtp, None, ops.ACT_NONE, 0.0)
+    y = AG.AffineRows.apply(linp, C2, Vp, ops.ACT_NONE, 0.0)
+    y = F.leaky_relu(F.dropout(y, p=gnn.post_mp[1].p, training=True), 0.1)         # post_mp.1 Dropout
     y = AG.Linear.apply(y, None, gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias, ops.ACT_RELU, 0.0)
     y = AG.Linear.apply(y, None, gnn.post_mp[5].weight.t(), gnn.post_mp[5].bias, ops.ACT_RELU, 0.0)
     # post_mp.7 (256 -> 1) as a 64-wide GEMM whose columns 1..63 are zero

@@ -225,8 +225,9 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 def gemm_multi(problems) -> None:
     """Up to four independent ``gemm`` problems in one launch (desco_gemm_f32_multi).  ``problems``: dicts with the
-    keyword arguments of ``gemm`` (a1, wt, bias, a2, act, slope, out -- ``out`` required); empty ones (no rows) are
-    skipped."""
+    keyword arguments of ``gemm`` (a1, wt, bias, a2, act, slope, out -- ``out`` required) plus, for the backward pass,
+    gate / gate_act / gate_slope (out = v * act'(gate), gate = the saved activation output) and accum (out += v); empty
+    ones (no rows) are skipped."""
     descs = (_lib.GemmDesc * len(problems))()
     flops = nbytes = 0.0
     for d, pr in zip(descs, problems):
@@ -248,6 +249,12 @@ def gemm_multi(problems) -> None:
             d.bias, d.bias_rows = _dev(bias, "bias"), 1
         d.act, d.slope = pr.get("act", ACT_NONE), pr.get("slope", 0.0)
         d.c, d.ldc = _rows(out, "out")
+        gate = pr.get("gate")
+        if gate is not None:          # (backward: multiply by act'(saved output) in the epilogue)
+            assert tuple(gate.shape) == (m, n)
+            d.gate, d.ldg = _rows(gate, "gate")
+            d.gate_act, d.gate_slope = pr["gate_act"], pr.get("gate_slope", 0.0)
+        d.accum = int(bool(pr.get("accum", False)))
         flops += 2.0 * m * (k1 + k2) * n
         nbytes += 4.0 * (m * (k1 + k2) + (k1 + k2) * n + m * n)
     L = _lib.lib()
@@ -853,6 +860,21 @@ def rowdot_add(y: torch.Tensor, w: torch.Tensor, b: float, add: Optional[torch.T
 # ------------------------------------------------------------------------------------------------
 # backward-pass entry points (csrc/train_ops.hip)
 # ------------------------------------------------------------------------------------------------
+def rowdot_bwd(y: torch.Tensor, w: torch.Tensor, dout: torch.Tensor):
+    """Backward of ``rowdot_add`` on y = relu(z): (dz [R, n], dwb [n + 1] = (dw, db)) in one pass over y."""
+    R, n = y.shape
+    assert dout.is_contiguous() and dout.numel() == R and w.is_contiguous() and w.numel() == n
+    dz = torch.empty((R, n), device=y.device, dtype=torch.float32)
+    dwb = torch.empty((n + 1,), device=y.device, dtype=torch.float32)
+    ws = torch.empty((1024 * (n + 1),), device=y.device, dtype=torch.float32)
+    yp, ldy = _rows(y, "y")
+    with _Timed("rowdot_bwd_kernel", 4.0 * R * n, 4.0 * (2 * R * n + R), launches=2):
+        _lib.check(_lib.lib().desco_rowdot_bwd_f32(yp, ldy, n, _dev(w, "w"), _dev(dout, "dout"), R, _dev(dz, "dz"), n,
+                                                   _dev(dwb, "dwb"), _dev(ws, "ws"), _stream()), "rowdot_bwd")
+    return dz, dwb
+
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
             accumulate: bool = False) -> torch.Tensor:
     """out[k, n] (+)= a[m, k]^T @ b[m, n]  (weight gradient; deterministic split-M reduction)."""

@@ -191,6 +191,9 @@ typedef struct desco_gemm_desc {
   const float* s; int ns; const float* ws;
   int act; float slope;
   float* c; int64_t ldc; int64_t m;
+  /* backward use: c = v * act'(gate[row, col]) for gate = the saved activation OUTPUT (gate_act / gate_slope: its
+   * activation; NULL: none) -- desco_act_grad_f32 fused into the epilogue; accum != 0: c += v instead of c = v */
+  const float* gate; int64_t ldg; int gate_act; float gate_slope; int accum;
 } desco_gemm_desc;
 int desco_gemm_f32_multi(int num, const desco_gemm_desc* descs, desco_stream_t stream);
 
@@ -519,6 +522,12 @@ int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, float* out, 
 int desco_adam_step_f32(int num, float* const* params, const float* const* grads, const int64_t* sizes, float* m,
                         float* v, float* steps, uint32_t* arrivals, const float* lr, double beta1, double beta2,
                         double eps, double weight_decay, desco_stream_t stream);
+
+/* Backward of out[r] = add[r] + y[r, :] . w + b with y = relu(z) (post_mp.7 on post_mp.6's output, gnn_model.py:40-53):
+ *   dz[r, c] = dout[r] * w[c] * (y[r, c] > 0),  dwb[c] = sum_r dout[r] * y[r, c] (c < n),  dwb[n] = sum_r dout[r]
+ * in one pass over y (n % 4 == 0, n <= 1024, 256 % (n / 4) == 0).  workspace: 1024 * (n + 1) floats. */
+int desco_rowdot_bwd_f32(const float* y, int64_t ldy, int n, const float* w, const float* dout, int64_t num_rows,
+                         float* dz, int64_t lddz, float* dwb, float* workspace, desco_stream_t stream);
 
 /* dz = dc * act'(c) for c = act(z) (contiguous, count elements) */
 int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,
