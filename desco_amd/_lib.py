@@ -98,6 +98,10 @@ SIGNATURES = {
     "desco_gemm_f32_multi": (c_int, [i32, POINTER(GemmDesc), vp]),
     "desco_linear_bwd_w_multi_workspace": (ctypes.c_size_t, [i32, POINTER(BwdWDesc)]),
     "desco_linear_bwd_w_multi_f32": (c_int, [i32, POINTER(BwdWDesc), vp, vp]),
+    "desco_shmp_trunk_small_max_rows": (c_int, []),
+    "desco_shmp_trunk_small_fwd_f32": (c_int, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp]),
+    "desco_shmp_trunk_small_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
+    "desco_linear_smallk_bwd_f32": (c_int, [vp, i64, i32, vp, i64, i64, vp, vp, vp]),
     "desco_rowdot_bwd_f32": (c_int, [vp, i64, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "desco_adam_step_f32": (c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp]),
     "desco_act_grad_f32": (c_int, [vp, vp, i32, f32, vp, i64, vp]),

@@ -241,6 +241,31 @@ class ShmpTrunk(torch.autograd.Function):
         return (dxn, None, None, None) + tuple(grads)
 
 
+class ShmpTrunkSmall(torch.autograd.Function):
+    """ShmpTrunk for a small single-type batch (the query graphs, at most ops.shmp_trunk_small_max_rows() rows, two
+    relation slots): the whole trunk is one launch forward and one backward (csrc/shmp_small.hip) instead of 37.
+    args: x0 [n, 64], batch (QueryBatch), Wt [L, 192, 64], bias [L, 64]; returns pooled [B, 64 (L + 1)].
+    Products are fp32 in either training precision (1.7 MFLOP per layer: nothing to gain from bf16 operands)."""
+
+    @staticmethod
+    def forward(ctx, x0, batch, wt, bias):
+        x0, wt, bias = x0.contiguous(), wt.contiguous(), bias.contiguous()
+        xall, pooled = ops.shmp_trunk_small_fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr,
+                                                batch.num_graphs)
+        ctx.batch = batch
+        ctx.save_for_backward(x0, xall, wt)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x0, xall, wt = ctx.saved_tensors
+        batch = ctx.batch
+        ti = batch.train_index()
+        dwt, dbias, dx0 = ops.shmp_trunk_small_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],
+                                                   ti["seg_id"], wt.transpose(1, 2).contiguous(), dpooled.contiguous())
+        return dx0, None, dwt, dbias
+
+
 class SmallKLinear(torch.autograd.Function):
     """pre_mp: out = feat @ wt + bias with tiny K (gnn_model.py:131); feat carries no gradient."""
 
@@ -252,10 +277,16 @@ class SmallKLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (feat,) = ctx.saved_tensors
+        if dout.shape[0] == 0:
+            return None, torch.zeros((feat.shape[1], dout.shape[1]), device=dout.device), \
+                torch.zeros((dout.shape[1],), device=dout.device)
+        if dout.shape[1] == 64 and feat.shape[1] <= 16:
+            dwt, db = ops.linear_smallk_bwd(feat, dout)         # weight rows and bias row in one pass (two launches)
+            return None, dwt, db
         dout = dout.contiguous()
         dwt = None
         if ctx.needs_input_grad[1]:
-            # K is 1 in the reference pipeline; a [K, n] product over M rows: K column-sums
+            # a [K, n] product over M rows: K column-sums
             dwt = torch.stack([ops.colsum(dout * feat[:, k:k + 1]) for k in range(feat.shape[1])])
         return None, dwt, ops.colsum(dout)
 
@@ -402,4 +433,58 @@ class GossipTrunk(torch.autograd.Function):
                                 dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
         return (None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp, dw3t, db3, dw5t, db5,
                 dwb7[:256])
+
+
+class Mlp(torch.autograd.Function):
+    """post_mp (gnn_model.py:40-53 of the reference) as ONE autograd node: h_{i+1} = act_i(h_i @ wt_i + b_i).
+
+    args: x [M, k0], acts ((act, slope), ...), w_nk (the nn.Linear weights [out, in] as they are stored: the operand
+    of dA = dZ W, no gradient asked of them here), then wt_0, b_0, wt_1, b_1, ... (wt_i = weight_i^T [in, out],
+    differentiable).  Backward: one GEMM per layer with the activation derivative in its epilogue (gemm_multi's gate),
+    all weight / bias gradients in one launch pair."""
+
+    @staticmethod
+    def forward(ctx, x, acts, w_nk, *wb):
+        hs = [x.contiguous()]
+        wts = []
+        for i, (act, slope) in enumerate(acts):
+            wt, b = wb[2 * i].contiguous(), wb[2 * i + 1]
+            wts.append(wt)
+            hs.append(_mm_fwd(hs[-1], None, wt, b, act, slope))
+        ctx.acts = acts
+        ctx.save_for_backward(*hs, *[w.detach() for w in w_nk], *wts)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        n = len(ctx.acts)
+        sv = ctx.saved_tensors
+        hs, w_nk, wts = sv[:n + 1], sv[n + 1:2 * n + 1], sv[2 * n + 1:]
+        dev = dout.device
+        dz = dout.contiguous()
+        act, slope = ctx.acts[n - 1]
+        if act != ops.ACT_NONE:
+            dz = ops.act_grad(dz, hs[n], act, slope)
+        grads = [None] * (2 * n)
+        wgrad = []
+        for i in range(n - 1, -1, -1):
+            grads[2 * i] = torch.empty_like(wts[i])
+            grads[2 * i + 1] = torch.empty((wts[i].shape[1],), device=dev)
+            wgrad.append(dict(a1=hs[i], dz=dz, dwt=grads[2 * i], dbias=grads[2 * i + 1]))
+            if i == 0 and not ctx.needs_input_grad[0]:
+                break
+            da = torch.empty((dz.shape[0], wts[i].shape[0]), device=dev)
+            w = w_nk[i]
+            if PRECISION == "bf16" and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+                _mm_bwd_da(dz, wts[i], out=da)
+                if i > 0 and ctx.acts[i - 1][0] != ops.ACT_NONE:
+                    da = ops.act_grad(da, hs[i], *ctx.acts[i - 1])
+            else:
+                pr = dict(a1=dz, wt=w if w.is_contiguous() else w.contiguous(), out=da)
+                if i > 0 and ctx.acts[i - 1][0] != ops.ACT_NONE:
+                    pr.update(gate=hs[i], gate_act=ctx.acts[i - 1][0], gate_slope=ctx.acts[i - 1][1])
+                ops.gemm_multi([pr])
+            dz = da
+        ops.linear_bwd_w_multi(wgrad)
+        return (dz if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 

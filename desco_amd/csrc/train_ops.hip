@@ -512,6 +512,53 @@ extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, f
   return launch_status("desco_colsum_f32");
 }
 
+// pre_mp's backward (desco_linear_smallk_bwd_f32): partial[s][k][n] = sum over slab s of feat[m, k] dout[m, n] (k < K),
+// partial[s][K][n] = sum of dout[m, n] -- the weight rows and the bias row of one tiny-K Linear in one pass over dout
+__global__ __launch_bounds__(256) void smallk_bwd_partial_kernel(const float* __restrict__ feat, int64_t ldf, int K,
+                                                                const float* __restrict__ dout, int64_t ldd,
+                                                                int64_t M, int64_t slab,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[16][64];
+  const int rsub = threadIdx.x >> 4, c4 = 4 * (threadIdx.x & 15);
+  const int64_t m_beg = (int64_t)blockIdx.x * slab;
+  const int64_t m_end = (m_beg + slab) < M ? (m_beg + slab) : M;
+  for (int k = 0; k <= K; ++k) {                           // (K is 1 or 2 in the reference pipeline: dout stays in L2)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t m = m_beg + rsub; m < m_end; m += 16) {
+      const float f = k < K ? feat[m * ldf + k] : 1.f;
+      const float4 v = *reinterpret_cast<const float4*>(dout + m * ldd + c4);
+      s.x += f * v.x; s.y += f * v.y; s.z += f * v.z; s.w += f * v.w;
+    }
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[rsub][c4]) = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+      partial[((int64_t)blockIdx.x * (K + 1) + k) * 64 + threadIdx.x] = t;
+    }
+  }
+}
+
+extern "C" int desco_linear_smallk_bwd_f32(const float* feat, int64_t ldf, int k, const float* dout, int64_t ldd,
+                                           int64_t m, float* dwb, float* workspace, desco_stream_t stream) {
+  if (!feat || !dout || !dwb || !workspace || m < 0 || k < 1 || k > 16 || ldd % 4 ||
+      (reinterpret_cast<uintptr_t>(dout) & 15))
+    return fail(DESCO_EINVAL, "desco_linear_smallk_bwd_f32: bad argument (1 <= k <= 16, 64 output columns)");
+  int64_t splits = (m + 255) / 256;
+  if (splits > 512) splits = 512;
+  if (splits < 1) splits = 1;
+  const int64_t slab = (m + splits - 1) / splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(smallk_bwd_partial_kernel, dim3((unsigned)splits), dim3(256), 0, st, feat, ldf, k, dout, ldd, m,
+                     slab > 0 ? slab : 1, workspace);
+  const int64_t count = (int64_t)(k + 1) * 64;
+  hipLaunchKernelGGL(reduce_strided_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, workspace, count,
+                     (int64_t)0, count, (int)splits, dwb);
+  return launch_status("desco_linear_smallk_bwd_f32");
+}
+
 // dz = (dout x w) * relu'(y), per-block partials of dw = y^T dout and db = sum dout (desco_rowdot_bwd_f32)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ y, int64_t ldy, int n,
                                                         const float* __restrict__ w, const float* __restrict__ dout,

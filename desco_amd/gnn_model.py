@@ -44,6 +44,9 @@ SHMP_BF16X6 = True
 # ... in the three-product fp16 form with per-row power-of-two scales (csrc/shmp_layer16.hip, F16 instantiations); needs
 # SHMP_BF16X6 and 16-row wave tiles
 SHMP_F16X3 = os.environ.get("DESCO_SHMP_F16X3", "1") != "0"
+# training: the query model's trunk (<= 144 rows) as one single-workgroup launch per direction (csrc/shmp_small.hip);
+# False: the general per-layer launches of autograd.ShmpTrunk (its cross-check in the tests)
+SMALL_TRUNK_KERNEL = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
@@ -635,7 +638,12 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
         flat = list(_lin_t(gnn.anchor_mlp[0])) if has_anchor else []
         for t, *_ in groups:
             flat += list(st[t])
-        pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, *flat)
+        if (SMALL_TRUNK_KERNEL and not has_anchor and S == 2 and len(groups) == 1 and core.layer_num >= 1
+                and 0 < N <= ops.shmp_trunk_small_max_rows()):
+            # the query graphs (135 rows): the whole trunk in one workgroup, one launch per direction
+            pooled = AG.ShmpTrunkSmall.apply(x, batch, *flat)
+        else:
+            pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, *flat)
         post = {"post": [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]}
         return _post_mp_train(AG, post, gnn, pooled, drop)
     pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
@@ -669,6 +677,11 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
 def _post_mp_train(AG, pk, gnn, pooled, drop):
     import torch.nn.functional as F
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
+    if not drop:
+        # the four Linears and their backward as one autograd node (activation derivatives in the GEMM epilogues, one
+        # launch pair for all weight gradients)
+        return AG.Mlp.apply(pooled, ((ops.ACT_LEAKY, 0.1), (ops.ACT_RELU, 0.0), (ops.ACT_RELU, 0.0), (ops.ACT_NONE, 0.0)),
+                            tuple(gnn.post_mp[i].weight for i in (0, 3, 5, 7)), w0, b0, w3, b3, w5, b5, w7, b7)
     if drop:                                                               # post_mp.1 (gnn_model.py:46)
         h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_NONE, 0.0)
         h = F.leaky_relu(F.dropout(h, p=gnn.post_mp[1].p, training=True), 0.1)

@@ -523,6 +523,30 @@ int desco_adam_step_f32(int num, float* const* params, const float* const* grads
                         float* v, float* steps, uint32_t* arrivals, const float* lr, double beta1, double beta2,
                         double eps, double weight_decay, desco_stream_t stream);
 
+/* The SHMP trunk of a SMALL single-type batch -- the query graphs of the neighborhood model, which the reference embeds
+ * again on every training batch (lightning_model.py:204-207; BaseGNNCore.forward gnn_model.py:253-277 + global_add_pool
+ * :88-89, 107) -- in ONE workgroup per direction: rows in LDS, layers separated by barriers.  num_rows <=
+ * desco_shmp_trunk_small_max_rows() (144), two relation slots per row (vrowptr [2 n + 1]), exact fp32 FMA chains.
+ *   fwd: X_0 = x0; X_{l+1} = relu([agg_0(X_l) | agg_1(X_l) | X_l] wt[l] + bias[l]) -> xall[l] ([L][n][64]);
+ *        pooled[b, 64 l : 64 (l + 1)] = sum of X_l over rows seg_ptr[b] .. seg_ptr[b + 1]
+ *   bwd: from dpooled [num_seg][ldp]: dwt [L][192][64], dbias [L][64], dx0 [n][64]; wt_t = wt with its last two axes
+ *        swapped ([L][64][192]); t_rowptr / t_col: the transposed index over virtual rows 3 k + s
+ *        (desco_vcsr_transpose_sym's, re-based to 3 blocks per row), seg_id [n]: the row's segment. */
+int desco_shmp_trunk_small_max_rows(void);
+int desco_shmp_trunk_small_fwd_f32(const float* x0, const int32_t* vrowptr, const int32_t* vcol, int num_rows,
+                                   int num_layers, const float* wt, const float* bias, const int32_t* seg_ptr,
+                                   int num_seg, float* xall, float* pooled, int64_t ldp, desco_stream_t stream);
+int desco_shmp_trunk_small_bwd_f32(const float* x0, const float* xall, const int32_t* vrowptr, const int32_t* vcol,
+                                   const int32_t* t_rowptr, const int32_t* t_col, const int32_t* seg_id, int num_rows,
+                                   int num_layers, const float* wt_t, const float* dpooled, int64_t ldp, float* dwt,
+                                   float* dbias, float* dx0, desco_stream_t stream);
+
+/* Backward of desco_linear_smallk_f32 with n = 64 (pre_mp, gnn_model.py:131; feat carries no gradient):
+ * dwb[k][0:64] = sum_m feat[m, k] dout[m, :] for k < K, dwb[K][0:64] = sum_m dout[m, :] (the bias gradient), in one
+ * pass over dout and one reduce.  workspace: 512 * (k + 1) * 64 floats. */
+int desco_linear_smallk_bwd_f32(const float* feat, int64_t ldf, int k, const float* dout, int64_t ldd, int64_t m,
+                                float* dwb, float* workspace, desco_stream_t stream);
+
 /* Backward of out[r] = add[r] + y[r, :] . w + b with y = relu(z) (post_mp.7 on post_mp.6's output, gnn_model.py:40-53):
  *   dz[r, c] = dout[r] * w[c] * (y[r, c] > 0),  dwb[c] = sum_r dout[r] * y[r, c] (c < n),  dwb[n] = sum_r dout[r]
  * in one pass over y (n % 4 == 0, n <= 1024, 256 % (n / 4) == 0).  workspace: 1024 * (n + 1) floats. */

@@ -638,3 +638,46 @@ def test_adam_matches_torch_adam(wd):
     sd2 = o2.state_dict()
     assert all(torch.equal(sd2["state"][k]["exp_avg"], sd["state"][k]["exp_avg"]) for k in sd["state"])
     assert o2.param_groups[0]["lr"] == o_own.param_groups[0]["lr"]
+
+
+# ---- the single-workgroup SHMP trunk of small batches (csrc/shmp_small.hip) -----------------------------------------------
+@pytest.mark.parametrize("layers", [1, 8])
+def test_small_trunk_matches_the_layerwise_trunk(layers):
+    """autograd.ShmpTrunkSmall (one launch per direction) against autograd.ShmpTrunk (the general per-layer launches)
+    on the 29 standard query graphs: pooled output and the gradients of x0, the stacked weights and biases."""
+    from helpers import standard_queries
+    from desco_amd import autograd as AG
+    from desco_amd.batch import QueryBatch
+    qb = QueryBatch(standard_queries()[1], DEV)
+    n, B = qb.num_rows, qb.num_graphs
+    assert 0 < n <= ops.shmp_trunk_small_max_rows()
+    g = torch.Generator().manual_seed(layers)
+    x0 = torch.randn(n, 64, generator=g)
+    wt = torch.randn(layers, 192, 64, generator=g) / 10
+    bias = torch.randn(layers, 64, generator=g) / 4
+    seed = torch.randn(B, 64 * (layers + 1), generator=g)
+    res = []
+    for small in (True, False):
+        a, w, b = (t.clone().to(DEV).requires_grad_() for t in (x0, wt, bias))
+        if small:
+            pooled = AG.ShmpTrunkSmall.apply(a, qb, w, b)
+        else:
+            pooled = AG.ShmpTrunk.apply(a, qb, [("union_node", 0, n, 2)], False, w, b)
+        (pooled * seed.to(DEV)).sum().backward()
+        res.append((pooled.detach(), a.grad, w.grad, b.grad))
+    worst = 0.0
+    for name, u, v in zip(("pooled", "dx0", "dWt", "dbias"), res[0], res[1]):
+        err = float((u - v).abs().max() / (1e-6 + v.abs().max()))
+        worst = max(worst, err)
+        assert err < 2e-6, (name, err)
+    print(f"[parity] single-workgroup trunk vs layer-wise trunk, L={layers}: worst max|d| / max|ref| = {worst:.2e}")
+
+
+def test_small_trunk_refuses_large_batches():
+    L = ops._lib.lib()
+    z = torch.zeros(8, device=DEV)
+    zi = torch.zeros(8, device=DEV, dtype=torch.int32)
+    rc = L.desco_shmp_trunk_small_fwd_f32(z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 145, 1, z.data_ptr(), z.data_ptr(),
+                                          zi.data_ptr(), 1, z.data_ptr(), z.data_ptr(), 128, None)
+    assert rc == -1 and b"desco_shmp_trunk_small_fwd_f32" in L.desco_last_error()
+
