@@ -23,6 +23,17 @@ inline int launch_status(const char* what) {
   return 0;
 }
 
+// Kernels whose waves run VALU phases beside OTHER waves' MFMAs must not use packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on MI355X they returned wrong values -- sporadically, 1 % of the results of
+// the wave-autonomous gossip kernel, always in lanes 48-63 in the block form -- whenever another wave of the SIMD was
+// issuing MFMAs, with every operand right; the same arithmetic as scalar v_fma_f32 is exact and bit-reproducible
+// (profiles/r4_b_gossip_f16_race.md).  A kernel attribute, so the rest of a file keeps the packed forms.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DESCO_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define DESCO_NO_PACKED_F32
+#endif
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == DESCO_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == DESCO_ACT_LEAKY) return v > 0.f ? v : v * slope;

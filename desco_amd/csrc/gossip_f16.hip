@@ -572,6 +572,201 @@ __global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t n
 #undef GF16_LDX
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-autonomous form (round 4, second half).  With two fp16 planes ALL nine weight blocks fit in LDS at once
+// (147 456 B), and with the neighbour-sum phase computed directly in the MFMA B layout (lane = node, 16 features per
+// lane) nothing is shared between the waves of a workgroup but those read-only weights: no activation images, no weight
+// ring, NO barrier inside the work loop.  Every wave carries its own 16 nodes through the whole network for a chunk of
+// queries, and the eight waves of a CU drift apart freely -- one wave's neighbour sums, epilogues and record loads run
+// under the other waves' MFMAs, which the lock-stepped block form could not do (phase 1 and six barriers per item were
+// ~40 % of its time with no MFMA in flight).  Work unit = (16-node group, WQ queries), drawn per wave from the caller's
+// queue.  The GEMM chain, scales, k permutation and weight images are those of the block form above.
+constexpr int WQ = 8;                       // queries per work unit
+constexpr int WCOLS = 15;                   // neighbour steps whose column ids are staged per wave ([15][16] ints)
+constexpr int WCST = 896;                   // u, d1, tp, b3 (64 each), b5, w7 (256 each), r, t (64 each)
+constexpr size_t LDS_WAVE = (size_t)9 * WBLK * 2 + (size_t)WCST * 4 + (size_t)8 * (WCOLS * 16 + 64) * 4;
+static_assert(LDS_WAVE <= 160 * 1024, "gossip_wave_f16: LDS budget exceeded");
+
+__global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kernel(Args g, int64_t num_groups) {
+  extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
+  short* WB = reinterpret_cast<short*>(gf_lds);                       // nine resident weight blocks
+  float* cst = reinterpret_cast<float*>(WB + 9 * WBLK);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int* ecolw = reinterpret_cast<int*>(cst + WCST) + wave * (WCOLS * 16 + 64);   // this wave's staged column ids ...
+  float* zpw = reinterpret_cast<float*>(ecolw + WCOLS * 16);                     // ... and zp_q
+  const int q4 = lane >> 4;
+  const int wrow = lane & 15;
+  const int wswz = (wrow >> 1) & 7;
+  const int Q = g.Q;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(g.wstream);
+    for (int i = tid; i < 9 * WBLK * 2 / 16; i += GNT) gf_lds[i] = src[i];
+    for (int i = tid; i < 64; i += GNT) {
+      cst[i] = g.u[i];
+      cst[64 + i] = g.d1[i];
+      cst[128 + i] = g.tp[i];
+      cst[192 + i] = g.b3[i];
+      cst[768 + i] = g.r[i];
+      cst[832 + i] = g.t[i];
+    }
+    for (int i = tid; i < 256; i += GNT) {
+      cst[256 + i] = g.b5[i];
+      cst[512 + i] = g.w7[i];
+    }
+  }
+  const float winv1 = g.winv[0], winvp = g.winv[1], winv3 = g.winv[2], winv5 = g.winv[3];
+  __syncthreads();                                     // the only barrier: weights and constants are in place
+
+  const int QC = (Q + WQ - 1) / WQ;
+  const int64_t nunits = num_groups * QC;
+  const unsigned long long nwaves = (unsigned long long)gridDim.x * 8;
+  int64_t unit = (int64_t)blockIdx.x * 8 + wave;
+  const int fq = 4 * q4;
+  // this lane's 16 features of the standard-order operands (hh, h1): 8 q4 .. +7 and 32 + 8 q4 .. +7
+  const int fa = 8 * q4, fb = 32 + 8 * q4;
+#define GW_V4(p_) (*reinterpret_cast<const f32x4*>(p_))
+  while (unit < nunits) {
+    // ticket of the next unit: in flight over this one
+    unsigned long long tk = 0;
+    if (lane == 0) tk = nwaves + atomicAdd(g.queue, 1ull);
+    const int64_t grp = unit / QC;
+    const int qa = (int)(unit - grp * QC) * WQ;
+    const int qb = qa + WQ < Q ? qa + WQ : Q;
+    const int64_t row_raw = grp * 16 + wrow;
+    const bool valid = row_raw < g.num_nodes;
+    const int64_t row = valid ? row_raw : g.num_nodes - 1;
+    const int e0 = g.rowptr[row];
+    const int deg = valid ? g.rowptr[row + 1] - e0 : 0;
+    int maxdeg = deg;
+    for (int m = 1; m < 16; m <<= 1) {
+      const int o = __shfl_xor(maxdeg, m, 64);
+      maxdeg = maxdeg > o ? maxdeg : o;
+    }
+    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
+    const int nst = maxdeg < WCOLS ? maxdeg : WCOLS;
+    for (int i = q4; i < nst; i += 4)
+      if (i < deg) ecolw[i * 16 + wrow] = g.col[e0 + i];
+
+    for (int q = qa; q < qb; ++q) {
+      zpw[lane] = g.zp[q * 64 + lane];
+      const float gq = g.g1[q];
+      const float4 si = g.scal[row * Q + q];           // (a0, b0, a1, x)
+      f32x4 acc0, acc1, acc2, acc3;
+      Frag XH, X1;
+      float s_a;
+      {
+        // ---- neighbour sum and own h1 in the B layout of the first GEMM ----------------------------------------------
+        const f32x4 p0 = GW_V4(g.p + q * 64 + fa), p1 = GW_V4(g.p + q * 64 + fa + 4), p2 = GW_V4(g.p + q * 64 + fb),
+                    p3 = GW_V4(g.p + q * 64 + fb + 4);
+        const f32x4 z0 = GW_V4(g.z + q * 64 + fa), z1 = GW_V4(g.z + q * 64 + fa + 4), z2 = GW_V4(g.z + q * 64 + fb),
+                    z3 = GW_V4(g.z + q * 64 + fb + 4);
+        const f32x4 r0 = GW_V4(cst + 768 + fa), r1 = GW_V4(cst + 768 + fa + 4), r2 = GW_V4(cst + 768 + fb),
+                    r3 = GW_V4(cst + 768 + fb + 4);
+        const f32x4 t0 = GW_V4(cst + 832 + fa), t1 = GW_V4(cst + 832 + fa + 4), t2 = GW_V4(cst + 832 + fb),
+                    t3 = GW_V4(cst + 832 + fb + 4);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 h0 = zero4, h1 = zero4, h2 = zero4, h3 = zero4;
+#define GW_H1(s_, c_) __builtin_elementwise_max((s_).x * p##c_ + (s_).y * r##c_ + (s_).w * t##c_ + z##c_, zero4)
+        for (int i = 0; i < maxdeg; ++i) {
+          const bool on = i < deg;
+          int j = (int)row;
+          if (on) j = i < WCOLS ? ecolw[i * 16 + wrow] : g.col[e0 + i];
+          const float4 sj = g.scal[(int64_t)j * Q + q];
+          const float gt = on ? (j < (int)row ? gq : 1.f - gq) : 0.f;
+          h0 += gt * GW_H1(sj, 0);
+          h1 += gt * GW_H1(sj, 1);
+          h2 += gt * GW_H1(sj, 2);
+          h3 += gt * GW_H1(sj, 3);
+        }
+        const f32x4 s0 = GW_H1(si, 0), s1 = GW_H1(si, 1), s2 = GW_H1(si, 2), s3 = GW_H1(si, 3);
+#undef GW_H1
+        // one power of two for the node's h1 AND hh (they meet in one accumulator)
+        const float m = quarters_max(fmaxf(absmax16(h0, h1, h2, h3), absmax16(s0, s1, s2, s3)));
+        s_a = f16_scale_for(m);
+        make_frag(h0, h1, h2, h3, s_a, XH);
+        make_frag(s0, s1, s2, s3, s_a, X1);
+      }
+      Frag XC;
+      float s_c;
+      // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) ------------------------------------------------------------
+      GF16_ZERO()
+      GF16_BLOCK(WB + 0 * WBLK, XH)
+      GF16_BLOCK(WB + 1 * WBLK, X1)
+      {
+        const float f = pow2_inverse(s_a) * winv1;
+        const float* u_ = cst + fq;
+        const float* d_ = cst + 64 + fq;
+#define GW_EPI1(a_, i_) a_ = __builtin_elementwise_max(a_ * f + (GW_V4(u_ + 16 * (i_)) * si.z + GW_V4(d_ + 16 * (i_))), f32x4{0.f, 0.f, 0.f, 0.f});
+        GW_EPI1(acc0, 0) GW_EPI1(acc1, 1) GW_EPI1(acc2, 2) GW_EPI1(acc3, 3)
+#undef GW_EPI1
+        s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
+        make_frag(acc0, acc1, acc2, acc3, s_c, XC);
+      }
+      // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) ------------------------------------------------------
+      GF16_ZERO()
+      GF16_BLOCK(WB + 2 * WBLK, X1)
+      {
+        const float rs = s_c * pow2_inverse(s_a);
+        GF16_SCALE(rs)
+      }
+      GF16_BLOCK(WB + 3 * WBLK, XC)
+      {
+        const float f = pow2_inverse(s_c) * winvp;
+        const float* t_ = cst + 128 + fq;
+        const float* z_ = zpw + fq;
+#define GW_EPI2(a_, i_)                                                                                       \
+  {                                                                                                           \
+    const f32x4 v_ = a_ * f + (GW_V4(t_ + 16 * (i_)) * si.w + GW_V4(z_ + 16 * (i_)));                          \
+    a_ = __builtin_elementwise_max(v_, v_ * 0.1f);                                                            \
+  }
+        GW_EPI2(acc0, 0) GW_EPI2(acc1, 1) GW_EPI2(acc2, 2) GW_EPI2(acc3, 3)
+#undef GW_EPI2
+        s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
+        make_frag(acc0, acc1, acc2, acc3, s_c, XC);
+      }
+      // ---- block 4: y2 = relu(y1 W3 + b3) ----------------------------------------------------------------------------
+      GF16_ZERO()
+      GF16_BLOCK(WB + 4 * WBLK, XC)
+      {
+        const float f = pow2_inverse(s_c) * winv3;
+        const float* b_ = cst + 192 + fq;
+#define GW_EPI3(a_, i_) a_ = __builtin_elementwise_max(a_ * f + GW_V4(b_ + 16 * (i_)), f32x4{0.f, 0.f, 0.f, 0.f});
+        GW_EPI3(acc0, 0) GW_EPI3(acc1, 1) GW_EPI3(acc2, 2) GW_EPI3(acc3, 3)
+#undef GW_EPI3
+        s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
+        make_frag(acc0, acc1, acc2, acc3, s_c, XC);
+      }
+      // ---- blocks 5..8: head partial  sum_c relu(y2 W5 + b5)[c] * w7[c] ------------------------------------------------
+      float part = 0.f;
+      const float fh = pow2_inverse(s_c) * winv5;
+#define GW_HEAD1(a_, cg_, i_)                                                                                 \
+  {                                                                                                           \
+    const f32x4 v_ = __builtin_elementwise_max(a_ * fh + GW_V4(cst + 256 + 64 * (cg_) + 16 * (i_) + fq),       \
+                                               f32x4{0.f, 0.f, 0.f, 0.f}) *                                   \
+                     GW_V4(cst + 512 + 64 * (cg_) + 16 * (i_) + fq);                                          \
+    part += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                                                \
+  }
+#define GW_HEAD(cg_)                                                                                         \
+  GF16_ZERO()                                                                                                \
+  GF16_BLOCK(WB + (5 + (cg_)) * WBLK, XC)                                                                    \
+  GW_HEAD1(acc0, cg_, 0) GW_HEAD1(acc1, cg_, 1) GW_HEAD1(acc2, cg_, 2) GW_HEAD1(acc3, cg_, 3)
+      GW_HEAD(0) GW_HEAD(1) GW_HEAD(2) GW_HEAD(3)
+#undef GW_HEAD
+#undef GW_HEAD1
+      part = quarters_sum(part);
+      if (lane < 16 && valid) g.out[row * Q + q] = part + g.b7 + si.w;
+    }
+    unit = (int64_t)__builtin_amdgcn_readfirstlane((int)(tk & 0xffffffffull)) |
+           ((int64_t)__builtin_amdgcn_readfirstlane((int)(tk >> 32)) << 32);
+  }
+#undef GW_V4
+  if (lane == 0 && atomicAdd(g.queue + 1, 1ull) == nwaves - 1) {        // last wave out: leave the queue clean
+    g.queue[0] = 0;
+    g.queue[1] = 0;
+  }
+}
+
 // The weight stream: block b of the nine 64 x 64 blocks (W1[:, 0:64], W1[:, 64:128], Wp[:, 0:64], Wp[:, 64:128], W3,
 // W5[0:64], W5[64:128], W5[128:192], W5[192:256]) as the LDS image the kernel copies linearly: plane-major, rows of
 // 64 halves with the 16-byte chunk index XOR (row >> 1) & 7, and for the blocks whose input arrives in registers
@@ -610,6 +805,43 @@ extern "C" int desco_gossip_f16_stream(const int16_t* w1_planes, const int16_t* 
                      reinterpret_cast<const short*>(w3_planes), reinterpret_cast<const short*>(w5_planes),
                      reinterpret_cast<short*>(stream));
   return launch_status("desco_gossip_f16_stream");
+}
+
+extern "C" int desco_gossip_wave_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
+                                           int64_t num_nodes, int num_q, const float* g1, const float* p,
+                                           const float* z, const float* zp, const float* r, const float* t,
+                                           const float* u, const float* tp, const float* d1, const int16_t* wstream,
+                                           const float* winv, const float* b3, const float* b5, const float* w7,
+                                           float b7, float* out, uint64_t* queue, desco_stream_t stream) {
+  using namespace gf16;
+  if (num_nodes == 0) return 0;
+  auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
+  auto mis8 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 7) != 0; };
+  if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !wstream || !winv || !b3 || !b5 ||
+      !w7 || !out || !queue || num_nodes < 0 || num_q < 1 || num_q > 65535 || mis16(scal4) || mis16(wstream) ||
+      mis16(p) || mis16(z) || mis16(r) || mis16(t) || mis8(queue))
+    return fail(DESCO_EINVAL, "desco_gossip_wave_f16x3_f32: bad argument");
+  const int64_t groups = (num_nodes + 15) / 16;
+  Args a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z, zp, r, t, u, tp, d1,
+         reinterpret_cast<const short*>(wstream), winv, b3, b5, w7, b7, out, nullptr,
+         reinterpret_cast<unsigned long long*>(queue)};
+  static DeviceOnce attr_once;
+  if (!attr_once.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_wave_f16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_WAVE);
+    if (e != hipSuccess) return fail((int)e, "desco_gossip_wave_f16x3_f32: cannot size LDS");
+    attr_once.mark();
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int64_t units = groups * ((num_q + WQ - 1) / WQ);
+  const int64_t blocks = (units + 7) / 8;
+  const unsigned grid = (unsigned)(blocks < (int64_t)cus ? blocks : (int64_t)cus);
+  hipLaunchKernelGGL(gossip_wave_f16_kernel, dim3(grid), dim3(GNT), LDS_WAVE, (hipStream_t)stream, a, groups);
+  return launch_status("desco_gossip_wave_f16x3_f32");
 }
 
 extern "C" int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,

@@ -433,6 +433,15 @@ int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, cons
                                  const float* u, const float* tp, const float* d1, const int16_t* wstream,
                                  const float* winv, const float* b3, const float* b5, const float* w7, float b7,
                                  float* out, const uint8_t* tile_perm, uint64_t* queue, desco_stream_t stream);
+
+/* The same network in WAVE-AUTONOMOUS form (round 4): all nine weight blocks resident in LDS, a wave carries 16 nodes
+ * through the whole network for 8 queries at a time, no barrier inside the work loop.  Arguments as above without
+ * tile_perm; queue: two zeroed 64-bit words, left zero. */
+int desco_gossip_wave_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col, int64_t num_nodes,
+                                int num_q, const float* g1, const float* p, const float* z, const float* zp,
+                                const float* r, const float* t, const float* u, const float* tp, const float* d1,
+                                const int16_t* wstream, const float* winv, const float* b3, const float* b5,
+                                const float* w7, float b7, float* out, uint64_t* queue, desco_stream_t stream);
 /* tile_perm (optional, 4-byte aligned, [ceil(num_nodes/128)*128] bytes from desco_gossip_tile_order): the order in
  * which the 8 waves of a block walk the rows of a 128-node tile in the neighbour-sum phase -- rows sorted by degree,
  * paired, pairs dealt to the waves in snake order (a half wave per row, the two halves of a wave in lock step, a block
