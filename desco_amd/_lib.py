@@ -87,7 +87,6 @@ SIGNATURES = {
     "desco_gossip_tile_order": (c_int, [vp, i64, vp, vp]),
     "desco_gossip_f16_stream": (c_int, [vp, vp, vp, vp, vp, vp]),
     "desco_gossip_fused_f16x3_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 14 + [f32, vp, vp, vp, vp]),
-    "desco_gossip_wave_f16x3_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 14 + [f32, vp, vp, vp]),
     "desco_csr_gather_sum_add_f32": (c_int, [vp, i64, vp, vp, i64, vp, i64, vp, i64, vp]),
     "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]),
     "desco_add_rows_f32": (c_int, [vp, i64, vp, i64, i64, i32, vp]),

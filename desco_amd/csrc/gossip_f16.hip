@@ -9,41 +9,38 @@
 //   y2   = relu(y1 W3 + b3)                                          (post_mp.3, K=64)     MFMA
 //   out  = x + b7 + sum_c relu(y2 W5 + b5)[c] * w7[c]                (post_mp.5/.7, N=256) MFMA
 //
-// What changed against the six-product bf16 kernel, and why:
+// What changed against the six-product bf16 kernel (gossip_fused.hip, kept as the cross-check), and why:
 //   * Arithmetic: x s = hi + lo in fp16 (22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16: 3 instead of 6
-//     MFMAs per tile step, 2 instead of 3 operand planes, 3-5 instead of 9 VALU per split pair.  fp16's 5-bit exponent is
-//     carried by power-of-two scales: one per weight matrix (host), one PER NODE per activation vector (largest |v| of
-//     the node's 64 features -> [2^14, 2^15)), undone exactly in the next epilogue.
-//   * A wave owns 16 NODES x all 64 features of a block (4 feature tiles x 1 node tile) instead of 32 x 32: the per-node
-//     maximum is then a wave-local reduction (two lane-quarter swaps), and in the transposed MFMA form (A = weight rows,
-//     B = activation rows) the C/D layout of one GEMM -- lane = node, registers = features 16 i + 4 q + e -- IS the B
-//     layout of the next one under a fixed permutation of k (baked into the weight stream on the host): h2, y1 and y2
-//     never leave the registers.  No activation images for them, no epilogue LDS writes, no fragment reads of
-//     activations for 6 of the 9 weight blocks, and no barrier on their account.
-//   * h1 / hh (written by the neighbour-sum phase in its own lane map) still pass through LDS images; a wave reads back
-//     exactly the 16 rows it wrote (wave-private).  One block barrier separates the phase from the GEMMs all the same
-//     (see there).
-//   * The only block-wide data left are the tile's scalar records (published once per item) and the weight blocks, which
-//     stream through a RING of four 16 KB buffers, loaded four and stored two blocks ahead of their use: one barrier per
-//     TWO blocks.  6 barriers per item instead of 10.
-// Block = 8 waves = one CU, persistent over (tile, query) items drawn from a ticket queue the CALLER provides.
+//     MFMAs per tile step, 2 instead of 3 operand planes, 3 instead of 9 VALU per split pair.  fp16's 5-bit exponent is
+//     carried by power-of-two scales: one per weight matrix, one PER NODE per activation vector (largest |v| of the
+//     node's 64 features -> [2^14, 2^15)), undone exactly in the next epilogue.
+//   * A wave owns 16 NODES x all 64 features (4 feature tiles x 1 node tile): the per-node maximum is a wave-local
+//     reduction (two lane-quarter swaps), and in the transposed MFMA form (A = weight rows, B = activation rows) the C/D
+//     layout of one GEMM -- lane = node, registers = features 16 i + 4 q + e -- IS the B layout of the next one under a
+//     fixed permutation of k (baked into the weight stream, desco_gossip_f16_stream): h2, y1 and y2 never leave the
+//     registers.
+//   * WAVE-AUTONOMOUS.  With two planes ALL nine 64 x 64 weight blocks fit in LDS at once (147 456 B), and the neighbour
+//     sums are computed directly in the B layout of the first GEMM (lane = node, 16 features per lane), so nothing is
+//     shared between the waves of a workgroup but those read-only weights: no activation images, no weight ring, NO
+//     barrier in the work loop.  Every wave carries its own 16 nodes through the whole network for a chunk of 8 queries
+//     (work unit, drawn per wave from the caller's queue), and the eight waves of a CU drift apart freely -- one wave's
+//     neighbour sums, epilogues and record loads run under the other waves' MFMAs.  The first version of this file kept
+//     the bf16 kernel's block structure (128-node items, lock-stepped waves, weights through a ring of four buffers, six
+//     barriers per item): 1.53 ms per 3.95 M (node, query) rows against 0.98 for this form on the same box.
+//   * Everything a query needs from memory (its records, p_q / z_q / zp_q, the first four neighbour records of every
+//     node) is requested one query ahead, in front of the previous query's GEMM chain.
+//   * No packed fp32 VALU instructions (DESCO_NO_PACKED_F32, common_device.hpp): beside other waves' MFMAs they
+//     returned wrong values.
 #include "common_device.hpp"
 
 namespace desco {
 
 namespace gf16 {
 
-constexpr int GT = 128;            // rows (nodes) per tile
-constexpr int GNT = 512;           // threads per block
-constexpr int PLN = GT * 64;       // halves per activation plane
+constexpr int GT = 128;            // nodes per tile of the optional degree order (desco_gossip_tile_order)
+constexpr int GNT = 512;           // threads per block: 8 waves, one workgroup per CU
 constexpr int WPL = 64 * 64;       // halves per weight-block plane
 constexpr int WBLK = 2 * WPL;      // halves per weight block (hi, lo)
-constexpr int PCAP = 1216;         // neighbour records prefetched for the next tile (up to three per thread)
-constexpr int ECAP = 1216;         // neighbour records staged per pass
-constexpr int CST = 832;           // u, d1, tp, b3 (64 each), b5, w7 (256 each), zp_q (64)
-constexpr size_t LDS_BYTES = (size_t)2 * 2 * PLN * 2 + (size_t)4 * WBLK * 2 + (size_t)ECAP * 20 + GT * 16 + 132 * 4 +
-                             CST * 4 + GT * 4 + GT + 16;
-static_assert(LDS_BYTES <= 160 * 1024, "gossip_f16: LDS budget exceeded");
 
 struct Args {
   const float4* scal;       // [N*Q] (a0, b0, a1, x)
@@ -75,24 +72,6 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// element offset of (row, k) inside a [rows][64] fp16 plane with swizzled 16-byte chunks
-__device__ __forceinline__ int pidx(const int row, const int k) {
-  return row * 64 + ((((k >> 3) ^ (row >> 1)) & 7) << 3) + (k & 7);
-}
-
-// max over the 32 lanes of a half wave (both halves at once) of NON-NEGATIVE floats, compared as unsigned integers
-// (same order, no NaN canonicalisation, v_max_u32_dpp): four DPP steps inside the 16-lane rows, one row swap
-__device__ __forceinline__ float half_wave_max(const float f) {
-  uint32_t v = __float_as_uint(f);
-#define GF16_DPP_MAX(ctrl_) { const uint32_t o_ = __builtin_amdgcn_update_dpp(0u, v, (ctrl_), 0xf, 0xf, true); v = v > o_ ? v : o_; }
-  GF16_DPP_MAX(0xB1)     // quad_perm [1,0,3,2]
-  GF16_DPP_MAX(0x4E)     // quad_perm [2,3,0,1]
-  GF16_DPP_MAX(0x141)    // row_half_mirror
-  GF16_DPP_MAX(0x140)    // row_mirror
-#undef GF16_DPP_MAX
-  const u32x2 w = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-  return __uint_as_float(w[0] > w[1] ? w[0] : w[1]);
-}
 // max / sum over the four lanes (r, r+16, r+32, r+48) that share a node in the MFMA layouts
 __device__ __forceinline__ float quarters_max(const float f) {      // f >= 0
   uint32_t v = __float_as_uint(f);
@@ -188,406 +167,13 @@ __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f3
 #define GF16_ZERO() { acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define GF16_SCALE(f_) { acc0 *= (f_); acc1 *= (f_); acc2 *= (f_); acc3 *= (f_); }
 
-// weight stream: block b_ (0..8) global -> register set, register set -> ring slot
-// (global base pointer + 32-bit offset: the block offset is an opaque scalar so that the compiler neither folds it into
-// per-block 64-bit vector addresses -- 36 registers it then spilled -- nor loses the global address space)
-#define GF16_WLOAD(q_, b_)                                                                   \
-  {                                                                                          \
-    uint32_t o_ = (uint32_t)(b_) * (WBLK * 2);                                               \
-    asm volatile("" : "+s"(o_));                                                             \
-    const char* s_ = reinterpret_cast<const char*>(g.wstream);                               \
-    q_##0 = *reinterpret_cast<const uint4*>(s_ + (o_ + woff));                               \
-    q_##1 = *reinterpret_cast<const uint4*>(s_ + (o_ + woff + WPL * 2));                     \
-  }
-#define GF16_WSTORE(q_, slot_)                                                               \
-  {                                                                                          \
-    short* d_ = WB + ((((slot_) + wbase) & 3) * WBLK) + 8 * tid;                             \
-    *reinterpret_cast<uint4*>(d_) = q_##0;                                                   \
-    *reinterpret_cast<uint4*>(d_ + WPL) = q_##1;                                             \
-  }
-#define GF16_RING(k_) (WB + ((((k_) + wbase) & 3) * WBLK))
-
-__global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t num_tiles) {
-  extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
-  short* I0 = reinterpret_cast<short*>(gf_lds);          // h1 planes (hi, lo)
-  short* I1 = I0 + 2 * PLN;                              // hh planes
-  short* WB = I1 + 2 * PLN;                              // ring of four weight blocks
-  int* ecol = reinterpret_cast<int*>(WB + 4 * WBLK);     // [ECAP] neighbour records: column ...
-  float4* escal = reinterpret_cast<float4*>(ecol + ECAP);   // ... and scalar record
-  float4* srow = escal + ECAP;                           // scalars of the tile rows
-  int* rp = reinterpret_cast<int*>(srow + GT);           // rowptr[n0 .. n0+128]
-  float* cst = reinterpret_cast<float*>(rp + 132);       // bias vectors (see CST)
-  float* sA = cst + CST;                                 // [128] per-node scale of (h1, hh)
-  uint8_t* tperm = reinterpret_cast<uint8_t*>(sA + GT);  // [128] phase-1 slot -> row
-  unsigned long long* tick = reinterpret_cast<unsigned long long*>(tperm + GT);   // the item after the current one
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q4 = lane >> 4;                 // k chunk within a 32-deep step / feature quad of a 16x16 tile
-  const int wrow = lane & 15;               // this lane's weight row inside a feature tile (A operand)
-  const int wswz = (wrow >> 1) & 7;         // chunk swizzle of weight rows 16 i + wrow
-  const int Q = g.Q;
-  const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
-  int64_t item = blockIdx.x;
-  if (item >= nitems) return;
-
-  for (int i = tid; i < 64; i += GNT) {
-    cst[i] = g.u[i];
-    cst[64 + i] = g.d1[i];
-    cst[128 + i] = g.tp[i];
-    cst[192 + i] = g.b3[i];
-  }
-  for (int i = tid; i < 256; i += GNT) {
-    cst[256 + i] = g.b5[i];
-    cst[512 + i] = g.w7[i];
-  }
-  const float winv1 = g.winv[0], winvp = g.winv[1], winv3 = g.winv[2], winv5 = g.winv[3];
-
-  // The (rowptr -> col -> scalar record) chain of the NEXT item is fetched into these registers in three stages spread
-  // over the current item and published to LDS when the current item is done.
-  float4 n_srow = make_float4(0.f, 0.f, 0.f, 0.f), n_scal = n_srow, n_scal2 = n_srow, n_scal3 = n_srow;
-  int n_rp = 0, n_col = 0, n_col2 = 0, n_col3 = 0, n_ebeg = 0, n_cnt = 0;
-  uint32_t n_perm = 0x03020100u + 0x04040404u * (uint32_t)(tid & 31);   // identity slots 4 tid .. 4 tid + 3
-  float n_zp = 0.f, n_gq = 0.f;
-  float2 n_pc = make_float2(0.f, 0.f), n_zc = n_pc;
-  const int f0 = 2 * (lane & 31);          // phase-1 lane map: features (f0, f0+1)
-#define GF16_STAGE1(it_)                                                                   \
-  {                                                                                        \
-    const int q_ = (int)((it_) % Q);                                                       \
-    const int64_t t0_ = ((it_) / Q) * GT;                                                  \
-    const int nr_ = (int)((g.num_nodes - t0_) < GT ? (g.num_nodes - t0_) : GT);            \
-    if (tid < GT) n_srow = g.scal[(t0_ + (tid < nr_ ? tid : nr_ - 1)) * Q + q_];           \
-    if (tid <= GT) n_rp = g.rowptr[t0_ + (tid < nr_ ? tid : nr_)];                         \
-    if (g.tperm && tid < GT / 4) n_perm = reinterpret_cast<const uint32_t*>(g.tperm + ((it_) / Q) * GT)[tid]; \
-    n_ebeg = g.rowptr[t0_];                                                                \
-    n_cnt = g.rowptr[t0_ + nr_] - n_ebeg;                                                  \
-    n_cnt = n_cnt < PCAP ? n_cnt : PCAP;                                                   \
-    if (tid < 64) n_zp = g.zp[q_ * 64 + tid];                                              \
-    n_gq = g.g1[q_];                                                                       \
-    n_pc = *reinterpret_cast<const float2*>(g.p + q_ * 64 + f0);                           \
-    n_zc = *reinterpret_cast<const float2*>(g.z + q_ * 64 + f0);                           \
-  }
-#define GF16_STAGE2() \
-  {                                                          \
-    if (tid < n_cnt) n_col = g.col[n_ebeg + tid];            \
-    if (tid + GNT < n_cnt) n_col2 = g.col[n_ebeg + tid + GNT]; \
-    if (tid + 2 * GNT < n_cnt) n_col3 = g.col[n_ebeg + tid + 2 * GNT]; \
-  }
-#define GF16_STAGE3(it_) \
-  {                                                                                          \
-    if (tid < n_cnt) n_scal = g.scal[(int64_t)n_col * Q + (int)((it_) % Q)];                 \
-    if (tid + GNT < n_cnt) n_scal2 = g.scal[(int64_t)n_col2 * Q + (int)((it_) % Q)];         \
-    if (tid + 2 * GNT < n_cnt) n_scal3 = g.scal[(int64_t)n_col3 * Q + (int)((it_) % Q)];     \
-  }
-
-  if (tid == 0) *tick = gridDim.x + atomicAdd(g.queue, 1ull);
-  GF16_STAGE1(item)
-  GF16_STAGE2()
-  GF16_STAGE3(item)
-  const float2 rc = *reinterpret_cast<const float2*>(g.r + f0);
-  const float2 tc = *reinterpret_cast<const float2*>(g.t + f0);
-  // Weight ring.  An item is ten slots (nine blocks + one empty), so slot parity = block parity: block k of an item is
-  // stored at step k - 2 from register set (k & 1), loaded at step k - 4, and sits in ring buffer (k + wbase) & 3
-  // with wbase = 0, 2, 0, 2, ... over this block's items.  A barrier in front of every EVEN step orders both hazards
-  // (stored two steps ahead -> visible; overwritten buffer last read four steps ago -> done).
-  uint4 qa0, qa1, qb0, qb1;
-  int wbase = 0;
-  const uint32_t woff = 16u * (uint32_t)tid;
-  GF16_WLOAD(qa, 0)
-  GF16_WLOAD(qb, 1)
-  GF16_WSTORE(qa, 0)
-  GF16_WSTORE(qb, 1)
-  GF16_WLOAD(qa, 2)
-  GF16_WLOAD(qb, 3)
-
-  for (;;) {
-    // ---- publish the prefetched tile data ------------------------------------------------------------------------
-    const int q = (int)(item % Q);
-    if (tid < GT) srow[tid] = n_srow;
-    if (tid <= GT) rp[tid] = n_rp;
-    if (tid < GT / 4) reinterpret_cast<uint32_t*>(tperm)[tid] = n_perm;
-    if (tid < n_cnt) {
-      ecol[tid] = n_col;
-      escal[tid] = n_scal;
-      if (tid + GNT < n_cnt) {
-        ecol[tid + GNT] = n_col2;
-        escal[tid + GNT] = n_scal2;
-      }
-      if (tid + 2 * GNT < n_cnt) {
-        ecol[tid + 2 * GNT] = n_col3;
-        escal[tid + 2 * GNT] = n_scal3;
-      }
-    }
-    if (tid < 64) cst[768 + tid] = n_zp;
-    const float gq = n_gq;
-    const float2 pc = n_pc, zc = n_zc;
-    const int cnt0 = n_cnt;
-    const int64_t n0 = (item / Q) * GT;
-    const int nrows = (int)((g.num_nodes - n0) < GT ? (g.num_nodes - n0) : GT);
-    __syncthreads();
-    const int64_t next = (int64_t)*tick;   // (written before the barrier)
-    const bool has_next = next < nitems;
-    unsigned long long tk = 0;             // ticket of the item after `next`: in flight until the end of this item
-    if (tid == 0 && has_next) tk = gridDim.x + atomicAdd(g.queue, 1ull);
-    if (has_next) GF16_STAGE1(next)
-
-    // ---- phase 1: h1 of the tile rows, gated neighbour sum hh; rows tperm[16 wave ..] belong to this wave ---------
-    {
-      int lane1 = lane;
-      asm volatile("" : "+v"(lane1));      // keeps this phase's addresses out of the registers of the GEMM phase
-      const int half1 = lane1 >> 5, f1 = 2 * (lane1 & 31);
-      float2 hh[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) hh[i] = make_float2(0.f, 0.f);
-      const int ebeg = rp[0], eend = rp[GT];
-      // pass 0: the prefetched records [ebeg, ebeg+cnt0); later passes (tiles with more than PCAP neighbour records)
-      // stage ECAP records at a time from global memory
-      int base = ebeg, cnt = cnt0;
-      for (;;) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int row = tperm[wave * 16 + 2 * i + half1];
-          const int node = (int)n0 + row;
-          int lo = rp[row] - base, hi = rp[row + 1] - base;
-          lo = lo < 0 ? 0 : lo;
-          hi = hi > cnt ? cnt : hi;
-          float2 a = hh[i];
-          for (int e = lo; e < hi; ++e) {
-            const float4 sj = escal[e];
-            float hx = sj.x * pc.x + sj.y * rc.x + sj.w * tc.x + zc.x;
-            float hy = sj.x * pc.y + sj.y * rc.y + sj.w * tc.y + zc.y;
-            hx = hx > 0.f ? hx : 0.f;
-            hy = hy > 0.f ? hy : 0.f;
-            const float gt = ecol[e] < node ? gq : 1.f - gq;
-            a.x += gt * hx;
-            a.y += gt * hy;
-          }
-          hh[i] = a;
-        }
-        base += cnt;
-        if (base >= eend) break;
-        __syncthreads();          // everyone is done with the staged records
-        cnt = (eend - base) < ECAP ? (eend - base) : ECAP;
-        for (int e = tid; e < cnt; e += GNT) {
-          const int j = g.col[base + e];
-          ecol[e] = j;
-          escal[e] = g.scal[(int64_t)j * Q + q];
-        }
-        __syncthreads();
-      }
-      // (two passes: the loads of all eight rows first -- the LDS stores of a row would fence the next row's loads)
-      int rows8[8];
-      float2 hs[8];
-      const uint4 tp16 = *reinterpret_cast<const uint4*>(tperm + wave * 16);      // this wave's 16 slot -> row bytes
-      const uint32_t tpw[4] = {tp16.x, tp16.y, tp16.z, tp16.w};
-      float4 sis[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        rows8[i] = (int)((tpw[i >> 1] >> (16 * (i & 1) + 8 * half1)) & 0xffu);           // byte 2 i + half1
-        sis[i] = srow[rows8[i]];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 si = sis[i];
-        float hx = si.x * pc.x + si.y * rc.x + si.w * tc.x + zc.x;
-        float hy = si.x * pc.y + si.y * rc.y + si.w * tc.y + zc.y;
-        hs[i] = make_float2(hx > 0.f ? hx : 0.f, hy > 0.f ? hy : 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = rows8[i];
-        const float hx = hs[i].x, hy = hs[i].y;
-        // one power of two for the node's h1 AND hh (they meet in one accumulator): the largest of the 128 values
-        const float m = half_wave_max(fmaxf(fmaxf(hx, hy), fmaxf(fabsf(hh[i].x), fabsf(hh[i].y))));
-        const float s = f16_scale_for(m);
-        if (f1 == 0) sA[row] = s;
-        uint32_t h_, l_;
-        const int o = pidx(row, f1);
-        split2_f16x2(hx * s, hy * s, h_, l_);
-        *reinterpret_cast<uint32_t*>(I0 + o) = h_;
-        *reinterpret_cast<uint32_t*>(I0 + PLN + o) = l_;
-        split2_f16x2(hh[i].x * s, hh[i].y * s, h_, l_);
-        *reinterpret_cast<uint32_t*>(I1 + o) = h_;
-        *reinterpret_cast<uint32_t*>(I1 + PLN + o) = l_;
-      }
-    }
-    // The rows this wave reads below are the rows it wrote above, so the images would need no block barrier -- but the
-    // phase above must not run beside another wave's GEMM phase: without this barrier a handful of (node, query) results
-    // differed from run to run.  Traced (round 4, profiles/r4_b_gossip_f16_race.md) to the self term h1 coming out
-    // wrong in lanes 48-63, low half of the packed fp32 operations only, with every ingredient (dumped from the same
-    // registers) right -- only when a slower wave was still in phase 1 while others issued MFMAs; neither full waits
-    // for LDS / vector memory, nor replacing the lane swaps and byte reads, nor fencing the MFMA chains removed it,
-    // the barrier does (84 of 84 repeat runs identical, tools/debug/gossip_f16_probe2.py).  The compiler fence keeps
-    // the fragment reads (fp16 vectors) behind the image stores (32-bit words) under type-based aliasing.
-    asm volatile("" ::: "memory");
-    __syncthreads();
-    // ---- GEMM chain on this wave's 16 nodes ------------------------------------------------------------------------
-    int lane2 = lane;
-    asm volatile("" : "+v"(lane2));
-    const int nrow = tperm[wave * 16 + (lane2 & 15)];      // this lane's node (row of the tile)
-    const float4 sx = srow[nrow];                          // (a0, b0, a1, x)
-    const float s_a = sA[nrow];
-    const int fq = 4 * (lane2 >> 4);                        // first feature of this lane inside a feature tile
-    Frag XH, X1;                                           // hh, h1 as B fragments (standard k order)
-    const int xsw = (nrow >> 1) & 7;
-    const int xc0 = ((q4 ^ xsw) & 7) << 3, xc1 = (((4 + q4) ^ xsw) & 7) << 3;
-#define GF16_LDX(X_, img_)                                                   \
-  {                                                                          \
-    const short* a_ = (img_) + nrow * 64;                                    \
-    X_.h0 = *reinterpret_cast<const f16x8*>(a_ + xc0);                       \
-    X_.l0 = *reinterpret_cast<const f16x8*>(a_ + PLN + xc0);                 \
-    X_.h1 = *reinterpret_cast<const f16x8*>(a_ + xc1);                       \
-    X_.l1 = *reinterpret_cast<const f16x8*>(a_ + PLN + xc1);                 \
-  }
-    GF16_LDX(XH, I1)
-    f32x4 acc0, acc1, acc2, acc3;          // feature tiles 0..3 of this lane's node
-    Frag XC;                               // h2, then y1, then y2 (permuted k order)
-    float s_c;                             // its scale
-#define GF16_V4(p_) (*reinterpret_cast<const f32x4*>(p_))
-    // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) ------------------------------------------------------------
-    GF16_WSTORE(qa, 2)
-    GF16_WLOAD(qa, 4)
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(0), XH)
-    GF16_WSTORE(qb, 3)
-    GF16_WLOAD(qb, 5)
-    GF16_LDX(X1, I0)
-    GF16_BLOCK(GF16_RING(1), X1)
-    {
-      const float f = pow2_inverse(s_a) * winv1;
-      const float* u_ = cst + fq;
-      const float* d_ = cst + 64 + fq;
-#define GF16_EPI1(a_, i_) a_ = __builtin_elementwise_max(a_ * f + (GF16_V4(u_ + 16 * (i_)) * sx.z + GF16_V4(d_ + 16 * (i_))), f32x4{0.f, 0.f, 0.f, 0.f});
-      GF16_EPI1(acc0, 0) GF16_EPI1(acc1, 1) GF16_EPI1(acc2, 2) GF16_EPI1(acc3, 3)
-#undef GF16_EPI1
-      s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
-      make_frag(acc0, acc1, acc2, acc3, s_c, XC);
-    }
-    // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) ------------------------------------------------------
-    __syncthreads();
-    if (has_next) GF16_STAGE2()
-    GF16_WSTORE(qa, 4)
-    GF16_WLOAD(qa, 6)
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(2), X1)
-    GF16_WSTORE(qb, 5)
-    GF16_WLOAD(qb, 7)
-    {
-      const float rs = s_c * pow2_inverse(s_a);       // units of h1's scale -> units of h2's scale (exact)
-      GF16_SCALE(rs)
-    }
-    GF16_BLOCK(GF16_RING(3), XC)
-    {
-      const float f = pow2_inverse(s_c) * winvp;
-      const float* t_ = cst + 128 + fq;
-      const float* z_ = cst + 768 + fq;
-#define GF16_EPI2(a_, i_)                                                                                     \
-  {                                                                                                           \
-    const f32x4 v_ = a_ * f + (GF16_V4(t_ + 16 * (i_)) * sx.w + GF16_V4(z_ + 16 * (i_)));                      \
-    a_ = __builtin_elementwise_max(v_, v_ * 0.1f);                                                            \
-  }
-      GF16_EPI2(acc0, 0) GF16_EPI2(acc1, 1) GF16_EPI2(acc2, 2) GF16_EPI2(acc3, 3)
-#undef GF16_EPI2
-      s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
-      make_frag(acc0, acc1, acc2, acc3, s_c, XC);
-    }
-    // ---- block 4: y2 = relu(y1 W3 + b3) ----------------------------------------------------------------------------
-    __syncthreads();
-    if (has_next) GF16_STAGE3(next)
-    GF16_WSTORE(qa, 6)
-    GF16_WLOAD(qa, 8)
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(4), XC)
-    {
-      const float f = pow2_inverse(s_c) * winv3;
-      const float* b_ = cst + 192 + fq;
-#define GF16_EPI3(a_, i_) a_ = __builtin_elementwise_max(a_ * f + GF16_V4(b_ + 16 * (i_)), f32x4{0.f, 0.f, 0.f, 0.f});
-      GF16_EPI3(acc0, 0) GF16_EPI3(acc1, 1) GF16_EPI3(acc2, 2) GF16_EPI3(acc3, 3)
-#undef GF16_EPI3
-      s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
-      make_frag(acc0, acc1, acc2, acc3, s_c, XC);
-    }
-    // ---- blocks 5..8: head partial  sum_c relu(y2 W5 + b5)[c] * w7[c], 4 column groups of 64 ------------------------
-    float part = 0.f;
-    const float fh = pow2_inverse(s_c) * winv5;
-#define GF16_HEAD1(a_, cg_, i_)                                                                               \
-  {                                                                                                           \
-    const f32x4 v_ = __builtin_elementwise_max(a_ * fh + GF16_V4(cst + 256 + 64 * (cg_) + 16 * (i_) + fq),     \
-                                               f32x4{0.f, 0.f, 0.f, 0.f}) *                                   \
-                     GF16_V4(cst + 512 + 64 * (cg_) + 16 * (i_) + fq);                                        \
-    part += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                                                \
-  }
-// (fenced for the scheduler: left alone it overlaps the four blocks' bias / w7 reads and epilogues -- 213 live registers
-// there, and the allocator then parks the next item's prefetched records in scratch)
-#define GF16_HEAD(cg_)                                                                                       \
-  __builtin_amdgcn_sched_barrier(0);                                                                         \
-  GF16_HEAD1(acc0, cg_, 0) GF16_HEAD1(acc1, cg_, 1) GF16_HEAD1(acc2, cg_, 2) GF16_HEAD1(acc3, cg_, 3)        \
-  asm volatile("" : "+v"(part));   /* the sum is DONE here (pure arithmetic is otherwise sunk to its use) */  \
-  __builtin_amdgcn_sched_barrier(0);
-    GF16_WSTORE(qb, 7)
-    if (has_next) GF16_WLOAD(qb, 1)        // (step 5 would load the empty slot 9; step 7's load is taken here)
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(5), XC)
-    GF16_HEAD(0)
-    __syncthreads();
-    GF16_WSTORE(qa, 8)
-    if (has_next) GF16_WLOAD(qa, 0)        // block 0 of the next item (slot 10)
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(6), XC)
-    GF16_HEAD(1)
-    GF16_ZERO()                            // step 7: nothing to store (slot 9 is empty); its load went out at step 5
-    GF16_BLOCK(GF16_RING(7), XC)
-    GF16_HEAD(2)
-    __syncthreads();
-    if (has_next) {                        // step 8: block 0 of the next item into slot 10
-      GF16_WSTORE(qa, 10)
-      GF16_WLOAD(qa, 2)
-    }
-    GF16_ZERO()
-    GF16_BLOCK(GF16_RING(8), XC)
-    GF16_HEAD(3)
-#undef GF16_HEAD
-#undef GF16_HEAD1
-    if (has_next) {                        // step 9 (no block): block 1 of the next item into slot 11
-      GF16_WSTORE(qb, 11)
-      GF16_WLOAD(qb, 3)
-    }
-    part = quarters_sum(part);
-    if (lane2 < 16 && nrow < nrows) g.out[(n0 + nrow) * Q + q] = part + g.b7 + sx.w;
-    if (!has_next) break;
-    item = next;
-    wbase ^= 2;
-    if (tid == 0) *tick = tk;
-    // No barrier here: everything the next publish overwrites (srow, rp, tperm, the records, zp_q, sA is written in
-    // phase 1) was last read in front of the barrier before block 8 or is read by the writing thread only (tick).
-  }
-  if (tid == 0 && atomicAdd(g.queue + 1, 1ull) == gridDim.x - 1) {      // last block out: leave the queue clean
-    g.queue[0] = 0;
-    g.queue[1] = 0;
-  }
-#undef GF16_STAGE1
-#undef GF16_STAGE2
-#undef GF16_STAGE3
-#undef GF16_V4
-#undef GF16_LDX
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-autonomous form (round 4, second half).  With two fp16 planes ALL nine weight blocks fit in LDS at once
-// (147 456 B), and with the neighbour-sum phase computed directly in the MFMA B layout (lane = node, 16 features per
-// lane) nothing is shared between the waves of a workgroup but those read-only weights: no activation images, no weight
-// ring, NO barrier inside the work loop.  Every wave carries its own 16 nodes through the whole network for a chunk of
-// queries, and the eight waves of a CU drift apart freely -- one wave's neighbour sums, epilogues and record loads run
-// under the other waves' MFMAs, which the lock-stepped block form could not do (phase 1 and six barriers per item were
-// ~40 % of its time with no MFMA in flight).  Work unit = (16-node group, WQ queries), drawn per wave from the caller's
-// queue.  The GEMM chain, scales, k permutation and weight images are those of the block form above.
 constexpr int WQ = 8;                       // queries per work unit
 constexpr int WCOLS = 15;                   // neighbour steps whose column ids are staged per wave ([15][16] ints)
 constexpr int WCST = 896;                   // u, d1, tp, b3 (64 each), b5, w7 (256 each), r, t (64 each)
 constexpr size_t LDS_WAVE = (size_t)9 * WBLK * 2 + (size_t)WCST * 4 + (size_t)8 * (WCOLS * 16 + 64) * 4;
-static_assert(LDS_WAVE <= 160 * 1024, "gossip_wave_f16: LDS budget exceeded");
+static_assert(LDS_WAVE <= 160 * 1024, "gossip_f16: LDS budget exceeded");
 
-__global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kernel(Args g, int64_t num_groups) {
+__global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kernel(Args g, int64_t num_groups) {
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
   short* WB = reinterpret_cast<short*>(gf_lds);                       // nine resident weight blocks
   float* cst = reinterpret_cast<float*>(WB + 9 * WBLK);
@@ -633,7 +219,16 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kerne
     const int64_t grp = unit / QC;
     const int qa = (int)(unit - grp * QC) * WQ;
     const int qb = qa + WQ < Q ? qa + WQ : Q;
-    const int64_t row_raw = grp * 16 + wrow;
+    // this lane's node.  With a tile order (desco_gossip_tile_order: the rows of a 128-node tile sorted by degree, pairs
+    // dealt to eight waves in snake order) group gi of the tile takes sorted ranks 16 gi .. 16 gi + 15 -- rank t sits
+    // at slot 16 w + 2 (t >> 4) + (t & 1) with w = its pair's snake position -- so the 16 nodes of a wave have similar
+    // degrees and the neighbour loop below (as many steps as the group's largest degree) wastes few lanes.
+    int64_t row_raw = grp * 16 + wrow;
+    if (g.tperm) {
+      const int gi = (int)(grp & 7), sl = wrow >> 1;
+      const int64_t t0 = (grp >> 3) * GT;
+      row_raw = t0 + g.tperm[t0 + 16 * ((gi & 1) ? 7 - sl : sl) + 2 * gi + (wrow & 1)];
+    }
     const bool valid = row_raw < g.num_nodes;
     const int64_t row = valid ? row_raw : g.num_nodes - 1;
     const int e0 = g.rowptr[row];
@@ -647,20 +242,46 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kerne
     const int nst = maxdeg < WCOLS ? maxdeg : WCOLS;
     for (int i = q4; i < nst; i += 4)
       if (i < deg) ecolw[i * 16 + wrow] = g.col[e0 + i];
+    // bit i: neighbour i of this node has the smaller id (gate g1 instead of 1 - g1); the same for every query
+    uint32_t lt = 0;
+    for (int i = 0; i < nst; ++i)
+      if (i < deg && ecolw[i * 16 + wrow] < (int)row) lt |= 1u << i;
+
+    // Everything query q needs from memory travels one query ahead: issued in front of the GEMM chain of query q - 1
+    // (in front of the loop for the first one), consumed at the top of query q.
+    float nzp, ngq;
+    float4 nsi, nr0, nr1, nr2, nr3;
+    f32x4 np0, np1, np2, np3, nz0, nz1, nz2, nz3;
+    nr0 = nr1 = nr2 = nr3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GW_NREC(i_) g.scal[(int64_t)((i_) < deg ? ecolw[(i_) * 16 + wrow] : (int)row) * Q + qn_]
+#define GW_PREFETCH(q_)                                                                        \
+  {                                                                                            \
+    const int qn_ = (q_);                                                                      \
+    nzp = g.zp[qn_ * 64 + lane];                                                               \
+    ngq = g.g1[qn_];                                                                           \
+    nsi = g.scal[row * Q + qn_];                                                               \
+    np0 = GW_V4(g.p + qn_ * 64 + fa); np1 = GW_V4(g.p + qn_ * 64 + fa + 4);                    \
+    np2 = GW_V4(g.p + qn_ * 64 + fb); np3 = GW_V4(g.p + qn_ * 64 + fb + 4);                    \
+    nz0 = GW_V4(g.z + qn_ * 64 + fa); nz1 = GW_V4(g.z + qn_ * 64 + fa + 4);                    \
+    nz2 = GW_V4(g.z + qn_ * 64 + fb); nz3 = GW_V4(g.z + qn_ * 64 + fb + 4);                    \
+    if (maxdeg > 0) nr0 = GW_NREC(0);                                                          \
+    if (maxdeg > 1) nr1 = GW_NREC(1);                                                          \
+    if (maxdeg > 2) nr2 = GW_NREC(2);                                                          \
+    if (maxdeg > 3) nr3 = GW_NREC(3);                                                          \
+  }
+    GW_PREFETCH(qa)
 
     for (int q = qa; q < qb; ++q) {
-      zpw[lane] = g.zp[q * 64 + lane];
-      const float gq = g.g1[q];
-      const float4 si = g.scal[row * Q + q];           // (a0, b0, a1, x)
+      zpw[lane] = nzp;
+      const float gq = ngq;
+      const float4 si = nsi;                           // (a0, b0, a1, x)
       f32x4 acc0, acc1, acc2, acc3;
       Frag XH, X1;
       float s_a;
       {
         // ---- neighbour sum and own h1 in the B layout of the first GEMM ----------------------------------------------
-        const f32x4 p0 = GW_V4(g.p + q * 64 + fa), p1 = GW_V4(g.p + q * 64 + fa + 4), p2 = GW_V4(g.p + q * 64 + fb),
-                    p3 = GW_V4(g.p + q * 64 + fb + 4);
-        const f32x4 z0 = GW_V4(g.z + q * 64 + fa), z1 = GW_V4(g.z + q * 64 + fa + 4), z2 = GW_V4(g.z + q * 64 + fb),
-                    z3 = GW_V4(g.z + q * 64 + fb + 4);
+        const f32x4 p0 = np0, p1 = np1, p2 = np2, p3 = np3, z0 = nz0, z1 = nz1, z2 = nz2, z3 = nz3;
+        const float4 c0 = nr0, c1 = nr1, c2 = nr2, c3 = nr3;
         const f32x4 r0 = GW_V4(cst + 768 + fa), r1 = GW_V4(cst + 768 + fa + 4), r2 = GW_V4(cst + 768 + fb),
                     r3 = GW_V4(cst + 768 + fb + 4);
         const f32x4 t0 = GW_V4(cst + 832 + fa), t1 = GW_V4(cst + 832 + fa + 4), t2 = GW_V4(cst + 832 + fb),
@@ -668,18 +289,38 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kerne
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 h0 = zero4, h1 = zero4, h2 = zero4, h3 = zero4;
 #define GW_H1(s_, c_) __builtin_elementwise_max((s_).x * p##c_ + (s_).y * r##c_ + (s_).w * t##c_ + z##c_, zero4)
-        for (int i = 0; i < maxdeg; ++i) {
-          const bool on = i < deg;
-          int j = (int)row;
-          if (on) j = i < WCOLS ? ecolw[i * 16 + wrow] : g.col[e0 + i];
-          const float4 sj = g.scal[(int64_t)j * Q + q];
-          const float gt = on ? (j < (int)row ? gq : 1.f - gq) : 0.f;
-          h0 += gt * GW_H1(sj, 0);
-          h1 += gt * GW_H1(sj, 1);
-          h2 += gt * GW_H1(sj, 2);
-          h3 += gt * GW_H1(sj, 3);
+#define GW_ADD(rec_, gt_)                                                                      \
+  {                                                                                            \
+    h0 += (gt_) * GW_H1(rec_, 0);                                                              \
+    h1 += (gt_) * GW_H1(rec_, 1);                                                              \
+    h2 += (gt_) * GW_H1(rec_, 2);                                                              \
+    h3 += (gt_) * GW_H1(rec_, 3);                                                              \
+  }
+#define GW_GATE(i_) ((i_) < deg ? (((lt >> (i_)) & 1u) ? gq : 1.f - gq) : 0.f)
+        if (maxdeg > 0) GW_ADD(c0, GW_GATE(0))
+        if (maxdeg > 1) GW_ADD(c1, GW_GATE(1))
+        if (maxdeg > 2) GW_ADD(c2, GW_GATE(2))
+        if (maxdeg > 3) GW_ADD(c3, GW_GATE(3))
+        for (int i = 4; i < maxdeg; i += 4) {          // beyond the prefetched four: four records in flight per step
+          int j0 = (int)row, j1 = j0, j2 = j0, j3 = j0;
+#define GW_COL(j_, k_) if (i + (k_) < deg) j_ = i + (k_) < WCOLS ? ecolw[(i + (k_)) * 16 + wrow] : g.col[e0 + i + (k_)];
+          GW_COL(j0, 0) GW_COL(j1, 1) GW_COL(j2, 2) GW_COL(j3, 3)
+#undef GW_COL
+          const float4 a0 = g.scal[(int64_t)j0 * Q + q];
+          float4 a1 = a0, a2 = a0, a3 = a0;
+          if (i + 1 < maxdeg) a1 = g.scal[(int64_t)j1 * Q + q];
+          if (i + 2 < maxdeg) a2 = g.scal[(int64_t)j2 * Q + q];
+          if (i + 3 < maxdeg) a3 = g.scal[(int64_t)j3 * Q + q];
+#define GW_GT(j_, k_) (i + (k_) < deg ? ((j_) < (int)row ? gq : 1.f - gq) : 0.f)
+          GW_ADD(a0, GW_GT(j0, 0))
+          if (i + 1 < maxdeg) GW_ADD(a1, GW_GT(j1, 1))
+          if (i + 2 < maxdeg) GW_ADD(a2, GW_GT(j2, 2))
+          if (i + 3 < maxdeg) GW_ADD(a3, GW_GT(j3, 3))
+#undef GW_GT
         }
         const f32x4 s0 = GW_H1(si, 0), s1 = GW_H1(si, 1), s2 = GW_H1(si, 2), s3 = GW_H1(si, 3);
+#undef GW_GATE
+#undef GW_ADD
 #undef GW_H1
         // one power of two for the node's h1 AND hh (they meet in one accumulator)
         const float m = quarters_max(fmaxf(absmax16(h0, h1, h2, h3), absmax16(s0, s1, s2, s3)));
@@ -687,6 +328,7 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kerne
         make_frag(h0, h1, h2, h3, s_a, XH);
         make_frag(s0, s1, s2, s3, s_a, X1);
       }
+      if (q + 1 < qb) GW_PREFETCH(q + 1)
       Frag XC;
       float s_c;
       // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) ------------------------------------------------------------
@@ -760,6 +402,8 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_wave_f16_kerne
     unit = (int64_t)__builtin_amdgcn_readfirstlane((int)(tk & 0xffffffffull)) |
            ((int64_t)__builtin_amdgcn_readfirstlane((int)(tk >> 32)) << 32);
   }
+#undef GW_PREFETCH
+#undef GW_NREC
 #undef GW_V4
   if (lane == 0 && atomicAdd(g.queue + 1, 1ull) == nwaves - 1) {        // last wave out: leave the queue clean
     g.queue[0] = 0;
@@ -807,43 +451,6 @@ extern "C" int desco_gossip_f16_stream(const int16_t* w1_planes, const int16_t* 
   return launch_status("desco_gossip_f16_stream");
 }
 
-extern "C" int desco_gossip_wave_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
-                                           int64_t num_nodes, int num_q, const float* g1, const float* p,
-                                           const float* z, const float* zp, const float* r, const float* t,
-                                           const float* u, const float* tp, const float* d1, const int16_t* wstream,
-                                           const float* winv, const float* b3, const float* b5, const float* w7,
-                                           float b7, float* out, uint64_t* queue, desco_stream_t stream) {
-  using namespace gf16;
-  if (num_nodes == 0) return 0;
-  auto mis16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) != 0; };
-  auto mis8 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 7) != 0; };
-  if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !wstream || !winv || !b3 || !b5 ||
-      !w7 || !out || !queue || num_nodes < 0 || num_q < 1 || num_q > 65535 || mis16(scal4) || mis16(wstream) ||
-      mis16(p) || mis16(z) || mis16(r) || mis16(t) || mis8(queue))
-    return fail(DESCO_EINVAL, "desco_gossip_wave_f16x3_f32: bad argument");
-  const int64_t groups = (num_nodes + 15) / 16;
-  Args a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z, zp, r, t, u, tp, d1,
-         reinterpret_cast<const short*>(wstream), winv, b3, b5, w7, b7, out, nullptr,
-         reinterpret_cast<unsigned long long*>(queue)};
-  static DeviceOnce attr_once;
-  if (!attr_once.done()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_wave_f16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_WAVE);
-    if (e != hipSuccess) return fail((int)e, "desco_gossip_wave_f16x3_f32: cannot size LDS");
-    attr_once.mark();
-  }
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
-  const int64_t units = groups * ((num_q + WQ - 1) / WQ);
-  const int64_t blocks = (units + 7) / 8;
-  const unsigned grid = (unsigned)(blocks < (int64_t)cus ? blocks : (int64_t)cus);
-  hipLaunchKernelGGL(gossip_wave_f16_kernel, dim3(grid), dim3(GNT), LDS_WAVE, (hipStream_t)stream, a, groups);
-  return launch_status("desco_gossip_wave_f16x3_f32");
-}
-
 extern "C" int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,
                                             int64_t num_nodes, int num_q, const float* g1, const float* p,
                                             const float* z, const float* zp, const float* r, const float* t,
@@ -857,17 +464,17 @@ extern "C" int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* r
   auto mis8 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 7) != 0; };
   if (!scal4 || !rowptr || !g1 || !p || !z || !zp || !r || !t || !u || !tp || !d1 || !wstream || !winv || !b3 || !b5 ||
       !w7 || !out || !queue || num_nodes < 0 || num_q < 1 || num_q > 65535 || mis16(scal4) || mis16(wstream) ||
-      mis8(p) || mis8(z) || mis8(r) || mis8(t) || mis8(queue) || (reinterpret_cast<uintptr_t>(tile_perm) & 3))
+      mis16(p) || mis16(z) || mis16(r) || mis16(t) || mis8(queue))
     return fail(DESCO_EINVAL, "desco_gossip_fused_f16x3_f32: bad argument");
-  const int64_t bx = (num_nodes + GT - 1) / GT;
-  if (bx > INT32_MAX) return fail(DESCO_EINVAL, "desco_gossip_fused_f16x3_f32: too many nodes");
+  // (with a tile order the groups are the eighths of whole 128-node tiles: a ragged last tile has empty ranks)
+  const int64_t groups = tile_perm ? (num_nodes + GT - 1) / GT * 8 : (num_nodes + 15) / 16;
   Args a{reinterpret_cast<const float4*>(scal4), rowptr, col, num_nodes, num_q, g1, p, z, zp, r, t, u, tp, d1,
          reinterpret_cast<const short*>(wstream), winv, b3, b5, w7, b7, out, tile_perm,
          reinterpret_cast<unsigned long long*>(queue)};
-  static DeviceOnce attr_once;        // function attributes are per device
+  static DeviceOnce attr_once;
   if (!attr_once.done()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gossip_fused_f16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_WAVE);
     if (e != hipSuccess) return fail((int)e, "desco_gossip_fused_f16x3_f32: cannot size LDS");
     attr_once.mark();
   }
@@ -876,8 +483,9 @@ extern "C" int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* r
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  const int64_t nitems = bx * num_q;
-  const unsigned grid = (unsigned)(nitems < (int64_t)cus ? nitems : (int64_t)cus);
-  hipLaunchKernelGGL(gossip_fused_f16_kernel, dim3(grid), dim3(GNT), LDS_BYTES, (hipStream_t)stream, a, bx);
+  const int64_t units = groups * ((num_q + WQ - 1) / WQ);
+  const int64_t blocks = (units + 7) / 8;
+  const unsigned grid = (unsigned)(blocks < (int64_t)cus ? blocks : (int64_t)cus);
+  hipLaunchKernelGGL(gossip_fused_f16_kernel, dim3(grid), dim3(GNT), LDS_WAVE, (hipStream_t)stream, a, groups);
   return launch_status("desco_gossip_fused_f16x3_f32");
 }

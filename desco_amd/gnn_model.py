@@ -32,7 +32,6 @@ FUSED_GOSSIP = True
 # the fused gossip pass in the three-product fp16 form (csrc/gossip_f16.hip); False: the six-product bf16 kernel
 # (csrc/gossip_fused.hip), kept as its cross-check
 GOSSIP_F16X3 = os.environ.get("DESCO_GOSSIP_F16X3", "1") != "0"
-GOSSIP_WAVE = os.environ.get("DESCO_GOSSIP_WAVE", "0") != "0"
 # inference GEMMs (anchor, post MLP, head, canonical table) on the bf16 matrix pipe with fp32-level
 # accuracy (bf16x6 split, csrc/gemm_split.hip); False: v_mfma_f32_32x32x2_f32 (gemm_f32.hip)
 GEMM_BF16X6 = True
@@ -788,7 +787,7 @@ def gossip_forward(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tensor) ->
             if GOSSIP_F16X3:
                 v["wstream"], v["winv"] = pk["wstream"], pk["winv"]
                 outs.append(ops.gossip_fused_f16(scal4, batch.rowptr, batch.col, N, q1 - q0, v, batch.work_queue,
-                                                 tile_perm=tperm, wave_form=GOSSIP_WAVE,
+                                                 tile_perm=tperm,
                                                  out=getattr(batch, "out_buf", None) if (q0 == 0 and q1 == Q) else None))
             else:
                 outs.append(ops.gossip_fused(scal4, batch.rowptr, batch.col, N, q1 - q0, v, tile_perm=tperm))

@@ -814,8 +814,9 @@ def gossip_f16_stream(w1: F16Planes, wp: F16Planes, w3: F16Planes, w5: F16Planes
 
 def gossip_fused_f16(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, num_nodes: int,
                      num_q: int, v: dict, queue: torch.Tensor, tile_perm: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, wave_form: bool = False) -> torch.Tensor:
-    """One on-chip pass per (128-node tile, query) in the three-product fp16 form (csrc/gossip_f16.hip): returns
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The whole gossip network on chip in the three-product fp16 form, one wave per (16 nodes, 8 queries) work unit
+    (csrc/gossip_f16.hip): returns
     pred [N, Q].  ``queue``: two zeroed int64 words (see desco_hip.h); ``out``: optional contiguous [N, Q] destination."""
     if out is None:
         out = torch.empty((num_nodes, num_q), device=scal.device, dtype=torch.float32)
@@ -833,14 +834,6 @@ def gossip_fused_f16(scal: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor
             raise ValueError(f"gossip_fused_f16: operand {n} must be contiguous")
         ptrs.append(_dev(v[n], n, torch.int16 if n == "wstream" else torch.float32))
     rows = float(num_nodes) * num_q
-    if wave_form:
-        with _Timed("gossip_wave_f16_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
-                    rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
-            _lib.check(L.desco_gossip_wave_f16x3_f32(_dev(scal, "scal"), _dev(rowptr, "rowptr", torch.int32),
-                                                     _dev(col, "col", torch.int32), num_nodes, num_q, *ptrs,
-                                                     float(v["b7"]), _dev(out, "out"), _dev(queue, "queue", torch.int64),
-                                                     _stream()), "gossip_wave_f16")
-        return out
     with _Timed("gossip_fused_f16_kernel", rows * GOSSIP_FUSED_FLOPS_PER_ROW,
                 rows * 20.0 + 4.0 * (col.numel() * (1 + 4 * num_q) + num_nodes)):
         _lib.check(L.desco_gossip_fused_f16x3_f32(_dev(scal, "scal"), _dev(rowptr, "rowptr", torch.int32),

@@ -418,8 +418,10 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
                            const float* b5, const float* w7, float b7, float* out,
                            const uint8_t* tile_perm, desco_stream_t stream);
 /* The same fused gossip pass in the THREE-product fp16 form (csrc/gossip_f16.hip; the product path since round 4):
- * per-node power-of-two scales carry the range, a wave owns 16 nodes x all features so that h2, y1, y2 stay in
- * registers between the GEMMs, weight blocks stream through a ring of four LDS buffers (5 barriers per item).
+ * per-node power-of-two scales carry the range; a wave owns 16 nodes x all features, all nine weight blocks stay
+ * resident in LDS and a wave carries its nodes through the whole network for 8 queries per work unit with no barrier
+ * in the loop.  tile_perm (optional, desco_gossip_tile_order's output): the 16 nodes of a wave are the degree-sorted
+ * ranks 16 i .. 16 i + 15 of their 128-node tile (speed only; p, z, r, t must be 16-byte aligned).
  *   wstream [9][2][4096] fp16 + winv[4]: desco_gossip_f16_stream of the four desco_split_f16x2_f32 plane sets
  *     (w1, wp [2][64][128]; w3 [2][64][64]; w5 [2][256][64]) and the 1/scale of each matrix, in that order;
  *   queue: two zeroed 64-bit words owned by the caller (work-item tickets of this launch; the kernel leaves them
@@ -433,15 +435,6 @@ int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, cons
                                  const float* u, const float* tp, const float* d1, const int16_t* wstream,
                                  const float* winv, const float* b3, const float* b5, const float* w7, float b7,
                                  float* out, const uint8_t* tile_perm, uint64_t* queue, desco_stream_t stream);
-
-/* The same network in WAVE-AUTONOMOUS form (round 4): all nine weight blocks resident in LDS, a wave carries 16 nodes
- * through the whole network for 8 queries at a time, no barrier inside the work loop.  Arguments as above without
- * tile_perm; queue: two zeroed 64-bit words, left zero. */
-int desco_gossip_wave_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col, int64_t num_nodes,
-                                int num_q, const float* g1, const float* p, const float* z, const float* zp,
-                                const float* r, const float* t, const float* u, const float* tp, const float* d1,
-                                const int16_t* wstream, const float* winv, const float* b3, const float* b5,
-                                const float* w7, float b7, float* out, uint64_t* queue, desco_stream_t stream);
 /* tile_perm (optional, 4-byte aligned, [ceil(num_nodes/128)*128] bytes from desco_gossip_tile_order): the order in
  * which the 8 waves of a block walk the rows of a 128-node tile in the neighbour-sum phase -- rows sorted by degree,
  * paired, pairs dealt to the waves in snake order (a half wave per row, the two halves of a wave in lock step, a block

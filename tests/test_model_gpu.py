@@ -906,3 +906,26 @@ def test_without_tconv_matches_oracle(setup):
     report("no-tconv target_emb", got_t, emb_t)
     assert_logits_close("no-tconv query_emb", got_q, emb_q)
     assert_logits_close("no-tconv target_emb", got_t, emb_t)
+
+
+def test_mfma_kernels_are_bit_reproducible(setup):
+    """Two passes over the same batch give bit-identical results, and so do five launches of the gossip kernel alone.
+    (Round 4: packed fp32 VALU instructions beside other waves' MFMAs returned wrong values in ~1 % of the gossip
+    kernel's outputs, differently in every launch -- profiles/r4_b_gossip_f16_race.md; the kernel is compiled without
+    them.  This is the regression test, and the same check for the SHMP layer kernel, which keeps its packed forms.)"""
+    nm, gm, qids, queries = setup
+    gs = GraphSet.from_edge_lists(golden_graphs(max_n=60) * 6)
+    part = build_partition(gs, 4)
+    nb = NeighborhoodBatch(part, DEV)
+    with torch.no_grad():
+        a = nm.graph_to_count(nb)
+        for _ in range(2):
+            assert torch.equal(nm.graph_to_count(nb), a)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(gs.num_nodes, len(queries), generator=g) * 20
+    gb = GossipBatch(gs, DEV, x=x)
+    with torch.no_grad():
+        ref = gm.graph_to_count(gb).clone()
+        for _ in range(5):
+            assert torch.equal(gm.graph_to_count(gb), ref)
+
