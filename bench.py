@@ -178,8 +178,10 @@ def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0, workers=None
         # tiny torch ops only adds synchronisation, so P single-threaded processes take disjoint shards of a sample
         # sized for ~target_seconds / 2 of wall time at the 1-thread rate per process
         P = len(workers)
+        # (drawn from the SAME graphs as the one-process sample: on a dataset ordered by size -- Syn_1827 -- cycling
+        #  over all of it would hand every worker graphs a hundred times dearer than the ones the rate was sized on)
         n_pp = int(max(2 * P, min(64 * len(graphs_host), 0.5 * target_seconds * runs[1] * P)))
-        sample_pp = [graphs_host[i % len(graphs_host)] for i in range(n_pp)]
+        sample_pp = [sample[i % len(sample)] for i in range(n_pp)]
         rate, wall, slowest, fastest = cpu_baseline_processes(workers, sd_n, sd_g, sample_pp, queries)
         pp = {"value": rate, "processes": P, "threads_per_process": 1, "graphs": n_pp, "wall_s": wall,
               "slowest_worker_s": slowest, "fastest_worker_s": fastest}

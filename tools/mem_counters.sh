@@ -26,7 +26,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(f"{out}/mem_{w}_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").replace("gf16::", "").replace("small::", "").strip()
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
 for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("TCP_TOTAL_READ_sum", 0) * 0 - sum(kv[1].get("TD_TD_BUSY_sum", 0) for _ in (0,))):

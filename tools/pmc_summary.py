@@ -19,7 +19,7 @@ def load(path, cname):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != cname:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").replace("gf16::", "").replace("small::", "").strip()
         if k.startswith("shmp_layer16_kernel<"):           # <NW, KB, ST, LD64, POOL, F16>
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
             k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}>"

@@ -18,7 +18,11 @@ P3="SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COE
 for WL in $WLS; do
   W=${WL%%:*}; R=${WL##*:}; K=${W}_x${R}
   ARGS="--workload $W --replicas $R"
-  python3 bench.py $ARGS --steps 10 --warmup 3 > $OUT/bench_$K.json 2> $OUT/bench_$K.err
+  # the default workload's line is the driver's (CPU baseline, training legs, secondary shapes); the other shapes run
+  # their own pass only -- the training legs and the CPU baseline do not depend on the inference workload
+  EXTRA=""
+  [ "$W" != "cox2" ] && EXTRA="--no-train --no-cpu-baseline --no-secondary --no-x1"
+  python3 bench.py $ARGS --steps 10 --warmup 3 $EXTRA > $OUT/bench_$K.json 2> $OUT/bench_$K.err
   head -c 300 $OUT/bench_$K.json; echo
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$K -- python3 $ROOT/bench.py $ARGS --steps 5 --warmup 2 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train > $OUT/stats_$K.log 2>&1
@@ -42,7 +46,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(f"{out}/sq_{key}_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").replace("gf16::", "").replace("small::", "").strip()
         if k.startswith("shmp_layer16_kernel<"):           # <NW, KB, ST, LD64, POOL, F16>
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
             k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}>"

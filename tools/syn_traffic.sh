@@ -38,7 +38,7 @@ for ds in (1, 0):
     cnt = collections.defaultdict(lambda: collections.defaultdict(int))
     for f in glob.glob(f"{out}/ds{ds}_p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").strip()
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").replace("gf16::", "").replace("small::", "").strip()
             if not k.startswith("shmp_layer16_kernel<"):
                 continue
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
