@@ -23,11 +23,12 @@ inline int launch_status(const char* what) {
   return 0;
 }
 
-// Kernels whose waves run VALU phases beside OTHER waves' MFMAs must not use packed fp32 instructions
-// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on MI355X they returned wrong values -- sporadically, 1 % of the results of
-// the wave-autonomous gossip kernel, always in lanes 48-63 in the block form -- whenever another wave of the SIMD was
-// issuing MFMAs, with every operand right; the same arithmetic as scalar v_fma_f32 is exact and bit-reproducible
-// (profiles/r4_b_gossip_f16_race.md).  A kernel attribute, so the rest of a file keeps the packed forms.
+// Compile a kernel without packed fp32 instruction selection (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The gossip
+// kernel needs it: with the packed forms its neighbour loop returned wrong values on MI355X -- sporadically, 1-2 % of the
+// results of the wave-autonomous form, lanes 48-63 in the block form, only while other waves of the SIMD issued MFMAs,
+// with every operand right; the same source as scalar v_fma_f32 is exact and bit-reproducible.  Neither the cause
+// (hardware or compiler) nor a reduced reproducer was found (profiles/r4_b_gossip_f16_race.md); the other kernels keep
+// their packed forms and are covered by the repeat test test_mfma_kernels_are_bit_reproducible.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DESCO_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
 #else
