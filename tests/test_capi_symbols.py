@@ -60,6 +60,38 @@ def test_new_entry_points_validate_their_arguments():
     assert b"desco_gossip_fused_f32" in L.desco_last_error()
 
 
+def test_round4_entry_points_validate_their_arguments():
+    """Round-4 entry points: bad arguments come back as DESCO_EINVAL with a message naming the entry point."""
+    L = _lib.lib()
+    one = np.zeros(4, np.float32)
+    assert L.desco_adam_step_f32(1, None, None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None) == -1
+    assert b"desco_adam_step_f32" in L.desco_last_error()
+    assert L.desco_adam_step_f32(0, None, None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None) == 0
+    assert L.desco_gemm_f32_multi(5, None, None) == -1 and b"desco_gemm_f32_multi" in L.desco_last_error()
+    assert L.desco_gemm_f32_multi(0, None, None) == 0
+    d = (_lib.GemmDesc * 1)()
+    d[0].m, d[0].k1, d[0].n = 8, 48, 64                    # k % 32 != 0, null operands
+    assert L.desco_gemm_f32_multi(1, d, None) == -1
+    assert L.desco_linear_bwd_w_multi_f32(17, None, None, None) == -1
+    assert b"desco_linear_bwd_w_multi_f32" in L.desco_last_error()
+    b = (_lib.BwdWDesc * 2)()
+    b[0].m, b[0].k1, b[0].n = 1000, 64, 64
+    b[1].m, b[1].k1, b[1].k2, b[1].n = 10, 128, 64, 64
+    assert L.desco_linear_bwd_w_multi_workspace(2, b) == (L.desco_linear_bwd_w_workspace(1000, 64, 64) +
+                                                          L.desco_linear_bwd_w_workspace(10, 192, 64))
+    assert L.desco_rowdot_bwd_f32(None, 256, 256, None, None, 4, None, 256, None, None, None) == -1
+    assert b"desco_rowdot_bwd_f32" in L.desco_last_error()
+    assert L.desco_linear_smallk_bwd_f32(None, 1, 1, None, 64, 4, None, None, None) == -1
+    assert b"desco_linear_smallk_bwd_f32" in L.desco_last_error()
+    assert L.desco_shmp_trunk_small_max_rows() == 144
+    assert L.desco_shmp_trunk_small_fwd_f32(None, None, None, 200, 8, None, None, None, 29, None, None, 576, None) == -1
+    assert b"desco_shmp_trunk_small_fwd_f32" in L.desco_last_error()
+    assert L.desco_shmp_trunk_small_bwd_f32(*([None] * 7), 10, 8, None, None, 576, None, None, None, None) == -1
+    assert L.desco_gossip_fused_f16x3_f32(*([None] * 3), 7, 29, *([None] * 14), 0.0, None, None, None, None) == -1
+    assert b"desco_gossip_fused_f16x3_f32" in L.desco_last_error()
+    assert L.desco_gemm_f16x3_f32 is not None and L.desco_row_absmax_f32 is not None
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from desco_amd import ops
