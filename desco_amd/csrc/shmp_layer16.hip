@@ -950,8 +950,12 @@ static bool shmp16_launch_nw(const ShmpArgs& g, int cus, hipStream_t st) {
 // x6 arguments validated by shmp_launch (shmp_layer.hip); g.wplanes set, g.sm <= 2
 bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
   if (!g.wplanes || g.sm < 0 || g.sm > 2 || g.S > MAXS) return false;
-  // 16 waves per block (12 x 16 rows measured 2-6 % slower: profiles/r2_h_ab_tile_rows.log)
-  if (g.wscale) return shmp16_launch_nw<16, true>(g, cus, (hipStream_t)stream);     // fp16 three-product planes
+  // bf16x6 form: 16 waves per block (12 measured 2-6 % slower there: profiles/r2_h_ab_tile_rows.log).  fp16 form: TWELVE,
+  // three per SIMD -- a quarter fewer tiles in flight per XCD means a quarter less traffic between two references to a
+  // source row, and with half the matrix work per tile the fourth wave per SIMD is not needed to hide latency: Syn_1827
+  // shapes 3.68 -> 3.39 ms per count-row launch, MSRC-21 + IMDB 2.93 -> 2.74, COX2 1.325 -> 1.30; 8, 10 and 14 waves are
+  // all slower (profiles/r4_m_ab_shmp_waves.log)
+  if (g.wscale) return shmp16_launch_nw<12, true>(g, cus, (hipStream_t)stream);     // fp16 three-product planes
   return shmp16_launch_nw<16, false>(g, cus, (hipStream_t)stream);
 }
 

@@ -1,14 +1,9 @@
 #!/bin/bash
-# A/B one environment switch on the SAME box: tools/debug/ab_env.sh VAR "v0 v1" -- <bench.py flags>
-VAR=$1; VALS=$2; shift 3
-for round in 1 2; do
-  for v in $VALS; do
-    env $VAR=$v python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-x1 --no-attainable --no-train "$@" 2>/dev/null | V="$VAR=$v" python -c "
-import sys, json, os
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); tot = sum(k['ms'] for k in d['kernels'].values())
-        parts = ['%s %.4f' % (n.replace('_kernel', ''), k['ms'] / k['calls']) for n, k in sorted(d['kernels'].items(), key=lambda kv: -kv[1]['ms']) if k['ms'] > 0.03 * tot]
-        print(os.environ['V'], 'step %.2f ms, value %d, partition %.1f s |' % (d['ms_per_step'], d['value'], d['config'].get('partition_build_s', 0)), '; '.join(parts))"
-  done
-done
+# A/B of an environment switch on one box:  ab_env.sh VAR "v1 v2 .." "<workload> <replicas>" ...
+VAR=$1; VALS=$2; shift; shift
+for WL in "$@"; do set -- $WL
+for rep in 1 2; do for V in $VALS; do
+  export $VAR=$V
+  python bench.py --workload $1 --replicas $2 --steps 5 --warmup 2 --no-cpu-baseline --no-x1 --no-secondary --no-attainable --no-train 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('$1 x$2 $VAR=$V', round(d['value']), round(d['ms_per_step'],2), [(k, round(v['ms']/v['calls'],3)) for k,v in d['kernels'].items() if 'shmp' in k and '3,2' in k])"
+done; done; done
