@@ -109,6 +109,10 @@ __device__ __forceinline__ void make_frag(const f32x4 v0, const f32x4 v1, const 
   f.h1 = __builtin_bit_cast(f16x8, u32x4{h[4], h[5], h[6], h[7]});
   f.l1 = __builtin_bit_cast(f16x8, u32x4{l[4], l[5], l[6], l[7]});
 }
+__device__ __forceinline__ f32x4 fma4(const float a, const f32x4 b, const f32x4 c) {
+  return f32x4{__builtin_fmaf(a, b[0], c[0]), __builtin_fmaf(a, b[1], c[1]), __builtin_fmaf(a, b[2], c[2]),
+               __builtin_fmaf(a, b[3], c[3])};
+}
 __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d) {
   const float m0 = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
   const float m1 = fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3])));
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
                     t3 = GW_V4(cst + 832 + fb + 4);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 h0 = zero4, h1 = zero4, h2 = zero4, h3 = zero4;
-#define GW_H1(s_, c_) __builtin_elementwise_max((s_).x * p##c_ + (s_).y * r##c_ + (s_).w * t##c_ + z##c_, zero4)
+// (three dependent FMAs per feature, z first: as a sum of products hipcc emits mul + 2 fma + add)
+#define GW_H1(s_, c_) __builtin_elementwise_max(fma4((s_).x, p##c_, fma4((s_).y, r##c_, fma4((s_).w, t##c_, z##c_))), zero4)
 #define GW_ADD(rec_, gt_)                                                                      \
   {                                                                                            \
     h0 += (gt_) * GW_H1(rec_, 0);                                                              \
