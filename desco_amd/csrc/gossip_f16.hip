@@ -22,7 +22,7 @@
 //   * WAVE-AUTONOMOUS.  With two planes ALL nine 64 x 64 weight blocks fit in LDS at once (147 456 B), and the neighbour
 //     sums are computed directly in the B layout of the first GEMM (lane = node, 16 features per lane), so nothing is
 //     shared between the waves of a workgroup but those read-only weights: no activation images, no weight ring, NO
-//     barrier in the work loop.  Every wave carries its own 16 nodes through the whole network for a chunk of 8 queries
+//     barrier in the work loop.  Every wave carries its own 16 nodes through the whole network for a chunk of 5 queries
 //     (work unit, drawn per wave from the caller's queue), and the eight waves of a CU drift apart freely -- one wave's
 //     neighbour sums, epilogues and record loads run under the other waves' MFMAs.  The first version of this file kept
 //     the bf16 kernel's block structure (128-node items, lock-stepped waves, weights through a ring of four buffers, six
@@ -171,7 +171,7 @@ __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f3
 #define GF16_ZERO() { acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define GF16_SCALE(f_) { acc0 *= (f_); acc1 *= (f_); acc2 *= (f_); acc3 *= (f_); }
 
-constexpr int WQ = 8;                       // queries per work unit
+constexpr int WQ = 5;                       // queries per work unit (29 = 6 units of <= 5: 3-10 measured, profiles/r4_j_*)
 constexpr int WCOLS = 15;                   // neighbour steps whose column ids are staged per wave ([15][16] ints)
 constexpr int WCST = 896;                   // u, d1, tp, b3 (64 each), b5, w7 (256 each), r, t (64 each)
 constexpr size_t LDS_WAVE = (size_t)9 * WBLK * 2 + (size_t)WCST * 4 + (size_t)8 * (WCOLS * 16 + 64) * 4;

@@ -419,7 +419,7 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
                            const uint8_t* tile_perm, desco_stream_t stream);
 /* The same fused gossip pass in the THREE-product fp16 form (csrc/gossip_f16.hip; the product path since round 4):
  * per-node power-of-two scales carry the range; a wave owns 16 nodes x all features, all nine weight blocks stay
- * resident in LDS and a wave carries its nodes through the whole network for 8 queries per work unit with no barrier
+ * resident in LDS and a wave carries its nodes through the whole network for 5 queries per work unit with no barrier
  * in the loop.  tile_perm (optional, desco_gossip_tile_order's output): the 16 nodes of a wave are the degree-sorted
  * ranks 16 i .. 16 i + 15 of their 128-node tile (speed only; p, z, r, t must be 16-byte aligned).
  *   wstream [9][2][4096] fp16 + winv[4]: desco_gossip_f16_stream of the four desco_split_f16x2_f32 plane sets
