@@ -759,6 +759,20 @@ def main():
                                    "mfma_TFLOPs": tfs, "mfma_frac_of_split_peak": tfs / gather_mfma_peak(),
                                    "share_of_kernel_time": gk["ms"] / tot2,
                                    "avg_launch_ms": gk["ms"] / gk["calls"]}
+                # HBM bytes of these launches from the committed PMC passes of THIS shape, under the same validity
+                # rules as the primary line (same launches per step, not below 0.9 x the algorithmic bytes)
+                try:
+                    pmc2 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"]
+                    e2 = pmc2.get(f"{wname}_x{wrep}", {}).get("kernels", {}).get(gather_kernel())
+                except (OSError, ValueError, KeyError):
+                    e2 = None
+                alg2 = gk["bytes"] / gk["calls"]
+                if e2 and world == 1 and e2.get("launches_per_step") and \
+                        abs(e2["launches_per_step"] - gk["calls"] / 3) < 1e-6:
+                    tr2 = e2["hbm_bytes_per_step"] / e2["launches_per_step"]
+                    if tr2 >= 0.9 * alg2:
+                        entry["gather"].update({"algorithmic_bytes_per_launch": alg2, "traffic": tr2,
+                                                "traffic_over_algorithmic": tr2 / alg2})
             secondary[f"{wname}_x{wrep}"] = entry
             del p2, g2
             torch.cuda.empty_cache()
