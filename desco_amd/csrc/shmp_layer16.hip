@@ -513,8 +513,10 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   // i % NW of the block's (i / NW)-th block tile): whatever the waves' speeds, the tiles in flight in a
   // block are consecutive -- a window of a few hundred rows that also holds most of their sources (a
   // neighborhood's rows are contiguous).  With a fixed wave -> tile map the waves drift apart by whole
-  // sweeps and the L2 saw 3.3 row fetches per row on Syn_1827 shapes (hit rate 36 %).  A wave keeps three
-  // indices: the tile it works on, the next one (CSR slice in flight) and the one after (its id range).
+  // sweeps and the L2 saw 3.3 row fetches per row on Syn_1827 shapes (hit rate 36 %).  A wave keeps two
+  // indices: the tile it works on and the next one (id range, CSR slice and ids in flight under this tile); a third --
+  // the id range a tile earlier still, rounds 2-3 -- widened the span of rows the block's waves work on at a time
+  // (round 4: -1 % time on the dense shapes without it, +7 % with a fourth).
 #define DESCO_NEXT_SUB() __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(next_sub, 1) : 0)
 #define DESCO_SUB_ROWS(i_, w0_, ok_)                                                          \
   {                                                                                           \
@@ -522,12 +524,11 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     w0_ = bt_ * (NW * WR) + ((i_) % NW) * WR;                                                 \
     ok_ = bt_ < tend && w0_ < g.num_rows;                                                     \
   }
-  int sub_n1, sub_n2;
+  int sub_n1;
   int64_t w0;
   {
     const int i0_ = DESCO_NEXT_SUB();
     sub_n1 = DESCO_NEXT_SUB();
-    sub_n2 = DESCO_NEXT_SUB();
     bool ok_;
     DESCO_SUB_ROWS(i0_, w0, ok_)
     if (!ok_) return;                                      // no barrier below: idle waves may leave
@@ -548,19 +549,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     rpb[RPN] = 0;
   }
   int ebase = __builtin_amdgcn_readfirstlane(rp[0]);     // (wave-uniform values are kept in SGPRs)
-  // id range [ebn, een) of the NEXT tile: two scalar loads, one tile ahead of the LDS-direct load of the ids
-  int ebn = 0, een = 0;
-  {
-    int64_t w0n;
-    bool okn_;
-    DESCO_SUB_ROWS(sub_n1, w0n, okn_)
-    if (S > 0 && okn_) {
-      const int nrn = (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR);
-      const int32_t* q_ = rowptr_s + (g.row0 + w0n) * S;
-      ebn = q_[0];
-      een = q_[nrn * S];
-    }
-  }
 
   float4 lo0, lo1, hi0, hi1;                               // gathered sums of the current block
   float4 u00, u01, u10, u11;                               // in flight: first source (lo, hi) of row it
@@ -583,20 +571,14 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     DESCO_SUB_ROWS(sub_n1, w0n, has_next)
     const int nrn = has_next ? (int)((g.num_rows - w0n) < WR ? (g.num_rows - w0n) : WR) : 0;
     int* ecn = ecb + (cur ^ 1) * WCAP;
-    const int ebn_cur = ebn, een_cur = een;                    // (id range of the next tile)
-    // id range of the tile after the next (scalar loads; consumed in the next iteration)
-    {
-      int64_t w02;
-      bool ok2_;
-      DESCO_SUB_ROWS(sub_n2, w02, ok2_)
-      ebn = 0;
-      een = 0;
-      if (S > 0 && ok2_) {
-        const int nr2 = (int)((g.num_rows - w02) < WR ? (g.num_rows - w02) : WR);
-        const int32_t* q_ = rowptr_s + (g.row0 + w02) * S;
-        ebn = q_[0];
-        een = q_[nr2 * S];
-      }
+    // id range [ebn_cur, een_cur) of the next tile: two scalar loads, consumed behind this tile's last relation-slot
+    // block (the LDS-direct load of the ids).  A wave holds TWO tiles, this one and the next: a third (its id range a
+    // tile earlier still) widens the span of rows the workgroup's waves work on at a time, and with it the L2 misses.
+    int ebn_cur = 0, een_cur = 0;
+    if (S > 0 && has_next) {
+      const int32_t* q_ = rowptr_s + (g.row0 + w0n) * S;
+      ebn_cur = q_[0];
+      een_cur = q_[nrn * S];
     }
     // fused pooling: this tile's segment-end bitmap and first partial slot (wave-uniform address:
     // scalar loads, in flight under the whole tile)
@@ -730,8 +712,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
       cur ^= 1;
       rp = rpn;
       ebase = ebn_cur;
-      sub_n1 = sub_n2;
-      sub_n2 = DESCO_NEXT_SUB();
+      sub_n1 = DESCO_NEXT_SUB();
       w0 = w0n;
       nr = nrn;
       grow0 = g.row0 + w0n;
