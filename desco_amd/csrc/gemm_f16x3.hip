@@ -218,18 +218,29 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
         ah[i] = *reinterpret_cast<const f16x8*>(ap + i * 32 * FST + co);
         al[i] = *reinterpret_cast<const f16x8*>(ap + i * 32 * FST + APLANE + co);
       }
+      f16x8 bh[WN], bl[WN];
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const short* bt = bp + j * 32 * FST + co;
-        const f16x8 bh = *reinterpret_cast<const f16x8*>(bt);
-        const f16x8 bl = *reinterpret_cast<const f16x8*>(bt + BPLANE);
-        // smallest terms first; the two row tiles alternate so dependent MFMAs are never adjacent
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl, acc[1][j], 0, 0, 0);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh, acc[1][j], 0, 0, 0);
+        bh[j] = *reinterpret_cast<const f16x8*>(bt);
+        bl[j] = *reinterpret_cast<const f16x8*>(bt + BPLANE);
+      }
+      // smallest terms first; one product of ALL 2 WN accumulators at a time: an accumulator comes round again after
+      // 2 WN MFMAs, not after two (a dependent 32x32x16 MFMA issued within its predecessor's 64 cycles waits for it)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh[j], acc[1][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl[j], acc[1][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh[j], acc[1][j], 0, 0, 0);
       }
     }
   }
