@@ -425,8 +425,8 @@ extern "C" int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, con
                                       desco_stream_t stream) {
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int k = k1 + k2;
-  if (!a1 || !dz || !dwt || !workspace || m < 0 || k1 <= 0 || k1 % TK || k2 < 0 || k2 % TK || n <= 0 ||
-      n % TN || (k2 > 0 && (!a2 || lda2 % 4 || mis16(a2))) || lda1 % 4 || lddz % 4 || mis16(a1) || mis16(dz))
+  if ((m > 0 && (!a1 || !dz)) || !dwt || !workspace || m < 0 || k1 <= 0 || k1 % TK || k2 < 0 || k2 % TK || n <= 0 ||
+      n % TN || (k2 > 0 && ((m > 0 && !a2) || lda2 % 4 || mis16(a2))) || lda1 % 4 || lddz % 4 || mis16(a1) || mis16(dz))
     return fail(DESCO_EINVAL, "desco_linear_bwd_w_f32: bad argument (k%64, n%64, 16-byte alignment)");
   const int splits = linear_bwd_w_splits(m, k, n);
   int64_t slab = (m + splits - 1) / splits;
@@ -465,8 +465,8 @@ extern "C" int desco_linear_bwd_w_multi_f32(int num, const desco_bwd_w_desc* d, 
   for (int i = 0; i < num; ++i) {
     const desco_bwd_w_desc& e = d[i];
     const int k = e.k1 + e.k2;
-    if (!e.a1 || !e.dz || !e.dwt || e.m < 0 || e.k1 <= 0 || e.k1 % TK || e.k2 < 0 || e.k2 % TK || e.n <= 0 ||
-        e.n % TN || (e.k2 > 0 && (!e.a2 || e.lda2 % 4 || mis16(e.a2))) || e.lda1 % 4 || e.lddz % 4 || mis16(e.a1) ||
+    if ((e.m > 0 && (!e.a1 || !e.dz)) || !e.dwt || e.m < 0 || e.k1 <= 0 || e.k1 % TK || e.k2 < 0 || e.k2 % TK || e.n <= 0 ||
+        e.n % TN || (e.k2 > 0 && ((e.m > 0 && !e.a2) || e.lda2 % 4 || mis16(e.a2))) || e.lda1 % 4 || e.lddz % 4 || mis16(e.a1) ||
         mis16(e.dz))
       return fail(DESCO_EINVAL, "desco_linear_bwd_w_multi_f32: bad argument (k%64, n%64, 16-byte alignment)");
     const int splits = linear_bwd_w_splits(e.m, k, e.n);

@@ -490,7 +490,8 @@ int desco_gemm_tn_f32(const float* a, int64_t lda, const float* b, int64_t ldb, 
 /* weight AND bias gradient of one Linear c = act([a1 | a2] wt + bias) in two launches (partials over M
  * slabs + one fixed-order reduce): dwt[k1+k2, n] = [a1 | a2]^T dz, dbias[n] = sum_m dz[m, n] (dbias may be
  * NULL; a2 may be NULL with k2 = 0).  k1 % 64 == k2 % 64 == n % 64 == 0.  Replaces two desco_gemm_tn_f32
- * and one desco_colsum_f32 call (six launches) of the training step.  workspace:
+ * and one desco_colsum_f32 call (six launches) of the training step.  m == 0 gives zero gradients (a1 / dz may then be
+ * NULL).  workspace:
  * desco_linear_bwd_w_workspace(m, k1 + k2, n) bytes. */
 size_t desco_linear_bwd_w_workspace(int64_t m, int k, int n);
 int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2,
@@ -499,7 +500,7 @@ int desco_linear_bwd_w_f32(const float* a1, int64_t lda1, int k1, const float* a
 
 /* Up to 16 independent problems of desco_linear_bwd_w_f32's form (contiguous dwt: lddw = n) in one partial launch and
  * one reduce launch: the (layer, row type) weight gradients of a training step's trunk, which nothing but the optimizer
- * waits for.  m == 0 gives zero gradients.  workspace: desco_linear_bwd_w_multi_workspace(num, descs) bytes. */
+ * waits for.  m == 0 gives zero gradients (a1 / dz may then be NULL).  workspace: desco_linear_bwd_w_multi_workspace(num, descs) bytes. */
 typedef struct desco_bwd_w_desc {
   const float* a1; int64_t lda1; int k1;
   const float* a2; int64_t lda2; int k2;

@@ -681,3 +681,62 @@ def test_small_trunk_refuses_large_batches():
                                           zi.data_ptr(), 1, z.data_ptr(), z.data_ptr(), 128, None)
     assert rc == -1 and b"desco_shmp_trunk_small_fwd_f32" in L.desco_last_error()
 
+
+# ---- round-4 training entry points, each against plain torch fp64 ---------------------------------------------------------
+def test_gemm_multi_with_gate_and_accumulate():
+    """desco_gemm_f32_multi: independent products in one launch; gate = multiply by act'(saved output) (the act_grad pass
+    fused into the epilogue), accum = add into the existing output; an empty problem is skipped."""
+    g = torch.Generator().manual_seed(7)
+    a0, w0, b0 = torch.randn(1000, 192, generator=g), torch.randn(192, 64, generator=g) / 8, torch.randn(64, generator=g)
+    a1, w1 = torch.randn(77, 64, generator=g), torch.randn(64, 256, generator=g) / 8
+    a2, w2 = torch.randn(300, 256, generator=g), torch.randn(256, 64, generator=g) / 8
+    gate_r = torch.randn(77, 256, generator=g)                   # "saved relu output": its sign is what matters
+    gate_l = torch.randn(300, 64, generator=g)
+    prev = torch.randn(300, 64, generator=g)
+    o0 = torch.empty(1000, 64, device=DEV)
+    o1 = torch.empty(77, 256, device=DEV)
+    o2 = prev.clone().to(DEV)
+    oe = torch.empty(0, 64, device=DEV)
+    ops.gemm_multi([dict(a1=a0.to(DEV)[:, :128], a2=a0.to(DEV)[:, 128:], wt=w0.to(DEV), bias=b0.to(DEV), act=ops.ACT_RELU, out=o0),
+                    dict(a1=a1.to(DEV), wt=w1.to(DEV), out=o1, gate=gate_r.to(DEV), gate_act=ops.ACT_RELU),
+                    dict(a1=a2.to(DEV), wt=w2.to(DEV), out=o2, gate=gate_l.to(DEV), gate_act=ops.ACT_LEAKY, gate_slope=0.1,
+                         accum=True),
+                    dict(a1=torch.empty(0, 64, device=DEV), wt=w1.to(DEV)[:, :64].contiguous(), out=oe)])
+    _close(o0, torch.relu(a0.double() @ w0.double() + b0.double()), atol=1e-4)
+    _close(o1, (a1.double() @ w1.double()) * (gate_r.double() > 0), atol=1e-4)
+    _close(o2, prev.double() + (a2.double() @ w2.double()) * torch.where(gate_l.double() > 0, 1.0, 0.1), atol=1e-4)
+
+
+def test_linear_bwd_w_multi_matches_the_single_problem_form():
+    g = torch.Generator().manual_seed(8)
+    probs, refs = [], []
+    for m, k1, k2 in ((5000, 128, 64), (0, 64, 64), (40, 64, 0), (700, 256, 64)):
+        a1 = torch.randn(m, k1, generator=g)
+        a2 = torch.randn(m, k2, generator=g) if k2 else None
+        dz = torch.randn(m, 64, generator=g)
+        A = a1 if a2 is None else torch.cat([a1, a2], 1)
+        refs.append((A.double().T @ dz.double(), dz.double().sum(0)))
+        probs.append(dict(a1=a1.to(DEV) if m else torch.empty(0, k1, device=DEV), a2=None if a2 is None else a2.to(DEV),
+                          dz=dz.to(DEV), dwt=torch.empty(k1 + k2, 64, device=DEV), dbias=torch.empty(64, device=DEV)))
+    ops.linear_bwd_w_multi(probs)
+    for pr, (rw, rb) in zip(probs, refs):
+        _close(pr["dwt"], rw, rtol=1e-4, atol=2e-3)
+        _close(pr["dbias"], rb, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("rows", [1, 1000, 300001])
+def test_rowdot_bwd_and_smallk_bwd(rows):
+    g = torch.Generator().manual_seed(rows)
+    y = torch.relu(torch.randn(rows, 256, generator=g))
+    w = torch.randn(256, generator=g)
+    d = torch.randn(rows, generator=g)
+    dz, dwb = ops.rowdot_bwd(y.to(DEV), w.to(DEV), d.to(DEV))
+    _close(dz, d.double()[:, None] * w.double()[None, :] * (y.double() > 0), atol=1e-5)
+    _close(dwb[:256], (y.double() * d.double()[:, None]).sum(0), rtol=1e-4, atol=1e-2)
+    _close(dwb[256:], d.double().sum().reshape(1), rtol=1e-4, atol=1e-2)
+    feat = torch.randn(rows, 2, generator=g)
+    dout = torch.randn(rows + 3, 64, generator=g)[3:]                     # a row-offset view
+    dwt, db = ops.linear_smallk_bwd(feat.to(DEV), dout.to(DEV))
+    _close(dwt, feat.double().T @ dout.double(), rtol=1e-4, atol=1e-2)
+    _close(db, dout.double().sum(0), rtol=1e-4, atol=1e-2)
+
