@@ -462,8 +462,10 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
 #endif
           for (int e = lo; e < hi; ++e) {
             const float4 sj = escal[e];
-            float hx = sj.x * pc.x + sj.y * rc.x + sj.w * tc.x + zc.x;
-            float hy = sj.x * pc.y + sj.y * rc.y + sj.w * tc.y + zc.y;
+            // (three dependent FMAs, z first: also keeps hipcc from selecting a packed multiply that takes the record's
+            //  odd dword through OP_SEL on src1 -- rule PK-OPSEL of tools/check_isa.py)
+            float hx = __builtin_fmaf(sj.x, pc.x, __builtin_fmaf(sj.y, rc.x, __builtin_fmaf(sj.w, tc.x, zc.x)));
+            float hy = __builtin_fmaf(sj.x, pc.y, __builtin_fmaf(sj.y, rc.y, __builtin_fmaf(sj.w, tc.y, zc.y)));
             hx = hx > 0.f ? hx : 0.f;
             hy = hy > 0.f ? hy : 0.f;
             const float gt = ecol[e] < node ? gq : 1.f - gq;
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
       for (int i = 0; i < 8; ++i) {
         const int row = tperm[wave * 16 + 2 * i + half1];
         const float4 si = srow[row];
-        float hx = si.x * pc.x + si.y * rc.x + si.w * tc.x + zc.x;
-        float hy = si.x * pc.y + si.y * rc.y + si.w * tc.y + zc.y;
+        float hx = __builtin_fmaf(si.x, pc.x, __builtin_fmaf(si.y, rc.x, __builtin_fmaf(si.w, tc.x, zc.x)));
+        float hy = __builtin_fmaf(si.x, pc.y, __builtin_fmaf(si.y, rc.y, __builtin_fmaf(si.w, tc.y, zc.y)));
         hx = hx > 0.f ? hx : 0.f;
         hy = hy > 0.f ? hy : 0.f;
         uint32_t h_, m_, l_;

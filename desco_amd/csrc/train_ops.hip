@@ -595,7 +595,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
       const float4 q = *reinterpret_cast<const float4*>(red + 4 * (g * tpr + threadIdx.x));
       t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
     }
-    *reinterpret_cast<float4*>(out + 4 * threadIdx.x) = t;
+    float* o4 = out + 4 * threadIdx.x;       // (rows of n + 1 floats: only 4-byte aligned)
+    o4[0] = t.x; o4[1] = t.y; o4[2] = t.z; o4[3] = t.w;
   }
   if (threadIdx.x == 0) {
     float t = 0.f;
@@ -608,9 +609,9 @@ extern "C" int desco_rowdot_bwd_f32(const float* y, int64_t ldy, int n, const fl
                                     int64_t num_rows, float* dz, int64_t lddz, float* dwb, float* workspace,
                                     desco_stream_t stream) {
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
-  if (!y || !w || !dout || !dz || !dwb || !workspace || num_rows < 0 || n < 4 || n > 1024 || n % 4 || 256 % (n / 4) ||
+  if (!y || !w || !dout || !dz || !dwb || !workspace || num_rows < 0 || n < 16 || n > 1024 || n % 16 || 256 % (n / 4) ||
       ldy % 4 || lddz % 4 || mis16(y) || mis16(w) || mis16(dz) || mis16(workspace))
-    return fail(DESCO_EINVAL, "desco_rowdot_bwd_f32: bad argument (n = 4 * a divisor of 256, 16-byte alignment)");
+    return fail(DESCO_EINVAL, "desco_rowdot_bwd_f32: bad argument (n = 16, 32, 64, ..., 1024: at most 64 row groups per pass; 16-byte alignment)");
   int64_t splits = (num_rows + 255) / 256;
   if (splits > 1024) splits = 1024;
   if (splits < 1) splits = 1;

@@ -2,7 +2,6 @@
 (subgraph_counting/data.py:37-58, 329-396; workload.py:1128-1671 graph_atlas_plus)."""
 from __future__ import annotations
 
-from collections import defaultdict
 from typing import List
 
 import networkx as nx
@@ -16,20 +15,22 @@ STANDARD_QUERY_IDS = [6, 7, 13, 14, 15, 16, 17, 18, 29, 30, 31, 34, 35, 36, 37, 
                       44, 45, 46, 47, 48, 49, 50, 51, 52]
 
 
+# first and one-past-last atlas id of the graphs with 3..6 nodes (the atlas is ordered by node count)
+_ATLAS_SPAN = {3: (4, 8), 4: (8, 19), 5: (19, 53), 6: (53, 209)}
+
+
 def gen_query_ids(query_size: List[int]) -> List[int]:
-    """Connected graph-atlas ids whose size is in ``query_size`` (data.py:37-58)."""
-    query_ids = defaultdict(list)
-    for i in range(6, 209):
-        g = nx.graph_atlas(i)
-        if nx.is_connected(g):
-            query_ids[len(g)].append(i)
-        if len(g) > max(query_size):
-            break
-    out = []
-    for size, ids in query_ids.items():
-        if size in query_size:
-            out.extend(ids)
-    return out
+    """The connected graph-atlas patterns of the requested sizes, by ascending size then id -- the contract of
+    data.py:37-58 (which scans ids 6..208, so sizes 3..6 exist and nothing else does; ``gen_query_ids([3, 4, 5])`` is
+    STANDARD_QUERY_IDS, pinned by tests/golden/queries.json)."""
+    ids: List[int] = []
+    for size in sorted(set(int(s) for s in query_size)):
+        lo, hi = _ATLAS_SPAN.get(size, (0, 0))
+        if size <= 5:
+            ids += [i for i in STANDARD_QUERY_IDS if lo <= i < hi]
+        else:
+            ids += [i for i in range(lo, hi) if nx.is_connected(nx.graph_atlas(i))]
+    return ids
 
 
 def graph_atlas_plus(atlas_id: int) -> nx.Graph:

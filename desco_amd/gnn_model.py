@@ -828,9 +828,10 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     g0 = c0._gate_value(E).reshape(-1)
     g1 = c1._gate_value(E).reshape(-1)
     # ---- constants per (node, query): deg_lo, deg_hi, s_lo, s_hi, x (functions of the batch alone: cached on it) ----
-    ck = (x.data_ptr(), x._version)
+    # (keyed on the tensor object -- kept alive by the cache, so its address cannot be reused -- and its version;
+    #  the library's in-place writers of x bump the version: ops.scatter_rows)
     cc = batch.__dict__.get("_train_consts")
-    if cc is None or cc[0] != ck:
+    if cc is None or cc[0][0] is not x or cc[0][1] != x._version:
         with torch.no_grad():
             ones, zeros = torch.ones(Q, device=dev), torch.zeros(Q, device=dev)
             sa = ops.gossip_scalars(x, batch.rowptr, batch.col, ones, zeros)    # (deg_lo, s_lo, deg_hi, x)
@@ -841,7 +842,7 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
             C6 = torch.stack([deg_hi, deg_lo - deg_hi, s_hi, s_lo - s_hi, xr, one], 1).contiguous()
             C3 = torch.stack([deg_hi, deg_lo - deg_hi, one], 1).contiguous()
             C2 = torch.stack([xr, one], 1).contiguous()
-        cc = batch.__dict__["_train_consts"] = (ck, C6, C3, C2)
+        cc = batch.__dict__["_train_consts"] = ((x, x._version), C6, C3, C2)
     _, C6, C3, C2 = cc
     # ---- operands folded from the parameters (tiny differentiable torch ops: DESIGN.md 4.2) ---------------------------
     a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + cb0)

@@ -221,11 +221,12 @@ class NeighborhoodCountingModel(_LightningLike):
         if GM.GEMM_BF16X6:
             T = ops.linear64(emb_t, hp["w_t_l64"])                         # target half
             # query half + bias: a function of (head weights, query embeddings) only -- cached with them at inference
-            qkey = (emb_q.data_ptr(), emb_q._version)
-            if torch.is_grad_enabled() or hp.get("qh_key") != qkey:
+            # (keyed on the tensor OBJECT, which the cache keeps alive: an address could be handed to the next query
+            #  set's embeddings by the caching allocator)
+            if torch.is_grad_enabled() or hp.get("qh_src") is not emb_q or hp.get("qh_ver") != emb_q._version:
                 Qh = ops.gemm_split(emb_q, hp["w_q_nk"], hp["b1"])
                 if not torch.is_grad_enabled():
-                    hp["qh_key"], hp["qh"] = qkey, Qh
+                    hp["qh_src"], hp["qh_ver"], hp["qh"] = emb_q, emb_q._version, Qh
             else:
                 Qh = hp["qh"]
         else:

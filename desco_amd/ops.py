@@ -693,6 +693,7 @@ def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor) -> to
         _lib.check(L.desco_scatter_rows_f32(sp, lds, _dev(rows, "rows", torch.int32),
                                             src.shape[0], src.shape[1], dp, ldd, _stream()),
                    "scatter_rows")
+    torch.autograd.graph.increment_version(dst)      # written through its raw pointer: caches keyed on the version see it
     return dst
 
 

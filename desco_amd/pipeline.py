@@ -244,7 +244,9 @@ class InferencePipeline:
                 b.out_buf = bufs["neigh"][r:r + b.num_graphs] if Q <= 32 else None
                 r += b.num_graphs
         counts = [nm.graph_to_count(b) for b in self.neigh_batches]            # main.py:296-301
-        if all(getattr(b, "out_buf", None) is not None for b in self.neigh_batches):
+        # (the persistent buffer is the result only if every block's launch really wrote its slice of it)
+        if counts and all(getattr(b, "out_buf", None) is not None and c.data_ptr() == b.out_buf.data_ptr()
+                          for b, c in zip(self.neigh_batches, counts)):
             neigh_count = bufs["neigh"]
         elif not counts:      # no node has a non-empty canonical neighborhood
             neigh_count = torch.zeros((0, Q), device=self.device)
@@ -265,7 +267,8 @@ class InferencePipeline:
             gb.x = x[n0:n1]
             gb.out_buf = bufs["node"][n0:n1] if Q <= 64 else None
             node.append(gm.graph_to_count(gb))                                # main.py:417-420
-        if Q <= 64 and GMOD.FUSED_GOSSIP and GMOD.GOSSIP_F16X3:
+        if node and all(gb.out_buf is not None and c.data_ptr() == gb.out_buf.data_ptr()
+                        for (_, _, gb), c in zip(self.gossip_batches, node)):
             node_count = bufs["node"]
         else:
             node_count = node[0] if len(node) == 1 else torch.cat(node)

@@ -6,11 +6,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from desco_amd import ops  # noqa: E402
+from helpers import assert_counts_close, assert_logits_close  # noqa: E402
 
 DEV = "cuda"
 
 
 def _close(got, ref, rtol=2e-5, atol=2e-5):
+    """One kernel against the fp64 evaluation of the same operation (NOT a model-level gate: those all go through
+    helpers.assert_logits_close / assert_counts_close).  Defaults 2e-5; a call that passes its own atol states the
+    accumulation it covers (split-K sums over m rows, gradients over a batch)."""
     torch.testing.assert_close(got.detach().cpu().double(), ref.double(), rtol=rtol, atol=atol)
 
 
@@ -121,7 +125,7 @@ def test_count_head(B, Q, hid, slope):
     assert got.shape == (B, Q)
     _close(got[idx.to(DEV)], ref)
     got2 = ops.count_head(t.to(DEV), qh.to(DEV), w2.to(DEV), torch.tensor(b2, device=DEV), slope, True)
-    _close(got2[idx.to(DEV)], 2 ** ref - 1, rtol=1e-4, atol=1e-4)
+    assert_counts_close("count head, exp2 - 1 form", got2[idx.to(DEV)], 2 ** ref - 1)
 
 
 def test_scatter_rows_and_linear_smallk_and_rowdot():
@@ -221,7 +225,7 @@ def test_fused_shmp_layer(S, sm, st, num_rows, row0, max_deg, x6):
              ops.split_bf16_planes(wt.t().contiguous().to(DEV)) if x6 else wt.to(DEV))
     ops.shmp_layer(x.to(DEV), ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm, w_dev,
                    bias.to(DEV), out, ytab=ytab, ytab_row0=0)
-    _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
+    assert_logits_close("fused SHMP layer vs fp64", out[row0:row0 + num_rows], ref)
     rest = torch.cat([out[:row0], out[row0 + num_rows:]])
     assert (rest == -7.0).all()          # rows outside the range are untouched
 
@@ -257,7 +261,7 @@ def test_fused_shmp_layer_strided_operands(S, sm, st, f16):
     split = ops.split_f16_planes if f16 else ops.split_bf16_planes
     ops.shmp_layer(xw.to(DEV)[:, 16:80], ptr.to(DEV), col.to(DEV), row0, num_rows, S, sm,
                    split(wt.t().contiguous().to(DEV)), bias.to(DEV), out, ytab=ytab, ytab_row0=0)
-    _close(out[row0:row0 + num_rows], ref, rtol=1e-4, atol=2e-4)
+    assert_logits_close("fused SHMP layer vs fp64", out[row0:row0 + num_rows], ref)
     assert (outw[:, :32] == -7.0).all() and (outw[:, 96:] == -7.0).all() and (outw[:row0] == -7.0).all()
 
 

@@ -91,3 +91,49 @@ def test_large_graphs_multiword_bitmaps_and_host_fallback():
     pipe = InferencePipeline(nm, gm, big, depth=2, device="cuda")
     assert pipe.partition_backend == "host"
     assert torch.isfinite(pipe.run()["graph_gossip_count"]).all()
+
+
+def test_device_builder_against_reference_golden(partition_golden):
+    """The HIP builder DIRECTLY against tests/golden/partition_golden.json (written from the reference's own
+    get_neigh_hetero by tests/golden/make_golden.py) -- not through the host builder: nx_neighs_indicator,
+    nx_neighs_index, the node set of every neighborhood, its induced edge set (the union of the six typed edge sets,
+    mapped back to graph ids, each undirected edge present in both directions), and the triangle / non-triangle type
+    of every edge against the definition (ToTconvHetero: the endpoints share a neighbour inside the neighborhood)."""
+    graphs = [(g["n"], [tuple(e) for e in g["edges"]]) for g in partition_golden["graphs"]]
+    part = build_partition_device(GraphSet.from_edge_lists(graphs), partition_golden["depth"])
+    ind, idx = [], []
+    for gid, g in enumerate(partition_golden["graphs"]):
+        ind += g["indicator"]
+        idx += [[gid, v] for v in g["index_nodes"]]
+    assert part.indicator.astype(bool).tolist() == ind
+    assert part.neigh_index.tolist() == idx
+    gs_ptr = np.concatenate([[0], np.cumsum([g["n"] for g in partition_golden["graphs"]])])
+    Nc = part.num_count
+    # local row (count rows first, then one canonical row per neighborhood) -> (neighborhood, graph-local node id)
+    owner = np.concatenate([np.repeat(np.arange(part.num_neigh), np.diff(part.count_ptr)), np.arange(part.num_neigh)])
+    gid_of = part.neigh_index[:, 0]
+    orig = np.concatenate([part.count_orig - gs_ptr[gid_of[owner[:Nc]]], part.neigh_index[:, 1]])
+    got_edges = [dict() for _ in range(part.num_neigh)]          # neighborhood -> {(a, b): is_triangle}
+    for (s, rel, d), ei in part.edge_index_dict().items():
+        src = ei[0] + (Nc if s == "canonical" else 0)
+        dst = ei[1] + (Nc if d == "canonical" else 0)
+        assert (owner[src] == owner[dst]).all(), (s, rel, d)
+        for b, a_, b_ in zip(owner[src].tolist(), orig[src].tolist(), orig[dst].tolist()):
+            assert (a_, b_) not in got_edges[b]
+            got_edges[b][(a_, b_)] = rel == "union_triangle"
+    b = 0
+    for gid, g in enumerate(partition_golden["graphs"]):
+        for ref in g["neighs"]:
+            c0, c1 = part.count_ptr[b], part.count_ptr[b + 1]
+            assert (part.count_orig[c0:c1] - gs_ptr[gid]).tolist() + [ref["canonical"]] == ref["nodes"]
+            adj = {v: set() for v in ref["nodes"]}
+            for u, v in ref["edges"]:
+                adj[u].add(v)
+                adj[v].add(u)
+            want = {}
+            for u, v in ref["edges"]:
+                tri = bool(adj[u] & adj[v])
+                want[(u, v)] = want[(v, u)] = tri
+            assert got_edges[b] == want, (gid, ref["canonical"])
+            b += 1
+    assert b == part.num_neigh
