@@ -29,8 +29,12 @@
 //     barriers per item): 1.53 ms per 3.95 M (node, query) rows against 0.98 for this form on the same box.
 //   * Everything a query needs from memory (its records, p_q / z_q / zp_q, the first four neighbour records of every
 //     node) is requested one query ahead, in front of the previous query's GEMM chain.
-//   * No packed fp32 VALU instructions (DESCO_NO_PACKED_F32, common_device.hpp): beside other waves' MFMAs they
-//     returned wrong values.
+//   * Round 5: the weight fragments travel through a ring of four register sets, three (tile, k step) ahead of the
+//     MFMAs that use them, across block boundaries, epilogues and queries (the 72 steps of a query repeat for the next
+//     one): round 4's block issued each fragment read one step ahead and waited out the LDS latency in front of every
+//     MFMA triple.  Packed fp32 selection is back on and the end-of-block accumulator drain is gone: the wrong-result
+//     mode of round 4 was one operand selection of the packed instructions (OP_SEL on src1/src2), which this source
+//     does not produce and tools/check_isa.py refuses in the linked library (profiles/r5_a_gossip_f16_hazard.md).
 #include "common_device.hpp"
 
 namespace desco {
@@ -96,22 +100,24 @@ struct Frag {
 __device__ __forceinline__ void make_frag(const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3, const float s,
                                           Frag& f) {
   uint32_t h[8], l[8];
-  split2_f16x2(v0[0] * s, v0[1] * s, h[0], l[0]);
-  split2_f16x2(v0[2] * s, v0[3] * s, h[1], l[1]);
-  split2_f16x2(v1[0] * s, v1[1] * s, h[2], l[2]);
-  split2_f16x2(v1[2] * s, v1[3] * s, h[3], l[3]);
-  split2_f16x2(v2[0] * s, v2[1] * s, h[4], l[4]);
-  split2_f16x2(v2[2] * s, v2[3] * s, h[5], l[5]);
-  split2_f16x2(v3[0] * s, v3[1] * s, h[6], l[6]);
-  split2_f16x2(v3[2] * s, v3[3] * s, h[7], l[7]);
+  const f32x4 w0 = v0 * s, w1 = v1 * s, w2 = v2 * s, w3 = v3 * s;
+  split2_f16x2(w0[0], w0[1], h[0], l[0]);
+  split2_f16x2(w0[2], w0[3], h[1], l[1]);
+  split2_f16x2(w1[0], w1[1], h[2], l[2]);
+  split2_f16x2(w1[2], w1[3], h[3], l[3]);
+  split2_f16x2(w2[0], w2[1], h[4], l[4]);
+  split2_f16x2(w2[2], w2[3], h[5], l[5]);
+  split2_f16x2(w3[0], w3[1], h[6], l[6]);
+  split2_f16x2(w3[2], w3[3], h[7], l[7]);
   f.h0 = __builtin_bit_cast(f16x8, u32x4{h[0], h[1], h[2], h[3]});
   f.l0 = __builtin_bit_cast(f16x8, u32x4{l[0], l[1], l[2], l[3]});
   f.h1 = __builtin_bit_cast(f16x8, u32x4{h[4], h[5], h[6], h[7]});
   f.l1 = __builtin_bit_cast(f16x8, u32x4{l[4], l[5], l[6], l[7]});
 }
+// a * b + c on four features, one rounding each (explicit: the contraction of `a * b + c` differs between hipcc's
+// scalar and packed selections, and the packed forms must not depend on the SLP vectoriser finding them)
 __device__ __forceinline__ f32x4 fma4(const float a, const f32x4 b, const f32x4 c) {
-  return f32x4{__builtin_fmaf(a, b[0], c[0]), __builtin_fmaf(a, b[1], c[1]), __builtin_fmaf(a, b[2], c[2]),
-               __builtin_fmaf(a, b[3], c[3])};
+  return __builtin_elementwise_fma(f32x4{a, a, a, a}, b, c);
 }
 __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d) {
   const float m0 = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
@@ -124,50 +130,46 @@ __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f3
 #define GF16_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0);
 // the three products (smallest first) of weight fragment (wh_, wl_) with activation fragment (xh_, xl_)
 #define GF16_MM(c_, wh_, wl_, xh_, xl_) GF16_MFMA(wl_, xh_, c_) GF16_MFMA(wh_, xl_, c_) GF16_MFMA(wh_, xh_, c_)
-// weight fragments of (feature tile i_, k step t_) from ring buffer wb_ into (h_, l_)
-#define GF16_LDW(h_, l_, wb_, i_, t_)                                                        \
-  {                                                                                          \
-    const short* a_ = (wb_) + (i_) * 16 * 64 + (((4 * (t_) + q4) ^ wswz) << 3);              \
-    h_ = *reinterpret_cast<const f16x8*>(a_);                                                \
-    l_ = *reinterpret_cast<const f16x8*>(a_ + WPL);                                          \
+// Weight fragment ring.  A query's 9 blocks are 36 PAIR STEPS: pair step d = (block d / 4, tile pair (d % 4) / 2, k step
+// d % 2) multiplies the k-step fragments of feature tiles 2 p and 2 p + 1 into their two accumulators -- six MFMAs, the
+// two dependent chains interleaved.  The hi / lo fragments of pair step d (four ds_read_b128, 16 registers) live in ring
+// slot d % 3 and are requested in front of the MFMAs of pair step d - 2: two pair steps = twelve MFMAs = 192 matrix-pipe
+// cycles of this wave ahead, the SIMD's other wave on top -- more than the LDS round trip under the eight waves' read
+// traffic.  The stream is the same for every query and node, so the ring runs on across block
+// boundaries, epilogues, queries and work units (round 4 requested each fragment one step ahead and waited out the LDS
+// latency in front of every MFMA triple: hipcc sinks a plain C++ LDS read to just above its use).
+// The reads and the waits are inline asm so that their ISSUE POINTS are fixed: volatile asm statements keep their program
+// order (also against the compiler's own LDS accesses), the fragments are outputs of the read and in/outputs of the wait,
+// so the MFMAs that use them come after it.  The counted wait is safe whatever else the compiler puts in between: LDS
+// operations of a wave return in order, a fragment read is complete once at most as many LGKM operations are outstanding
+// as were issued after it, and lgkmcnt(4) -- the four reads of the one younger pair step -- is at most that number.
+struct WFrag { f16x8 h0, l0, h1, l1; };          // tiles 2 p (0) and 2 p + 1 (1)
+#define GF16_RD_(dst_, base_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(base_), "n"(off_));
+#define GF16_REQ(d_)                                                                                    \
+  {                                                                                                     \
+    constexpr int dd_ = (d_) % 36, byte_ = (dd_ / 4) * (WBLK * 2) + ((dd_ % 4) / 2) * (2 * 16 * 64 * 2); \
+    const uint32_t b_ = (dd_ % 2 ? wa1 : wa0) + (uint32_t)(byte_ & ~0xffff);                            \
+    GF16_RD_(WF[(d_) % 3].h0, b_, byte_ & 0xffff)                                                       \
+    GF16_RD_(WF[(d_) % 3].l0, b_, (byte_ & 0xffff) + WPL * 2)                                           \
+    GF16_RD_(WF[(d_) % 3].h1, b_, (byte_ & 0xffff) + 16 * 64 * 2)                                       \
+    GF16_RD_(WF[(d_) % 3].l1, b_, (byte_ & 0xffff) + 16 * 64 * 2 + WPL * 2)                             \
   }
-// 24 MFMAs of one 64x64 weight block on this wave's 16 nodes: acc_i += W[16 i .. +15][:] X^T.  The fragments of the
-// next (tile, k step) are read while the MFMAs of the current one run.
-#define GF16_BLOCK(wb_, X_)                                                                  \
-  {                                                                                          \
-    const short* w_ = (wb_) + wrow * 64;                                                     \
-    f16x8 ah_, al_, bh_, bl_;                                                                \
-    GF16_LDW(ah_, al_, w_, 0, 0)                                                             \
-    GF16_LDW(bh_, bl_, w_, 0, 1)                                                             \
-    GF16_MM(acc0, ah_, al_, X_.h0, X_.l0)                                                    \
-    GF16_LDW(ah_, al_, w_, 1, 0)                                                             \
-    GF16_MM(acc0, bh_, bl_, X_.h1, X_.l1)                                                    \
-    GF16_LDW(bh_, bl_, w_, 1, 1)                                                             \
-    GF16_MM(acc1, ah_, al_, X_.h0, X_.l0)                                                    \
-    GF16_LDW(ah_, al_, w_, 2, 0)                                                             \
-    GF16_MM(acc1, bh_, bl_, X_.h1, X_.l1)                                                    \
-    GF16_LDW(bh_, bl_, w_, 2, 1)                                                             \
-    GF16_MM(acc2, ah_, al_, X_.h0, X_.l0)                                                    \
-    GF16_LDW(ah_, al_, w_, 3, 0)                                                             \
-    GF16_MM(acc2, bh_, bl_, X_.h1, X_.l1)                                                    \
-    GF16_LDW(bh_, bl_, w_, 3, 1)                                                             \
-    GF16_MM(acc3, ah_, al_, X_.h0, X_.l0)                                                    \
-    GF16_MM(acc3, bh_, bl_, X_.h1, X_.l1)                                                    \
-    GF16_DRAIN()                                                                             \
+#define GF16_WAIT(d_)                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(WF[(d_) % 3].h0), "+v"(WF[(d_) % 3].l0), "+v"(WF[(d_) % 3].h1), \
+               "+v"(WF[(d_) % 3].l1));
+// pair step d_: (accA_, accB_) += W[tiles 2p, 2p+1][k step] X^T, three products each, smallest first, chains interleaved
+#define GF16_PAIR(d_, accA_, accB_, xh_, xl_)                                                           \
+  {                                                                                                     \
+    GF16_WAIT(d_)                                                                                       \
+    GF16_REQ((d_) + 2)                                                                                  \
+    GF16_MFMA(WF[(d_) % 3].l0, xh_, accA_) GF16_MFMA(WF[(d_) % 3].l1, xh_, accB_)                       \
+    GF16_MFMA(WF[(d_) % 3].h0, xl_, accA_) GF16_MFMA(WF[(d_) % 3].h1, xl_, accB_)                       \
+    GF16_MFMA(WF[(d_) % 3].h0, xh_, accA_) GF16_MFMA(WF[(d_) % 3].h1, xh_, accB_)                       \
   }
-// End of a block: one VALU read of every accumulator chain's last result, fenced for the scheduler, BEFORE any later load
-// is issued.  An MFMA is issued in order but retires later (dependent chains of three queue up behind each other and
-// behind the SIMD's other wave), and the register allocator is free to hand a chain's dying intermediate register -- or
-// one the chain still has to write -- to the next LDS load (it did: the h1 fragments of block 1 landed in a register
-// that block 0's last MFMAs had not written yet; the load returned first, the MFMA result then overwrote it.  Found
-// as a run-to-run difference on a handful of nodes, tools/debug/gf16_variants.sh).  A VALU read of an MFMA result
-// is interlocked, a returning load is not.
-#define GF16_DRAIN()                                                                         \
-  {                                                                                          \
-    const float t_ = (acc0[3] + acc1[3]) + (acc2[3] + acc3[3]);                              \
-    asm volatile("" :: "v"(t_));                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-  }
+// the 24 MFMAs of weight block b_ on this wave's 16 nodes: acc_i += W[16 i .. +15][:] X^T
+#define GF16_BLOCK(b_, X_)                                                                              \
+  GF16_PAIR(4 * (b_) + 0, acc0, acc1, X_.h0, X_.l0) GF16_PAIR(4 * (b_) + 1, acc0, acc1, X_.h1, X_.l1)   \
+  GF16_PAIR(4 * (b_) + 2, acc2, acc3, X_.h0, X_.l0) GF16_PAIR(4 * (b_) + 3, acc2, acc3, X_.h1, X_.l1)
 #define GF16_ZERO() { acc0 = acc1 = acc2 = acc3 = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define GF16_SCALE(f_) { acc0 *= (f_); acc1 *= (f_); acc2 *= (f_); acc3 *= (f_); }
 
@@ -177,7 +179,7 @@ constexpr int WCST = 896;                   // u, d1, tp, b3 (64 each), b5, w7 (
 constexpr size_t LDS_WAVE = (size_t)9 * WBLK * 2 + (size_t)WCST * 4 + (size_t)8 * (WCOLS * 16 + 64) * 4;
 static_assert(LDS_WAVE <= 160 * 1024, "gossip_f16: LDS budget exceeded");
 
-__global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kernel(Args g, int64_t num_groups) {
+__global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t num_groups) {
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
   short* WB = reinterpret_cast<short*>(gf_lds);                       // nine resident weight blocks
   float* cst = reinterpret_cast<float*>(WB + 9 * WBLK);
@@ -207,6 +209,11 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
   }
   const float winv1 = g.winv[0], winvp = g.winv[1], winv3 = g.winv[2], winv5 = g.winv[3];
   __syncthreads();                                     // the only barrier: weights and constants are in place
+  // LDS byte addresses of this lane's fragment chunk of k step 0 / 1 in weight block 0, tile 0, hi plane
+  const uint32_t wa0 = (uint32_t)(uintptr_t)(WB + wrow * 64 + (((0 + q4) ^ wswz) << 3));
+  const uint32_t wa1 = (uint32_t)(uintptr_t)(WB + wrow * 64 + (((4 + q4) ^ wswz) << 3));
+  WFrag WF[3];
+  GF16_REQ(0) GF16_REQ(1)                              // the ring's head start: pair steps 0 and 1 of the first query
 
   const int QC = (Q + WQ - 1) / WQ;
   const int64_t nunits = num_groups * QC;
@@ -296,10 +303,11 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
 #define GW_H1(s_, c_) __builtin_elementwise_max(fma4((s_).x, p##c_, fma4((s_).y, r##c_, fma4((s_).w, t##c_, z##c_))), zero4)
 #define GW_ADD(rec_, gt_)                                                                      \
   {                                                                                            \
-    h0 += (gt_) * GW_H1(rec_, 0);                                                              \
-    h1 += (gt_) * GW_H1(rec_, 1);                                                              \
-    h2 += (gt_) * GW_H1(rec_, 2);                                                              \
-    h3 += (gt_) * GW_H1(rec_, 3);                                                              \
+    const float g_ = (gt_);                                                                    \
+    h0 = fma4(g_, GW_H1(rec_, 0), h0);                                                         \
+    h1 = fma4(g_, GW_H1(rec_, 1), h1);                                                         \
+    h2 = fma4(g_, GW_H1(rec_, 2), h2);                                                         \
+    h3 = fma4(g_, GW_H1(rec_, 3), h3);                                                         \
   }
 #define GW_GATE(i_) ((i_) < deg ? (((lt >> (i_)) & 1u) ? gq : 1.f - gq) : 0.f)
         if (maxdeg > 0) GW_ADD(c0, GW_GATE(0))
@@ -338,13 +346,13 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
       float s_c;
       // ---- blocks 0, 1: h2 = relu([hh|h1] W1 + a1*u + d1) ------------------------------------------------------------
       GF16_ZERO()
-      GF16_BLOCK(WB + 0 * WBLK, XH)
-      GF16_BLOCK(WB + 1 * WBLK, X1)
+      GF16_BLOCK(0, XH)
+      GF16_BLOCK(1, X1)
       {
         const float f = pow2_inverse(s_a) * winv1;
         const float* u_ = cst + fq;
         const float* d_ = cst + 64 + fq;
-#define GW_EPI1(a_, i_) a_ = __builtin_elementwise_max(a_ * f + (GW_V4(u_ + 16 * (i_)) * si.z + GW_V4(d_ + 16 * (i_))), f32x4{0.f, 0.f, 0.f, 0.f});
+#define GW_EPI1(a_, i_) a_ = __builtin_elementwise_max(fma4(f, a_, fma4(si.z, GW_V4(u_ + 16 * (i_)), GW_V4(d_ + 16 * (i_)))), f32x4{0.f, 0.f, 0.f, 0.f});
         GW_EPI1(acc0, 0) GW_EPI1(acc1, 1) GW_EPI1(acc2, 2) GW_EPI1(acc3, 3)
 #undef GW_EPI1
         s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
@@ -352,19 +360,19 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
       }
       // ---- blocks 2, 3: y1 = leaky([h1|h2] Wp + x*tp + zp_q, 0.1) ------------------------------------------------------
       GF16_ZERO()
-      GF16_BLOCK(WB + 2 * WBLK, X1)
+      GF16_BLOCK(2, X1)
       {
         const float rs = s_c * pow2_inverse(s_a);
         GF16_SCALE(rs)
       }
-      GF16_BLOCK(WB + 3 * WBLK, XC)
+      GF16_BLOCK(3, XC)
       {
         const float f = pow2_inverse(s_c) * winvp;
         const float* t_ = cst + 128 + fq;
         const float* z_ = zpw + fq;
 #define GW_EPI2(a_, i_)                                                                                       \
   {                                                                                                           \
-    const f32x4 v_ = a_ * f + (GW_V4(t_ + 16 * (i_)) * si.w + GW_V4(z_ + 16 * (i_)));                          \
+    const f32x4 v_ = fma4(f, a_, fma4(si.w, GW_V4(t_ + 16 * (i_)), GW_V4(z_ + 16 * (i_))));                    \
     a_ = __builtin_elementwise_max(v_, v_ * 0.1f);                                                            \
   }
         GW_EPI2(acc0, 0) GW_EPI2(acc1, 1) GW_EPI2(acc2, 2) GW_EPI2(acc3, 3)
@@ -374,34 +382,31 @@ __global__ __launch_bounds__(GNT) DESCO_NO_PACKED_F32 void gossip_fused_f16_kern
       }
       // ---- block 4: y2 = relu(y1 W3 + b3) ----------------------------------------------------------------------------
       GF16_ZERO()
-      GF16_BLOCK(WB + 4 * WBLK, XC)
+      GF16_BLOCK(4, XC)
       {
         const float f = pow2_inverse(s_c) * winv3;
         const float* b_ = cst + 192 + fq;
-#define GW_EPI3(a_, i_) a_ = __builtin_elementwise_max(a_ * f + GW_V4(b_ + 16 * (i_)), f32x4{0.f, 0.f, 0.f, 0.f});
+#define GW_EPI3(a_, i_) a_ = __builtin_elementwise_max(fma4(f, a_, GW_V4(b_ + 16 * (i_))), f32x4{0.f, 0.f, 0.f, 0.f});
         GW_EPI3(acc0, 0) GW_EPI3(acc1, 1) GW_EPI3(acc2, 2) GW_EPI3(acc3, 3)
 #undef GW_EPI3
         s_c = f16_scale_for(quarters_max(absmax16(acc0, acc1, acc2, acc3)));
         make_frag(acc0, acc1, acc2, acc3, s_c, XC);
       }
       // ---- blocks 5..8: head partial  sum_c relu(y2 W5 + b5)[c] * w7[c] ------------------------------------------------
-      float part = 0.f;
+      f32x4 hp = {0.f, 0.f, 0.f, 0.f};                 // four running sums per lane, folded once after the last block
       const float fh = pow2_inverse(s_c) * winv5;
 #define GW_HEAD1(a_, cg_, i_)                                                                                 \
-  {                                                                                                           \
-    const f32x4 v_ = __builtin_elementwise_max(a_ * fh + GW_V4(cst + 256 + 64 * (cg_) + 16 * (i_) + fq),       \
-                                               f32x4{0.f, 0.f, 0.f, 0.f}) *                                   \
-                     GW_V4(cst + 512 + 64 * (cg_) + 16 * (i_) + fq);                                          \
-    part += (v_[0] + v_[1]) + (v_[2] + v_[3]);                                                                \
-  }
+  hp = __builtin_elementwise_fma(__builtin_elementwise_max(fma4(fh, a_, GW_V4(cst + 256 + 64 * (cg_) + 16 * (i_) + fq)), \
+                                                           f32x4{0.f, 0.f, 0.f, 0.f}),                        \
+                                 GW_V4(cst + 512 + 64 * (cg_) + 16 * (i_) + fq), hp);
 #define GW_HEAD(cg_)                                                                                         \
   GF16_ZERO()                                                                                                \
-  GF16_BLOCK(WB + (5 + (cg_)) * WBLK, XC)                                                                    \
+  GF16_BLOCK(5 + (cg_), XC)                                                                    \
   GW_HEAD1(acc0, cg_, 0) GW_HEAD1(acc1, cg_, 1) GW_HEAD1(acc2, cg_, 2) GW_HEAD1(acc3, cg_, 3)
       GW_HEAD(0) GW_HEAD(1) GW_HEAD(2) GW_HEAD(3)
 #undef GW_HEAD
 #undef GW_HEAD1
-      part = quarters_sum(part);
+      const float part = quarters_sum((hp[0] + hp[1]) + (hp[2] + hp[3]));
       if (lane < 16 && valid) g.out[row * Q + q] = part + g.b7 + si.w;
     }
     unit = (int64_t)__builtin_amdgcn_readfirstlane((int)(tk & 0xffffffffull)) |

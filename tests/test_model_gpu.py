@@ -889,10 +889,9 @@ def test_without_tconv_matches_oracle(setup):
 
 
 def test_mfma_kernels_are_bit_reproducible(setup):
-    """Two passes over the same batch give bit-identical results, and so do five launches of the gossip kernel alone.
-    (Round 4: packed fp32 VALU instructions beside other waves' MFMAs returned wrong values in ~1 % of the gossip
-    kernel's outputs, differently in every launch -- profiles/r4_b_gossip_f16_race.md; the kernel is compiled without
-    them.  This is the regression test, and the same check for the SHMP layer kernel, which keeps its packed forms.)"""
+    """Two passes over the same batch give bit-identical results, and so do five launches of the gossip kernel alone
+    (the small-size companion of test_gossip_kernel_200_launches_bit_identical, and the same check for the SHMP layer
+    kernel)."""
     nm, gm, qids, queries = setup
     gs = GraphSet.from_edge_lists(golden_graphs(max_n=60) * 6)
     part = build_partition(gs, 4)
@@ -909,3 +908,40 @@ def test_mfma_kernels_are_bit_reproducible(setup):
         for _ in range(5):
             assert torch.equal(gm.graph_to_count(gb), ref)
 
+
+def test_gossip_kernel_200_launches_bit_identical(setup):
+    """The stress test of profiles/r5_a_gossip_f16_hazard.md: 200 consecutive launches of the fused gossip kernel at the
+    size the bench launches it with (16 M (node, query) rows, COX2-like degrees, the degree tile order on) return the same
+    bits.  The round-4 failure (a packed fp32 instruction that takes its low lane from the high dword of src1, wrong in
+    lanes 48-63 beside MFMAs) showed as 1-2 % of the results differing from launch to launch; the build refuses that
+    instruction form (tools/check_isa.py), and this is the run-time side of the same guarantee."""
+    nm, gm, qids, queries = setup
+    Q = len(queries)
+    N = 16_000_000 // Q
+    g = torch.Generator().manual_seed(11)
+    ids = torch.arange(N)
+    blk = 41                                              # COX2-sized components: a random tree plus ring-closing edges
+    par = (ids // blk) * blk + (torch.rand(N, generator=g) * (ids % blk).clamp(min=1)).long()
+    keep = (ids % blk) != 0
+    es = torch.randint(0, N, (N // 20,), generator=g)
+    ed = ((es // blk) * blk + torch.randint(0, blk, (N // 20,), generator=g)).clamp(max=N - 1)
+    src, dst = torch.cat([ids[keep], es[es != ed]]), torch.cat([par[keep], ed[es != ed]])
+    und = torch.unique(torch.minimum(src, dst) * N + torch.maximum(src, dst))
+    a, b = und // N, und % N
+    s2, d2 = torch.cat([a, b]), torch.cat([b, a])
+    order = torch.argsort(s2 * N + d2)
+    rowptr = torch.zeros(N + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(s2, minlength=N), 0)
+    from desco_amd.graphs import GraphSet as GS
+    gs = GS(np.array([0, N], dtype=np.int64), rowptr.numpy(), d2[order].numpy().astype(np.int32))
+    x = torch.rand(N, Q, generator=g) * 30
+    gm.set_query_emb(nm.get_query_emb())
+    gb = GossipBatch(gs, DEV, x=x)
+    with torch.no_grad():
+        ref = gm.graph_to_count(gb).clone()
+        assert torch.isfinite(ref).all()
+        bad = 0
+        for _ in range(200):
+            bad += int((gm.graph_to_count(gb).view(torch.int32) != ref.view(torch.int32)).sum())
+    print(f"[stress] 200 launches x {N * Q} results: {bad} differ from the first launch")
+    assert bad == 0

@@ -10,7 +10,7 @@ g++ -O2 -fPIC -c stub.cpp -o _build/stub.o
 build() {   # name, flags...
   local name=$1; shift
   local src=gossip_f16_var.hip
-  case $name in old_*) src=old_0d06b19/gossip_wave_f16.hip;; esac
+  case $name in old_*) src=old_0d06b19/gossip_wave_f16.hip;; ship*) src=$CS/gossip_f16.hip;; abl_*|exp_*) src=_build/gossip_f16_abl.hip;; esac
   /opt/rocm/bin/hipcc $BASE "$@" -c $src -o _build/$name.o 2>_build/$name.log || { cat _build/$name.log; exit 1; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _build/libgf16_$name.so _build/$name.o _build/stub.o
   /opt/rocm/bin/hipcc $BASE "$@" -S --cuda-device-only $src -o _build/$name.s 2>/dev/null
@@ -18,6 +18,25 @@ build() {   # name, flags...
      "$(grep -m1 -E '^\s+\.vgpr_count' _build/$name.s | tr -d ' ')"
 }
 NOSLP="-fno-slp-vectorize"
+abl() {   # timing ablations of the shipped kernel (make_ablations.py): wrong results by design
+  python3 make_ablations.py
+  build abl_none
+  build abl_nomfma -DABL_NOMFMA
+  build abl_noreq  -DABL_NOREQ
+  build abl_nop1   -DABL_NOP1
+  build abl_noepi  -DABL_NOEPI
+  build abl_nohead -DABL_NOHEAD
+  build abl_valu   -DABL_NOMFMA -DABL_NOREQ
+  build abl_mfma   -DABL_NOP1 -DABL_NOEPI
+}
+exps() {  # scheduling experiments on the shipped kernel (right results)
+  python3 make_ablations.py
+  build exp_prio1   -DEXP_PRIO=1
+  build exp_prio2   -DEXP_PRIO=2
+  build exp_stagger -DEXP_STAGGER
+}
+if [ -n "$1" ]; then for v in "$@"; do case $v in ship) build ship;; abl) abl;; exps) exps;; *) echo "ship | abl | exps"; exit 1;; esac; done; exit 0; fi
+build ship          # the kernel as it ships (desco_amd/csrc/gossip_f16.hip)
 build nopk
 build pk            -DVAR_PK
 build pk_w4         -DVAR_PK -DVAR_WAVES=4
