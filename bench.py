@@ -300,7 +300,7 @@ def cpu_baseline_processes(procs, sd_n, sd_g, sample, queries):
     return len(sample) / wall, wall, max(per), min(per)
 
 
-def train_leg(device, batch_size=512, stride=4, precision="fp32"):
+def train_leg(device, batch_size=512, stride=4, precision="fp32", epochs=1):
     """BASELINE configs 3 / 4 (Syn_1827 training): the neighborhood model's training step -- forward,
     backward (every op a C-ABI kernel, desco_amd.autograd), Adam -- on REAL-size batches: all 1 827
     Syn_1827-shaped graphs, the reference's batch of 512 neighborhoods (config.py:255; about 52 k rows per
@@ -333,7 +333,7 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     def step(b):
         opt.zero_grad(set_to_none=True)
         loss = nm.training_step(b, 0)
-        loss.backward()
+        AG.backward(loss)
         opt.step()
         return loss
 
@@ -345,13 +345,18 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     ops.PROFILER.enabled = True
     ops.PROFILER.reset()
     t0 = time.perf_counter()
-    for b in batches:
-        last = step(b).detach()
+    for _ in range(epochs):      # (epochs > 1: tools/check_pass_is_native.sh --train, which varies the timed step count)
+        for b in batches:
+            last = step(b).detach()
     torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / epochs
     ops.PROFILER.enabled = False
     first, last = float(first), float(last)
     summ = ops.PROFILER.summary()
+    for v in summ.values():
+        for k_ in ("ms", "calls", "launches", "flops", "bytes"):
+            if k_ in v:
+                v[k_] = v[k_] / epochs
     tot = sum(v["ms"] for v in summ.values())
     n = sum(b.num_graphs for b in batches)
     rows = sum(b.num_rows for b in batches)
@@ -367,13 +372,13 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     with torch.cuda.stream(side):
         for b in batches[:2]:          # autograd's AccumulateGrad nodes must have been created on this stream
             opt.zero_grad(set_to_none=True)
-            nm.train_forward(b, 0).backward()
+            AG.backward(nm.train_forward(b, 0))
             opt.step()
         for b in batches:
             opt.zero_grad(set_to_none=True)
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg, stream=side):
-                nm.train_forward(b, 0).backward()
+                AG.backward(nm.train_forward(b, 0))
                 opt.step()
             graphs.append(cg)
         for cg in graphs[:4]:
@@ -381,10 +386,11 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     torch.cuda.current_stream(device).wait_stream(side)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for cg in graphs:
-        cg.replay()
+    for _ in range(epochs):
+        for cg in graphs:
+            cg.replay()
     torch.cuda.synchronize(device)
-    dt_graph = time.perf_counter() - t0
+    dt_graph = (time.perf_counter() - t0) / epochs
     del graphs
     dt_eager, dt = dt, dt_graph
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -424,14 +430,14 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32"):
     }
 
 
-def train_gossip_leg(device, batch_graphs=256):
+def train_gossip_leg(device, batch_graphs=256, epochs=2):
     """BASELINE config 4's second stage (Syn_1827 full training): the gossip model's training step -- forward, backward
     (every op a C-ABI kernel, desco_amd.autograd), Adam -- on all 1 827 Syn_1827-shaped graphs in the reference's batches
     of 256 graphs (config.py:319), node inputs = the exact canonical counts perturbed by 10 % (what a trained
     neighborhood stage hands over), labels = the exact counts; loss = sum log2(|pred - y| + 1)
     (lightning_model.py:585-608, 630-635).  One untimed epoch, then two timed epochs with per-launch HIP events."""
     import torch
-    from desco_amd import ops, synthetic
+    from desco_amd import autograd as AG, ops, synthetic
     from desco_amd.batch import GossipBatch
     from desco_amd.data import STANDARD_QUERY_IDS, graph_atlas_plus
     from desco_amd.groundtruth import canonical_counts
@@ -455,7 +461,7 @@ def train_gossip_leg(device, batch_graphs=256):
     def step(b):
         opt.zero_grad(set_to_none=True)
         loss = gm.training_step(b, 0)
-        loss.backward()
+        AG.backward(loss)
         opt.step()
         return loss.detach()
 
@@ -467,7 +473,7 @@ def train_gossip_leg(device, batch_graphs=256):
     ops.PROFILER.enabled = True
     ops.PROFILER.reset()
     t0 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(epochs):
         for b in batches:
             last = step(b)
     torch.cuda.synchronize(device)
@@ -475,8 +481,8 @@ def train_gossip_leg(device, batch_graphs=256):
     ops.PROFILER.enabled = False
     summ = ops.PROFILER.summary()
     tot = sum(v["ms"] for v in summ.values())
-    steps = 2 * len(batches)
-    nodes = 2 * sum(b.num_nodes for b in batches)
+    steps = epochs * len(batches)
+    nodes = epochs * sum(b.num_nodes for b in batches)
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     peak = {"gemm_f32_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_kernel": PEAK_F32_MFMA_TFLOPS,
             "gemm_f32_multi_kernel": PEAK_F32_MFMA_TFLOPS, "linear_bwd_w_multi_kernel": PEAK_F32_MFMA_TFLOPS,
@@ -609,6 +615,10 @@ def main():
                     help="skip the training leg (Syn_1827-shaped neighborhood training steps, N=1 only)")
     ap.add_argument("--train-stride", type=int, default=4, help="training leg: time every k-th batch of the epoch")
     ap.add_argument("--train-precision", default="both", choices=["fp32", "bf16", "both"])
+    ap.add_argument("--train-only", action="store_true",
+                    help="run the training legs only and print their records as one JSON line (tools/check_pass_is_native.sh)")
+    ap.add_argument("--train-epochs", type=int, default=1,
+                    help="timed passes over the training legs' batches (default 1; the gossip leg runs twice as many)")
     ap.add_argument("--selftest-nccl", action="store_true",
                     help="2-rank RCCL gradient all-reduce check (needs 2 visible GPUs; skips otherwise)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -641,6 +651,13 @@ def main():
     device = D.local_device()
     D.init_from_env(device)
     assert D.world_size() == args.gpus, (D.world_size(), args.gpus)
+    if args.train_only:
+        precisions = ["fp32", "bf16"] if args.train_precision == "both" else [args.train_precision]
+        rec = {"train_syn_1827": {p_: train_leg(device, stride=args.train_stride, precision=p_, epochs=args.train_epochs)
+                                  for p_ in precisions},
+               "train_gossip": train_gossip_leg(device, epochs=2 * args.train_epochs)}
+        print(json.dumps(rec))
+        return
     # self-proof of the collective path: which backend is live and how many ranks it reaches
     collective = None
     if world > 1:

@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_libs.sh)
 LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -32,6 +32,32 @@ class BwdWDesc(ctypes.Structure):
     """desco_bwd_w_desc (include/desco_hip.h)"""
     _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32), ("a2", vp), ("lda2", i64), ("k2", i32), ("dz", vp),
                 ("lddz", i64), ("m", i64), ("n", i32), ("dwt", vp), ("dbias", vp)]
+
+
+class Copy2dDesc(ctypes.Structure):
+    """desco_copy2d_desc (include/desco_hip.h)"""
+    _fields_ = [("src", vp), ("lds", i64), ("dst", vp), ("ldd", i64), ("rows", i32), ("cols", i32), ("transpose", i32),
+                ("accumulate", i32)]
+
+
+class GossipFoldParams(ctypes.Structure):
+    """desco_gossip_fold_params (include/desco_hip.h)"""
+    _fields_ = [(n, vp) for n in ("E", "w_pre", "b_pre", "C0", "cb0", "D0", "db0", "C1", "cb1", "D1", "db1")] + \
+               [("G0", vp * 2), ("gb0", vp * 2), ("g2", vp * 2), ("gb2", vp * 2)] + \
+               [(n, vp) for n in ("P0", "p0", "P3", "P5")] + [("num_q", i32)]
+
+
+class GossipFoldOut(ctypes.Structure):
+    """desco_gossip_fold_out"""
+    _fields_ = [(n, vp) for n in ("V0", "V1", "Vp", "wt1", "wtp", "w3t", "w5t", "g0", "g1", "g1c", "a", "h0", "h1")]
+
+
+class GossipFoldGrads(ctypes.Structure):
+    """desco_gossip_fold_grads"""
+    _fields_ = [(n, vp) for n in ("dV0", "dV1", "dVp", "dwt1", "dwtp", "dw3t", "dw5t", "dg1",
+                                  "dC0", "dcb0", "dD0", "ddb0", "dC1", "dcb1", "dD1", "ddb1")] + \
+               [("dG0", vp * 2), ("dgb0", vp * 2), ("dg2", vp * 2), ("dgb2", vp * 2)] + \
+               [(n, vp) for n in ("dP0", "dp0", "dP3", "dP5", "scratch")]
 
 
 # name -> (restype, argtypes); mirrors include/desco_hip.h one to one
@@ -112,6 +138,14 @@ SIGNATURES = {
     "desco_affine_rows_bwd_f32": (c_int, [vp, i32, vp, i32, i64, vp, vp, vp]),
     "desco_rowdot2_f32": (c_int, [vp, vp, i32, vp, i64, vp]),
     "desco_rowdot_add_f32": (c_int, [vp, i64, i32, vp, f32, vp, vp, i64, vp]),
+    "desco_copy2d_multi_f32": (c_int, [i32, POINTER(Copy2dDesc), vp]),
+    "desco_fold_shmp_fwd_f32": (c_int, [vp, i32, i32, i32, vp, vp, vp]),
+    "desco_fold_shmp_bwd_f32": (c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "desco_loss_f32": (c_int, [vp, vp, i64, i32, vp, vp, vp, vp]),
+    "desco_affine_scalar_f32": (c_int, [vp, vp, vp, vp, vp, i64, vp]),
+    "desco_gossip_fold_fwd_f32": (c_int, [POINTER(GossipFoldParams), POINTER(GossipFoldOut), vp]),
+    "desco_gossip_fold_bwd_f32": (c_int, [POINTER(GossipFoldParams), POINTER(GossipFoldOut), POINTER(GossipFoldGrads), vp]),
+    "desco_fill_f32": (c_int, [vp, f32, i64, vp]),
 }
 
 

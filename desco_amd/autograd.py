@@ -1,9 +1,12 @@
 """torch.autograd bookkeeping around the HIP kernels (training path).
 
 Every Function's forward AND backward are C-ABI kernel launches (desco_amd.ops); torch only wires
-the graph, so ``loss.backward()`` + ``torch.optim.Adam`` train the reference-named parameters.
-The weight folding of gnn_model.pack_* is done with (tiny) differentiable torch ops, so gradients
-reach the original ``lin`` / ``updates`` / ``anchor_mlp`` / ``post_mp`` / ``count_model`` tensors.
+the graph, so ``loss.backward()`` + the optimizer train the reference-named parameters.  Since round 5
+that includes the glue: the weight folding (FoldShmp / FoldGossip) reads the parameters where torch
+keeps them and writes their gradients into one buffer, the moves between nn.Linear's [out, in] layout
+and the kernels' K-major operands are copy2d launches (TransposedMany, SplitT), the losses are one
+kernel pair each (Loss) -- a step launches no kernel of torch's or hipBLASLt's
+(tools/check_pass_is_native.sh --train; ``backward(loss)`` below seeds the graph without torch's ones_like).
 """
 from __future__ import annotations
 
@@ -51,7 +54,8 @@ class Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a1, a2, wt, bias, act, slope):
-        wt = wt.contiguous()
+        if not wt.is_contiguous():
+            wt = ops.transposed(wt.t()) if wt.t().is_contiguous() else wt.contiguous()
         ctx.bf16 = PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0
         if ctx.bf16:
             c = ops.gemm_bf16(a1, ops.round_bf16(wt.t()), bias, a2=a2, act=act, slope=slope)
@@ -72,7 +76,7 @@ class Linear(torch.autograd.Function):
             if ctx.bf16:     # dA[m,k] = sum_n dZ[m,n] wt[k,n]: wt is already the n-major operand
                 da = ops.gemm_bf16(dz, ops.round_bf16(wt))
             else:
-                da = ops.gemm(dz, wt.t().contiguous())         # dA = dZ @ Wt^T  (k % 64 == 0)
+                da = ops.gemm(dz, ops.transposed(wt))          # dA = dZ @ Wt^T  (k % 64 == 0)
             if need_a1:
                 da1 = da[:, :k1]
             if need_a2:
@@ -108,7 +112,7 @@ def _mm_bwd_da(dz, wt, out=None):
     """dA = dZ @ wt^T  ([m, n] x [k, n]^T -> [m, k])."""
     if PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0:
         return ops.gemm_bf16(dz, ops.round_bf16(wt), out=out)
-    return ops.gemm(dz, wt.t().contiguous(), out=out)
+    return ops.gemm(dz, ops.transposed(wt), out=out)
 
 
 class ShmpTrunk(torch.autograd.Function):
@@ -157,8 +161,7 @@ class ShmpTrunk(torch.autograd.Function):
         canon = anch = None
         if has_anchor:
             canon = torch.empty((B, P), device=dev)
-            for l, xl in enumerate(X):
-                canon[:, l * H:(l + 1) * H] = xl[Nc:]
+            ops.copy2d_multi([(xl[Nc:], canon[:, l * H:(l + 1) * H]) for l, xl in enumerate(X)])
             anch = _mm_fwd(canon, None, aw.contiguous(), ab, ops.ACT_LEAKY, 0.1)
         ops.segment_sum(X[0][:Nc], seg_ptr, B, extra=None if anch is None else anch[:, :H], out=pooled[:, :H])
         ops.segment_sum_layers(xall, Nc, seg_ptr, B, None if anch is None else anch[:, H:], pooled[:, H:])
@@ -210,15 +213,20 @@ class ShmpTrunk(torch.autograd.Function):
 
         # dZ of the last layer: its rows feed only the pooling / the anchor operand (one zero row stands in for D:
         # row stride 0, no transposed edges)
-        zero_d = torch.zeros((1, (S + 1) * H), device=dev).expand(N, -1)
-        empty_ptr = torch.zeros(N + 1, device=dev, dtype=torch.int32)
+        if "zero_d" not in ti:         # constants of the batch, made once
+            ti["zero_d"] = torch.zeros((1, (S + 1) * H), device=dev)
+            ti["empty_ptr"] = torch.zeros(N + 1, device=dev, dtype=torch.int32)
+        zero_d, empty_ptr = ti["zero_d"].expand(N, -1), ti["empty_ptr"]
         dz = ops.shmp_bwd_dx(zero_d, empty_ptr, ti["t_col_s1"], Nc, off_count, off_canon,
                              dpooled[:, L * H:(L + 1) * H], ti["seg_id"],
                              None if dcanon is None else dcanon[:, L * H:(L + 1) * H], X[L])
         D = torch.empty((N, (S + 1) * H), device=dev)
         fp32 = PRECISION == "fp32"
         # transposed weights of all layers in one copy per row type (dA = dZ Wt^T wants the n-major operand)
-        WtT = [w_.transpose(1, 2).contiguous() for w_ in Wt] if fp32 else None
+        WtT = None
+        if fp32:
+            WtT = [torch.empty((L, w_.shape[2], w_.shape[1]), device=dev) for w_ in Wt]
+            ops.copy2d_multi([(w_[l], t_[l], True) for w_, t_ in zip(Wt, WtT) for l in range(L)])
         wgrad = []                     # the weight / bias gradients feed nothing but the optimizer: formed together,
         for l in range(L - 1, -1, -1):  # 16 per launch pair, after the chain of input gradients
             live = [(g, r0, r1, su) for g, (t, r0, r1, su) in enumerate(groups)]
@@ -261,8 +269,10 @@ class ShmpTrunkSmall(torch.autograd.Function):
         x0, xall, wt = ctx.saved_tensors
         batch = ctx.batch
         ti = batch.train_index()
+        wt_t = torch.empty((wt.shape[0], wt.shape[2], wt.shape[1]), device=wt.device)
+        ops.copy2d_multi([(wt[l], wt_t[l], True) for l in range(wt.shape[0])])
         dwt, dbias, dx0 = ops.shmp_trunk_small_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],
-                                                   ti["seg_id"], wt.transpose(1, 2).contiguous(), dpooled.contiguous())
+                                                   ti["seg_id"], wt_t, dpooled.contiguous())
         return dx0, None, dwt, dbias
 
 
@@ -278,8 +288,7 @@ class SmallKLinear(torch.autograd.Function):
     def backward(ctx, dout):
         (feat,) = ctx.saved_tensors
         if dout.shape[0] == 0:
-            return None, torch.zeros((feat.shape[1], dout.shape[1]), device=dout.device), \
-                torch.zeros((dout.shape[1],), device=dout.device)
+            return None, ops.zeros((feat.shape[1], dout.shape[1]), dout.device), ops.zeros((dout.shape[1],), dout.device)
         if dout.shape[1] == 64 and feat.shape[1] <= 16:
             dwt, db = ops.linear_smallk_bwd(feat, dout)         # weight rows and bias row in one pass (two launches)
             return None, dwt, db
@@ -374,12 +383,14 @@ class GossipTrunk(torch.autograd.Function):
     accumulations, strided copies and zero fills between our kernels, and the activation derivatives were five extra
     passes over [N Q, 64..256] tensors: here they ride in the epilogue of the GEMM that produces the gradient.)
 
-    args: batch (rowptr / col), num_nodes, num_q, C6 [R,6], C3 [R,3], C2 [R,2] (constants), then tensors with
-    gradients: V0 [Q,6,64], g1 [Q], wt1 [128,64], V1 [Q,3,64], wtp [128,64], Vp [Q,2,64], w3t [64,64], b3 [64],
-    w5t [64,256], b5 [256], w7 [256].  Returns corr0 [R] = post_mp.7's product WITHOUT its bias."""
+    args: batch (rowptr / col), num_nodes, num_q, C6 [R,6], C3 [R,3], C2 [R,2] (constants), x [R] (the input counts, no
+    gradient), g1c = 1 - g1 and the raw post_mp.3 / .5 weights ([out, in]: the operands of dA = dZ W, no gradient asked
+    of them here), then tensors with gradients: V0 [Q,6,64], g1 [Q], wt1 [128,64], V1 [Q,3,64], wtp [128,64],
+    Vp [Q,2,64], w3t [64,64], b3 [64], w5t [64,256], b5 [256], w7 [256], b7 [1].
+    Returns pred [R] = x + post_mp.7(...)."""
 
     @staticmethod
-    def forward(ctx, rowptr, col, n, q, C6, C3, C2, V0, g1, wt1, V1, wtp, Vp, w3t, b3, w5t, b5, w7):
+    def forward(ctx, rowptr, col, n, q, C6, C3, C2, x, g1c, w3, w5, V0, g1, wt1, V1, wtp, Vp, w3t, b3, w5t, b5, w7, b7):
         V0, V1, Vp = V0.contiguous(), V1.contiguous(), Vp.contiguous()
         wt1, wtp, w3t, w5t = wt1.contiguous(), wtp.contiguous(), w3t.contiguous(), w5t.contiguous()
         g1, b3, b5, w7 = g1.contiguous(), b3.contiguous(), b5.contiguous(), w7.contiguous()
@@ -389,23 +400,24 @@ class GossipTrunk(torch.autograd.Function):
         y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1)   # post_mp.0 + .2
         y3 = ops.gemm(y, w3t, b3, act=ops.ACT_RELU)
         y5 = ops.gemm(y3, w5t, b5, act=ops.ACT_RELU)
-        corr = ops.rowdot_add(y5, w7, 0.0, None)
-        ctx.save_for_backward(rowptr, col, C6, C3, C2, g1, wt1, wtp, w3t, w5t, w7, h1, hh, h2, y, y3, y5)
+        pred = ops.affine_scalar(ops.rowdot_add(y5, w7, 0.0, None), add=b7, addv=x)
+        ctx.save_for_backward(rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5)
         ctx.n, ctx.q = n, q
-        return corr
+        return pred
 
     @staticmethod
     def backward(ctx, dcorr):
-        rowptr, col, C6, C3, C2, g1, wt1, wtp, w3t, w5t, w7, h1, hh, h2, y, y3, y5 = ctx.saved_tensors
+        rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5 = ctx.saved_tensors
         n, q = ctx.n, ctx.q
         R = h1.shape[0]
         dev = h1.device
-        dz5, dwb7 = ops.rowdot_bwd(y5, w7, dcorr.contiguous())                      # [R,256], (dw7 | .)
-        # dA = dZ W^T wants W itself as the [K = out, N = in] operand: the transposes of the (tiny) folded weights
-        w5 = w5t.t().contiguous()                                                    # [256, 64]
-        w3 = w3t.t().contiguous()
-        wp = wtp.view(2, 64, 64).transpose(1, 2).contiguous()                        # [(h1 | h2) block][out][in]
-        w1 = wt1.view(2, 64, 64).transpose(1, 2).contiguous()                        # [(hh | h1) block][out][in]
+        dz5, dwb7 = ops.rowdot_bwd(y5, w7, dcorr.contiguous())                      # [R,256], (dw7 | db7)
+        # dA = dZ W^T wants W itself as the [K = out, N = in] operand: post_mp.3 / .5 as torch keeps them, and the
+        # transposed blocks of the two folded weights (one copy2d launch)
+        wp = torch.empty((2, 64, 64), device=dev)                                    # [(h1 | h2) block][out][in]
+        w1 = torch.empty((2, 64, 64), device=dev)                                    # [(hh | h1) block][out][in]
+        ops.copy2d_multi([(wtp[:64], wp[0], True), (wtp[64:], wp[1], True), (wt1[:64], w1[0], True),
+                          (wt1[64:], w1[1], True)])
         dz3 = torch.empty((R, 64), device=dev)
         ops.gemm_multi([dict(a1=dz5, wt=w5, out=dz3, gate=y3, gate_act=ops.ACT_RELU)])
         dzp = torch.empty((R, 64), device=dev)
@@ -420,19 +432,19 @@ class GossipTrunk(torch.autograd.Function):
         ops.gemm_multi([dict(a1=dz1, wt=w1[0], out=dhh),
                         dict(a1=dz1, wt=w1[1], out=dh1, accum=True)])
         # transpose of the gated sum: the same kernel with 1 - g (GossipGather.backward)
-        ops.add_rows(dh1, ops.gossip_gather(dhh, rowptr, col, n, q, (1.0 - g1).contiguous()))
+        ops.add_rows(dh1, ops.gossip_gather(dhh, rowptr, col, n, q, g1c))
         dsig = ops.gossip_gather(h1, rowptr, col, n, q, None)                       # d out / d g1
         dg1 = ops.colsum(ops.rowdot2(dhh, dsig).view(n, q))
         dz0 = ops.act_grad(dh1, h1, ops.ACT_RELU, 0.0)
         dV0 = ops.affine_rows_bwd(C6, dz0, q)
         # the four weight / bias gradients wait for nothing and nothing but the optimizer waits for them: one launch pair
-        dw5t, db5 = torch.empty_like(w5t), torch.empty((256,), device=dev)
-        dw3t, db3 = torch.empty_like(w3t), torch.empty((64,), device=dev)
+        dw5t, db5 = torch.empty((64, 256), device=dev), torch.empty((256,), device=dev)
+        dw3t, db3 = torch.empty((64, 64), device=dev), torch.empty((64,), device=dev)
         dwtp, dwt1 = torch.empty_like(wtp), torch.empty_like(wt1)
         ops.linear_bwd_w_multi([dict(a1=y3, dz=dz5, dwt=dw5t, dbias=db5), dict(a1=y, dz=dz3, dwt=dw3t, dbias=db3),
                                 dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
-        return (None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp, dw3t, db3, dw5t, db5,
-                dwb7[:256])
+        return (None, None, None, None, None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp, dw3t,
+                db3, dw5t, db5, dwb7[:256], dwb7[256:257])
 
 
 class Mlp(torch.autograd.Function):
@@ -488,3 +500,198 @@ class Mlp(torch.autograd.Function):
         ops.linear_bwd_w_multi(wgrad)
         return (dz if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 
+
+
+# ---- round 5: the glue of a training step as autograd nodes on this library's kernels -------------------------------
+_ONES = {}
+
+
+def backward(loss: torch.Tensor) -> None:
+    """``loss.backward()`` seeded with a cached one (torch's implicit seed is a ones_like fill launch per step)."""
+    one = _ONES.get(loss.device)
+    if one is None:
+        one = _ONES[loss.device] = ops.fill(torch.empty((), device=loss.device, dtype=torch.float32), 1.0)
+    loss.backward(gradient=one)
+
+
+class Loss(torch.autograd.Function):
+    """mode 0: mean smooth_l1(pred - log2(y + 1)) (lightning_model.py:246-254, 285-289); mode 1: sum log2(|pred - y| + 1)
+    (:630-635).  The gradient is formed in the forward pass (desco_loss_f32) and scaled by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, y, mode):
+        loss, dpred = ops.loss_fwd(pred.contiguous(), y.contiguous(), mode)
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dpred,) = ctx.saved_tensors
+        return ops.scale_by_scalar(dpred, dloss), None, None
+
+
+class TransposedMany(torch.autograd.Function):
+    """(w_0^T, w_1^T, ...) of 2-D weights as contiguous tensors: one copy2d launch forward, one backward
+    (nn.Linear keeps [out, in]; the GEMM entry points take the K-major [in, out])."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        outs = [torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32) for w in ws]
+        ops.copy2d_multi([(w, o, True) for w, o in zip(ws, outs)])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        outs = [torch.empty((d.shape[1], d.shape[0]), device=d.device, dtype=torch.float32) for d in dws]
+        ops.copy2d_multi([(d.contiguous(), o, True) for d, o in zip(dws, outs)])
+        return tuple(outs)
+
+
+class SplitT(torch.autograd.Function):
+    """(w[:, :h]^T, w[:, h:]^T) of one [out, in] weight (count_model.0 on cat(target, query), lightning_model.py:176-193);
+    the backward writes both halves of ONE gradient tensor, so the parameter receives a single gradient."""
+
+    @staticmethod
+    def forward(ctx, w, h):
+        a = torch.empty((h, w.shape[0]), device=w.device, dtype=torch.float32)
+        b = torch.empty((w.shape[1] - h, w.shape[0]), device=w.device, dtype=torch.float32)
+        ops.copy2d_multi([(w[:, :h], a, True), (w[:, h:], b, True)])
+        ctx.h, ctx.shape = h, tuple(w.shape)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        dw = torch.empty(ctx.shape, device=da.device, dtype=torch.float32)
+        ops.copy2d_multi([(da.contiguous(), dw[:, :ctx.h], True), (db.contiguous(), dw[:, ctx.h:], True)])
+        return dw, None
+
+
+class PreLinear(torch.autograd.Function):
+    """pre_mp of every row type into ONE buffer x [N, 64] (gnn_model.py:131; no torch.cat): args feat [N, K], groups
+    [(type, r0, r1, su)], then per group wt [K, 64], bias [64]."""
+
+    @staticmethod
+    def forward(ctx, feat, groups, *wb):
+        x = torch.empty((feat.shape[0], 64), device=feat.device, dtype=torch.float32)
+        for g, (_, r0, r1, _) in enumerate(groups):
+            if r1 > r0:
+                ops.linear_smallk(feat[r0:r1], wb[2 * g].contiguous(), wb[2 * g + 1], out=x[r0:r1])
+        ctx.save_for_backward(feat)
+        ctx.groups = groups
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (feat,) = ctx.saved_tensors
+        dx = dx.contiguous()
+        K = feat.shape[1]
+        out = []
+        for _, r0, r1, _ in ctx.groups:
+            if r1 > r0 and K <= 16:
+                dwt, db = ops.linear_smallk_bwd(feat[r0:r1], dx[r0:r1])
+            elif r1 > r0:
+                dwt = torch.stack([ops.colsum(dx[r0:r1] * feat[r0:r1, k:k + 1]) for k in range(K)])
+                db = ops.colsum(dx[r0:r1])
+            else:
+                dwt, db = ops.zeros((K, 64), dx.device), ops.zeros((64,), dx.device)
+            out += [dwt, db]
+        return (None, None) + tuple(out)
+
+
+class FoldSpec:
+    """The address table of one row type's parameters for desco_fold_shmp_* (built once per model and device; the
+    parameters are updated in place by the optimizer, so their addresses hold)."""
+
+    def __init__(self, core, t):
+        L = core.layer_num
+        keys = core.slot_keys(t)
+        uniq = list(dict.fromkeys(keys))
+        self.L, self.S, self.NU = L, len(keys), len(uniq)
+        params, index = [], {}
+
+        def add(p):
+            if id(p) not in index:
+                index[id(p)] = len(params)
+                params.append(p)
+            return index[id(p)]
+
+        rows = []
+        for l in range(L):
+            row = [add(core.updates[l][t].weight), add(core.updates[l][t].bias)]
+            row += [add(core.convs[l][k].lin.weight) for k in keys]
+            row += [add(core.convs[l][k].lin.bias) for k in uniq]
+            rows.append(row)
+        self.params = params
+        offs, total = [], 0
+        for p in params:
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise ValueError("FoldShmp: parameters must be contiguous fp32")
+            offs.append(total)
+            total += p.numel()
+        self.offsets, self.total = offs, total
+        dev = params[0].device
+        self.key = tuple(p.data_ptr() for p in params)
+        self.table = torch.tensor([[params[i].data_ptr() for i in row] for row in rows], dtype=torch.int64).to(dev)
+        self.goff = torch.tensor([[offs[i] for i in row] for row in rows], dtype=torch.int64).to(dev)
+
+    def valid(self):
+        return self.key == tuple(p.data_ptr() for p in self.params)
+
+
+class FoldShmp(torch.autograd.Function):
+    """(Wt [L, (S+1) 64, 64], fb [L, 64]) of one row type from its raw parameters (spec.params, passed so that autograd
+    routes their gradients): desco_fold_shmp_fwd / _bwd.  Replaces gnn_model.pack_shmp_stacked's torch ops."""
+
+    @staticmethod
+    def forward(ctx, spec, *params):
+        ctx.spec = spec
+        return ops.fold_shmp_fwd(spec.table, spec.L, spec.S, spec.NU)
+
+    @staticmethod
+    def backward(ctx, dwt, dfb):
+        sp = ctx.spec
+        flat = torch.empty((sp.total,), device=dwt.device, dtype=torch.float32)
+        ops.fold_shmp_bwd(sp.table, sp.goff, sp.L, sp.S, sp.NU, dwt.contiguous(), dfb.contiguous(), flat)
+        return (None,) + tuple(flat[o:o + p.numel()].view(p.shape) for o, p in zip(sp.offsets, sp.params))
+
+
+_GF_ORDER = ("C0", "cb0", "D0", "db0", "C1", "cb1", "D1", "db1", "G0_0", "gb0_0", "g2_0", "gb2_0", "G0_1", "gb0_1", "g2_1",
+             "gb2_1", "P0", "p0", "P3", "P5")
+
+
+class FoldGossip(torch.autograd.Function):
+    """The operands of GossipTrunk from the gossip model's raw parameters (desco_gossip_fold_fwd / _bwd; formulas in
+    csrc/train_native.hip, algebra DESIGN.md 4.2).  args: E [Q, 64], w_pre [64], b_pre [64] (no gradient), then the
+    parameters in _GF_ORDER (g2_i = lin_gate.2.weight [1, 64]).  Returns (V0, g1, g1c, wt1, V1, wtp, Vp, w3t, w5t)."""
+
+    @staticmethod
+    def _pack(E, w_pre, b_pre, ps):
+        d = dict(zip(_GF_ORDER, ps))
+        return dict(E=E, w_pre=w_pre, b_pre=b_pre, C0=d["C0"], cb0=d["cb0"], D0=d["D0"], db0=d["db0"], C1=d["C1"],
+                    cb1=d["cb1"], D1=d["D1"], db1=d["db1"], G0=[d["G0_0"], d["G0_1"]], gb0=[d["gb0_0"], d["gb0_1"]],
+                    g2=[d["g2_0"].view(-1), d["g2_1"].view(-1)], gb2=[d["gb2_0"], d["gb2_1"]], P0=d["P0"], p0=d["p0"],
+                    P3=d["P3"], P5=d["P5"])
+
+    @staticmethod
+    def forward(ctx, E, w_pre, b_pre, *ps):
+        P = FoldGossip._pack(E, w_pre, b_pre, ps)
+        O = ops.gossip_fold_fwd(P)
+        ctx.P, ctx.O = P, O
+        ctx.mark_non_differentiable(O["g1c"])
+        ctx.set_materialize_grads(False)        # (an absent gradient arrives as None, not as a zero fill of torch's)
+        return O["V0"], O["g1"], O["g1c"], O["wt1"], O["V1"], O["wtp"], O["Vp"], O["w3t"], O["w5t"]
+
+    @staticmethod
+    def backward(ctx, dV0, dg1, _dg1c, dwt1, dV1, dwtp, dVp, dw3t, dw5t):
+        P, O = ctx.P, ctx.O
+        z = lambda t, like: ops.zeros(tuple(like.shape), like.device) if t is None else t.contiguous()   # noqa: E731
+        dO = dict(dV0=z(dV0, O["V0"]), dV1=z(dV1, O["V1"]), dVp=z(dVp, O["Vp"]), dwt1=z(dwt1, O["wt1"]),
+                  dwtp=z(dwtp, O["wtp"]), dw3t=z(dw3t, O["w3t"]), dw5t=z(dw5t, O["w5t"]),
+                  dg1=None if dg1 is None else dg1.contiguous())
+        G = ops.gossip_fold_bwd(P, O, dO)
+        g = {"C0": G["dC0"], "cb0": G["dcb0"], "D0": G["dD0"], "db0": G["ddb0"], "C1": G["dC1"], "cb1": G["dcb1"],
+             "D1": G["dD1"], "db1": G["ddb1"], "P0": G["dP0"], "p0": G["dp0"], "P3": G["dP3"], "P5": G["dP5"]}
+        for i in range(2):
+            g[f"G0_{i}"], g[f"gb0_{i}"] = G["dG0"][i], G["dgb0"][i]
+            g[f"g2_{i}"], g[f"gb2_{i}"] = G["dg2"][i].view(1, -1), G["dgb2"][i]
+        return (None, None, None) + tuple(g[n] for n in _GF_ORDER)

@@ -607,6 +607,17 @@ def pack_shmp_stacked(gnn: BaseGNN) -> dict:
     return out
 
 
+def fold_shmp_native(gnn: BaseGNN, t: str):
+    """(Wt [L, (S_t+1) 64, 64], fb [L, 64]) of row type ``t`` -- pack_shmp_stacked's folding -- by desco_fold_shmp_fwd
+    from the raw parameters, differentiable through autograd.FoldShmp (gradients in one flat buffer, no torch op)."""
+    from . import autograd as AG
+    specs = gnn.__dict__.setdefault("_fold_specs", {})
+    sp = specs.get(t)
+    if sp is None or not sp.valid():
+        sp = specs[t] = AG.FoldSpec(gnn.gnn_core, t)
+    return AG.FoldShmp.apply(sp, *sp.params)
+
+
 def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
     """Differentiable twin of ``shmp_forward`` (same math, un-fused kernels, autograd Functions from
     desco_amd.autograd; every forward and backward op is a C-ABI kernel launch)."""
@@ -628,23 +639,34 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
         seg_ptr = batch.graph_ptr
     feat = batch.node_feature
     if feat is None:
-        feat = torch.zeros((N, core.input_dim), device=dev)
+        feat = batch.__dict__.get("_zero_feat")          # ZeroNodeFeat: a constant of the batch, made once
+        if feat is None or feat.shape[1] != core.input_dim:
+            feat = batch.__dict__["_zero_feat"] = torch.zeros((N, core.input_dim), device=dev)
     if FUSED_TRAIN_TRUNK and not drop and all(len(core.slot_keys(t)) == su for t, _, _, su in groups):
-        # the whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk) on weights folded
-        # in stacked form
-        x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *_lin_t(core.pre_mp[0][t])) for t, r0, r1, _ in groups], 0)
+        # The whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk) on weights folded in
+        # stacked form.  Everything between the parameters and that node is this library's kernels too (round 5): the
+        # folding reads the parameters through an address table (autograd.FoldShmp), the K-major copies of pre_mp /
+        # anchor_mlp / post_mp are one copy2d launch (autograd.TransposedMany), pre_mp writes one buffer (PreLinear).
         has_anchor = isinstance(batch, NeighborhoodBatch)
-        st = pack_shmp_stacked(gnn)
-        flat = list(_lin_t(gnn.anchor_mlp[0])) if has_anchor else []
+        lins = [core.pre_mp[0][t] for t, *_ in groups] + ([gnn.anchor_mlp[0]] if has_anchor else []) + \
+               [gnn.post_mp[i] for i in (0, 3, 5, 7)]
+        wts = AG.TransposedMany.apply(*[m.weight for m in lins])
+        ng = len(groups)
+        pre = []
+        for g in range(ng):
+            pre += [wts[g], lins[g].bias]
+        x = AG.PreLinear.apply(feat, groups, *pre)
+        flat = [wts[ng], gnn.anchor_mlp[0].bias] if has_anchor else []
         for t, *_ in groups:
-            flat += list(st[t])
+            flat += list(fold_shmp_native(gnn, t))
         if (SMALL_TRUNK_KERNEL and not has_anchor and S == 2 and len(groups) == 1 and core.layer_num >= 1
                 and 0 < N <= ops.shmp_trunk_small_max_rows()):
             # the query graphs (135 rows): the whole trunk in one workgroup, one launch per direction
             pooled = AG.ShmpTrunkSmall.apply(x, batch, *flat)
         else:
             pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, *flat)
-        post = {"post": [_lin_t(gnn.post_mp[i]) for i in (0, 3, 5, 7)]}
+        pw = wts[ng + (1 if has_anchor else 0):]
+        post = {"post": [(pw[j], gnn.post_mp[i].bias) for j, i in enumerate((0, 3, 5, 7))]}
         return _post_mp_train(AG, post, gnn, pooled, drop)
     pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
     ti = batch.train_index()
@@ -825,8 +847,6 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     c0, c1 = core.convs[0], core.convs[1]
     C0, cb0, D0, db0 = c0.lin_com.weight, c0.lin_com.bias, c0.lin_update.weight, c0.lin_update.bias
     C1, cb1, D1, db1 = c1.lin_com.weight, c1.lin_com.bias, c1.lin_update.weight, c1.lin_update.bias
-    g0 = c0._gate_value(E).reshape(-1)
-    g1 = c1._gate_value(E).reshape(-1)
     # ---- constants per (node, query): deg_lo, deg_hi, s_lo, s_hi, x (functions of the batch alone: cached on it) ----
     # (keyed on the tensor object -- kept alive by the cache, so its address cannot be reused -- and its version;
     #  the library's in-place writers of x bump the version: ops.scatter_rows)
@@ -844,7 +864,25 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
             C2 = torch.stack([xr, one], 1).contiguous()
         cc = batch.__dict__["_train_consts"] = ((x, x._version), C6, C3, C2)
     _, C6, C3, C2 = cc
-    # ---- operands folded from the parameters (tiny differentiable torch ops: DESIGN.md 4.2) ---------------------------
+    drop = gnn.training and core.dropout > 0
+    if not drop and Q <= 64:
+        # The operands folded from the parameters by one kernel each way (autograd.FoldGossip, csrc/train_native.hip;
+        # algebra DESIGN.md 4.2), then the whole per-(node, query) pipeline and its backward as one autograd node
+        # (autograd.GossipTrunk): the step launches nothing but this library's kernels.
+        gl = [c.lin_gate for c in (c0, c1)]
+        V0, g1, g1c, wt1, V1, wtp, Vp, w3t, w5t = AG.FoldGossip.apply(
+            E.contiguous(), w_pre.contiguous(), b_pre.contiguous(), C0, cb0, D0, db0, C1, cb1, D1, db1,
+            gl[0][0].weight, gl[0][0].bias, gl[0][2].weight, gl[0][2].bias,
+            gl[1][0].weight, gl[1][0].bias, gl[1][2].weight, gl[1][2].bias,
+            gnn.post_mp[0].weight, gnn.post_mp[0].bias, gnn.post_mp[3].weight, gnn.post_mp[5].weight)
+        pred = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, x.reshape(-1), g1c,
+                                    gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(),
+                                    V0, g1, wt1, V1, wtp, Vp, w3t, gnn.post_mp[3].bias, w5t, gnn.post_mp[5].bias,
+                                    gnn.post_mp[7].weight.view(-1), gnn.post_mp[7].bias)
+        return pred.view(N, Q)
+    # ---- operands folded from the parameters with differentiable torch ops (dropout, or more than 64 queries) ----------
+    g0 = c0._gate_value(E).reshape(-1)
+    g1 = c1._gate_value(E).reshape(-1)
     a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + cb0)
     v = _mv(C0[:, H:], w_pre)
     D0a, D0b, D0c = D0[:, :H], D0[:, H:2 * H], D0[:, 2 * H:]
@@ -862,13 +900,13 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     tp = _mv(P0[:, H:2 * H], w_pre).expand(Q, H)
     zp = E @ P0[:, :H].t() + (_mv(P0[:, H:2 * H], b_pre) + p0)
     Vp = torch.stack([tp, zp], 1)                                                   # [Q,2,64]
-    drop = gnn.training and core.dropout > 0
     if not drop:
-        # the whole per-(node, query) pipeline and its backward as one autograd node (autograd.GossipTrunk)
-        corr = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, V0, g1, wt1, V1, wtp, Vp,
-                                    gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias, gnn.post_mp[5].weight.t(),
-                                    gnn.post_mp[5].bias, gnn.post_mp[7].weight[0]) + gnn.post_mp[7].bias
-        return (x.reshape(-1) + corr).view(N, Q)
+        pred = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, x.reshape(-1), (1.0 - g1).detach().contiguous(),
+                                    gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(),
+                                    V0, g1, wt1, V1, wtp, Vp, gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias,
+                                    gnn.post_mp[5].weight.t(), gnn.post_mp[5].bias, gnn.post_mp[7].weight.view(-1),
+                                    gnn.post_mp[7].bias)
+        return pred.view(N, Q)
     # ---- dropout (--gossip_dropout > 0): op-by-op autograd Functions, F.dropout where the reference applies it --------
     h1 = F.dropout(AG.AffineRows.apply(None, C6, V0, ops.ACT_RELU, 0.0), p=core.dropout, training=True)        # :274
     hh = AG.GossipGather.apply(h1, batch.rowptr, batch.col, N, Q, g1)

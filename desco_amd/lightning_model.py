@@ -69,7 +69,7 @@ class _LightningLike(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.logged: Dict[str, float] = {}
+        self.logged: Dict[str, Any] = {}
         self.hparams_dict: Dict[str, Any] = {}
 
     @property
@@ -80,7 +80,12 @@ class _LightningLike(nn.Module):
             return torch.device("cpu")
 
     def log(self, name, value, **kwargs):
-        self.logged[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
+        # (kept as the device tensor: a float() here would be a host sync -- and a D2H copy -- in every training step;
+        #  ``logged_value(name)`` reads it)
+        self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else float(value)
+
+    def logged_value(self, name) -> float:
+        return float(self.logged[name])
 
     def save_hyperparameters(self, **hp):
         self.hparams_dict = hp
@@ -285,17 +290,21 @@ class NeighborhoodCountingModel(_LightningLike):
             emb_q = self.emb_model_query(self._queries())
             emb_t = self.emb_model(batch)
         W1, b1 = self.count_model[0].weight, self.count_model[0].bias
-        T = AG.Linear.apply(emb_t, None, W1[:, :H].t(), None, ops.ACT_NONE, 0.0)
-        Qh = AG.Linear.apply(emb_q, None, W1[:, H:].t(), b1, ops.ACT_NONE, 0.0)
-        w2, b2, slope = self.count_model[2].weight[0], self.count_model[2].bias[0], self.count_model[1].negative_slope
+        wt_t, wt_q = AG.SplitT.apply(W1, H)                # K-major halves of count_model.0; one gradient for W1
+        T = AG.Linear.apply(emb_t, None, wt_t, None, ops.ACT_NONE, 0.0)
+        Qh = AG.Linear.apply(emb_q, None, wt_q, b1, ops.ACT_NONE, 0.0)
+        # (views, not selects: a select's backward is a zero fill + copy of torch's)
+        w2, b2 = self.count_model[2].weight.view(-1), self.count_model[2].bias.view(())
+        slope = self.count_model[1].negative_slope
         if Qh.shape[0] <= 32:
             logits = AG.CountHead.apply(T, Qh, w2, b2, slope)
         else:       # query groups of 32 (see _logits)
             logits = torch.cat([AG.CountHead.apply(T, Qh[q0:q0 + 32].contiguous(), w2, b2, slope)
                                 for q0 in range(0, Qh.shape[0], 32)], dim=1)
-        truth = torch.log2(batch.y.to(logits.dtype) + 1)
-        # mean over queries of per-query means == mean over all [B, Q] entries
-        return self.criterion(logits, truth)
+        # mean over queries of per-query means == mean over all [B, Q] entries; smooth_l1(logit - log2(y + 1)) and its
+        # gradient in one kernel pair (criterion below is the same formula in torch, for callers that want it)
+        y = batch.y if batch.y.dtype == torch.float32 else batch.y.float()
+        return AG.Loss.apply(logits, y, 0)
 
     def training_step(self, batch, batch_idx):                               # :133-136
         loss = self.train_forward(batch, batch_idx)
@@ -366,7 +375,10 @@ class GossipCountingModel(_LightningLike):
         if batch.y is None:
             raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
         pred = self.emb_model(batch, query_emb=self.query_emb.to(self.device))
-        return torch.sum(self.criterion(pred, batch.y.to(pred.dtype)))
+        # sum log2(|pred - y| + 1) and its gradient in one kernel pair (criterion above is the same formula in torch)
+        from . import autograd as AG
+        y = batch.y if batch.y.dtype == torch.float32 else batch.y.float()
+        return AG.Loss.apply(pred, y, 1)
 
     def training_step(self, batch, batch_idx):                              # :553-556
         loss = self.train_forward(batch, batch_idx)

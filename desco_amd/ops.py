@@ -6,6 +6,7 @@ CPU tensors -- there is no eager / CPU fallback.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -1068,3 +1069,156 @@ def rowdot2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         _lib.check(L.desco_rowdot2_f32(_dev(a, "a"), _dev(b, "b"), n, _dev(out, "out"), R,
                                        _stream()), "rowdot2")
     return out
+
+
+# ---- round 5: the glue of the training steps (csrc/train_native.hip) ------------------------------------------------
+def copy2d_multi(problems) -> None:
+    """Strided 2-D copies / transposes in one launch per 24 (desco_copy2d_multi_f32).  ``problems``: (src, dst) or
+    (src, dst, transpose) or (src, dst, transpose, accumulate) with 2-D fp32 tensors whose rows are contiguous;
+    transpose: dst [cols, rows] = src^T."""
+    descs = (_lib.Copy2dDesc * len(problems))()
+    nbytes = 0.0
+    for d, pr in zip(descs, problems):
+        src, dst = pr[0], pr[1]
+        tr = bool(pr[2]) if len(pr) > 2 else False
+        rows, cols = src.shape
+        assert tuple(dst.shape) == ((cols, rows) if tr else (rows, cols)), (tuple(src.shape), tuple(dst.shape), tr)
+        d.rows, d.cols, d.transpose = rows, cols, int(tr)
+        d.accumulate = int(bool(pr[3])) if len(pr) > 3 else 0
+        if rows and cols:
+            d.src, d.lds = _rows(src, "src")
+            d.dst, d.ldd = _rows(dst, "dst")
+        nbytes += 8.0 * rows * cols
+    with _Timed("copy2d_multi_kernel", 0.0, nbytes):
+        _lib.check(_lib.lib().desco_copy2d_multi_f32(len(problems), descs, _stream()), "copy2d_multi")
+
+
+def transposed(w: torch.Tensor) -> torch.Tensor:
+    """w^T as a new contiguous tensor (one copy2d launch)."""
+    out = torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32)
+    copy2d_multi([(w, out, True)])
+    return out
+
+
+def fold_shmp_fwd(table: torch.Tensor, L: int, S: int, NU: int):
+    """(wt [L, (S+1) 64, 64], fb [L, 64]) from the parameter address table of one row type (desco_fold_shmp_fwd_f32)."""
+    wt = torch.empty((L, (S + 1) * 64, 64), device=table.device, dtype=torch.float32)
+    fb = torch.empty((L, 64), device=table.device, dtype=torch.float32)
+    with _Timed("fold_shmp_fwd_kernel", 2.0 * L * S * 64 ** 3, 4.0 * L * ((S + 2) * 4096 + (S + 1) * 4096)):
+        _lib.check(_lib.lib().desco_fold_shmp_fwd_f32(_dev(table, "table", torch.int64), L, S, NU, _dev(wt, "wt"),
+                                                      _dev(fb, "fb"), _stream()), "fold_shmp_fwd")
+    return wt, fb
+
+
+def fold_shmp_bwd(table: torch.Tensor, goff: torch.Tensor, L: int, S: int, NU: int, dwt: torch.Tensor,
+                  dfb: torch.Tensor, grads: torch.Tensor) -> None:
+    """the gradients of every parameter of the table into the flat buffer ``grads`` (desco_fold_shmp_bwd_f32)"""
+    assert dwt.is_contiguous() and dfb.is_contiguous() and tuple(dwt.shape) == (L, (S + 1) * 64, 64)
+    with _Timed("fold_shmp_bwd_kernel", 4.0 * L * S * 64 ** 3, 4.0 * L * (2 * (S + 2) * 4096 + (S + 1) * 4096)):
+        _lib.check(_lib.lib().desco_fold_shmp_bwd_f32(_dev(table, "table", torch.int64), _dev(goff, "goff", torch.int64),
+                                                      L, S, NU, _dev(dwt, "dwt"), _dev(dfb, "dfb"), _dev(grads, "grads"),
+                                                      _stream()), "fold_shmp_bwd")
+
+
+_LOSS_WS = {}
+
+
+def loss_fwd(pred: torch.Tensor, y: torch.Tensor, mode: int):
+    """(loss [] , dpred) of desco_loss_f32: mode 0 = mean smooth_l1(pred - log2(y + 1)), mode 1 = sum log2(|pred - y| + 1)"""
+    assert pred.is_contiguous() and y.is_contiguous() and pred.shape == y.shape and pred.numel() > 0
+    dev = pred.device
+    ws = _LOSS_WS.get(dev)
+    if ws is None:
+        ws = _LOSS_WS[dev] = torch.empty(1024, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    dpred = torch.empty_like(pred)
+    with _Timed("loss_partial_kernel", 0.0, 12.0 * pred.numel()):
+        _lib.check(_lib.lib().desco_loss_f32(_dev(pred, "pred"), _dev(y, "y"), pred.numel(), mode, _dev(loss, "loss"),
+                                             _dev(dpred, "dpred"), _dev(ws, "ws"), _stream()), "loss")
+    return loss, dpred
+
+
+def affine_scalar(a: torch.Tensor, mul: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+                  addv: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a * mul[0] + add[0] + addv with one-element device tensors mul / add (no host read) and an optional addend."""
+    assert a.is_contiguous() and (addv is None or (addv.is_contiguous() and addv.numel() == a.numel()))
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().desco_affine_scalar_f32(_dev(a, "a"), _opt(mul, "mul"), _opt(add, "add"), _opt(addv, "addv"),
+                                                  _dev(out, "out"), a.numel(), _stream()), "affine_scalar")
+    return out
+
+
+def scale_by_scalar(a: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    return affine_scalar(a, mul=s)
+
+
+def _gossip_fold_params(P: dict) -> "_lib.GossipFoldParams":
+    p = _lib.GossipFoldParams()
+    for n in ("E", "w_pre", "b_pre", "C0", "cb0", "D0", "db0", "C1", "cb1", "D1", "db1", "P0", "p0", "P3", "P5"):
+        t = P[n]
+        assert t.is_contiguous(), n
+        setattr(p, n, _dev(t, n))
+    for n in ("G0", "gb0", "g2", "gb2"):
+        arr = getattr(p, n)
+        for i in range(2):
+            assert P[n][i].is_contiguous(), n
+            arr[i] = _dev(P[n][i], n)
+    p.num_q = P["E"].shape[0]
+    return p
+
+
+def _gossip_fold_out(O: dict) -> "_lib.GossipFoldOut":
+    o = _lib.GossipFoldOut()
+    for n in ("V0", "V1", "Vp", "wt1", "wtp", "w3t", "w5t", "g0", "g1", "g1c", "a", "h0", "h1"):
+        setattr(o, n, _dev(O[n], n))
+    return o
+
+
+def gossip_fold_fwd(P: dict) -> dict:
+    """desco_gossip_fold_fwd_f32: P = the parameter tensors by the names of desco_gossip_fold_params; returns the outputs
+    by the names of desco_gossip_fold_out."""
+    Q, dev = P["E"].shape[0], P["E"].device
+    e = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)          # noqa: E731
+    O = dict(V0=e(Q, 6, 64), V1=e(Q, 3, 64), Vp=e(Q, 2, 64), wt1=e(128, 64), wtp=e(128, 64), w3t=e(64, 64), w5t=e(64, 256),
+             g0=e(Q), g1=e(Q), g1c=e(Q), a=e(Q, 64), h0=e(Q, 64), h1=e(Q, 64))
+    p, o = _gossip_fold_params(P), _gossip_fold_out(O)
+    with _Timed("gossip_fold_fwd_kernel", 0.0, 0.0):
+        _lib.check(_lib.lib().desco_gossip_fold_fwd_f32(ctypes.byref(p), ctypes.byref(o), _stream()), "gossip_fold_fwd")
+    return O
+
+
+def gossip_fold_bwd(P: dict, O: dict, dO: dict) -> dict:
+    """desco_gossip_fold_bwd_f32: gradients of the parameters (dict by desco_gossip_fold_grads' output names)"""
+    Q, dev = P["E"].shape[0], P["E"].device
+    G = {("d" + n): torch.empty_like(P[n]) for n in ("C0", "cb0", "D0", "db0", "C1", "cb1", "D1", "db1", "P0", "p0", "P3", "P5")}
+    for n in ("G0", "gb0", "g2", "gb2"):
+        G["d" + n] = [torch.empty_like(P[n][i]) for i in range(2)]
+    d = _lib.GossipFoldGrads()
+    for n in ("dV0", "dV1", "dVp", "dwt1", "dwtp", "dw3t", "dw5t"):
+        assert dO[n].is_contiguous(), n
+        setattr(d, n, _dev(dO[n], n))
+    d.dg1 = _opt(dO.get("dg1"), "dg1")
+    for n in ("dC0", "dcb0", "dD0", "ddb0", "dC1", "dcb1", "dD1", "ddb1", "dP0", "dp0", "dP3", "dP5"):
+        setattr(d, n, _dev(G[n], n))
+    for n in ("dG0", "dgb0", "dg2", "dgb2"):
+        arr = getattr(d, n)
+        for i in range(2):
+            arr[i] = _dev(G[n][i], n)
+    scratch = torch.empty((4 * Q * 64,), device=dev, dtype=torch.float32)
+    d.scratch = _dev(scratch, "scratch")
+    p, o = _gossip_fold_params(P), _gossip_fold_out(O)
+    with _Timed("gossip_fold_bwd_kernel", 0.0, 0.0):
+        _lib.check(_lib.lib().desco_gossip_fold_bwd_f32(ctypes.byref(p), ctypes.byref(o), ctypes.byref(d), _stream()),
+                   "gossip_fold_bwd")
+    return G
+
+
+def fill(t: torch.Tensor, value: float) -> torch.Tensor:
+    assert t.is_contiguous() and t.dtype == torch.float32
+    _lib.check(_lib.lib().desco_fill_f32(_dev(t, "t"), float(value), t.numel(), _stream()), "fill")
+    return t
+
+
+def zeros(shape, device) -> torch.Tensor:
+    """torch.zeros without torch's fill kernel"""
+    return fill(torch.empty(shape, device=device, dtype=torch.float32), 0.0)

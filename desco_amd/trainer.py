@@ -83,19 +83,20 @@ class Trainer:
 
     def _graph_epoch(self, model, opt, batches, graphs, side, capture: bool):
         """One epoch on the side stream: eager (epoch 0), then capture-once / replay per batch."""
+        from . import autograd as AG
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for i, batch in enumerate(batches):
                 if not capture:
                     opt.zero_grad(set_to_none=True)
-                    model.train_forward(batch, i).backward()
+                    AG.backward(model.train_forward(batch, i))
                     opt.step()
                     continue
                 if i not in graphs:
                     opt.zero_grad(set_to_none=True)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):      # (the capture does not execute the step)
-                        model.train_forward(batch, i).backward()
+                        AG.backward(model.train_forward(batch, i))
                         opt.step()
                     graphs[i] = g
                 graphs[i].replay()
@@ -154,7 +155,7 @@ class Trainer:
                 for i, batch, _ in steps:
                     opt.zero_grad(set_to_none=True)
                     loss = model.training_step(batch, i)
-                    loss.backward()
+                    AG.backward(loss)          # (loss.backward() seeded without torch's ones_like fill)
                     opt.step()
             model.eval()
             val = self._mean_loss(model, datamodule.val_dataloader(), "validation_step")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DESCO_ABI_VERSION 4
+#define DESCO_ABI_VERSION 5
 #define DESCO_H 64
 
 #define DESCO_EINVAL (-1)
@@ -582,6 +582,75 @@ int desco_affine_rows_bwd_f32(const float* c, int ks, const float* dz, int qv, i
                               float* dv, float* workspace, desco_stream_t stream);
 int desco_rowdot2_f32(const float* a, const float* b, int ncols, float* out, int64_t num_rows,
                       desco_stream_t stream);
+
+/* ---- round 5: the glue of the training steps (lightning_model.py:228-254, 285-289, 585-608, 630-635) ----------------- */
+
+/* Strided 2-D copies / transposes, any number per call (24 per launch): dst[r][c] = src[r][c], or with transpose != 0
+ * dst[c][r] = src[r][c] (dst is then cols x rows); accumulate != 0 adds into dst.  The moves between nn.Linear's
+ * [out, in] layout and the K-major operands of the GEMM entry points, the canonical rows into the anchor operand, the
+ * halves of a split weight -- what torch's .t().contiguous() / cat / slice assignment launched in rounds 2-4. */
+typedef struct desco_copy2d_desc {
+  const float* src; int64_t lds;
+  float* dst; int64_t ldd;
+  int32_t rows, cols, transpose, accumulate;
+} desco_copy2d_desc;
+int desco_copy2d_multi_f32(int num, const desco_copy2d_desc* descs, desco_stream_t stream);
+
+/* The weight folding of the fused SHMP layer (gnn_model.py:253-277: per edge type SAGEConv.lin, per node type the update
+ * Linear over cat(aggregate, x)) for all layers of one row type, read from the parameters where torch keeps them:
+ *   wt[l][s 64 + k][n] = sum_j U_l[n][j] W_{l,s}[j][k]  (s < slots),   wt[l][slots 64 + k][n] = U_l[n][64 + k],
+ *   fb[l][n] = sum_j U_l[n][j] (sum_u b_{l,u}[j]) + c_l[n].
+ * table: device array, per layer [U, c, W_0 .. W_{slots-1}, b_0 .. b_{num_bias-1}] as int64 device addresses (U
+ * [64, 128], W [64, 64], c / b [64], contiguous fp32; slots of one relation carry the same W address).
+ * bwd: from dwt / dfb the gradient of every parameter, written at grad_offsets[same index] (in floats) of `grads`
+ * (tied W: the sum over its slots, written once).  Exact fp32 FMA chains in a fixed order. */
+int desco_fold_shmp_fwd_f32(const int64_t* table, int num_layers, int slots, int num_bias, float* wt, float* fb,
+                            desco_stream_t stream);
+int desco_fold_shmp_bwd_f32(const int64_t* table, const int64_t* grad_offsets, int num_layers, int slots, int num_bias,
+                            const float* dwt, const float* dfb, float* grads, desco_stream_t stream);
+
+/* The two training losses and their gradients in one pass (+ a one-block fold of the partial sums, fixed order):
+ *   mode 0  loss = mean_i smooth_l1(pred[i] - log2(y[i] + 1))     (lightning_model.py:285-289, 246-254; beta = 1)
+ *   mode 1  loss = sum_i log2(|pred[i] - y[i]| + 1)                (lightning_model.py:630-635)
+ * dpred[i] = d loss / d pred[i].  workspace: 1024 floats. */
+int desco_loss_f32(const float* pred, const float* y, int64_t count, int mode, float* loss, float* dpred,
+                   float* workspace, desco_stream_t stream);
+
+/* out[i] = a[i] * mul[0] + add[0] + addv[i], every term but a optional (NULL): a saved gradient times the upstream
+ * gradient of its scalar loss; x + correction + post_mp.7's bias.  p[i] = value. */
+int desco_affine_scalar_f32(const float* a, const float* mul, const float* add, const float* addv, float* out,
+                            int64_t count, desco_stream_t stream);
+int desco_fill_f32(float* p, float value, int64_t count, desco_stream_t stream);
+
+/* The operands of the gossip training trunk as functions of the raw parameters (gnn_model.py:58-103, 230-260, 303-350;
+ * algebra DESIGN.md 4.2), for num_q <= 64 queries with embeddings E [num_q, 64]; E, w_pre = pre_mp.weight[:, 0] and
+ * b_pre = pre_mp.bias carry no gradient (the layer-0 input is detached, gnn_model.py:236-240):
+ *   V0 [Q,6,64] = [p, g0 p, r, g0 r, t, z], V1 [Q,3,64] = [u, g1 u, db1], Vp [Q,2,64] = [tp, zp], wt1 = [(D1a C1)^T; D1b^T],
+ *   wtp = [P0c^T; P0d^T], w3t = P3^T, w5t = P5^T, gates g0 / g1 = lin_gate(E), g1c = 1 - g1      (formulas: train_native.hip)
+ * All matrices in nn.Linear's [out, in] layout: C0 [64,128], D0 [64,192], C1 [64,64], D1 [64,128], G0 [64,64], g2 [64]
+ * (lin_gate.2.weight[0]), gb2 [1], P0 [64,256], P3 [64,64], P5 [256,64].  a, h0, h1 [Q,64]: saved for the backward.
+ * bwd: the gradient of every parameter from the gradients of the outputs (dg1: the trunk's own gate gradient, may be
+ * NULL); scratch: 4 * num_q * 64 floats.  One workgroup each; exact fp32 FMA chains in a fixed order. */
+typedef struct desco_gossip_fold_params {
+  const float *E, *w_pre, *b_pre;
+  const float *C0, *cb0, *D0, *db0, *C1, *cb1, *D1, *db1;
+  const float *G0[2], *gb0[2], *g2[2], *gb2[2];
+  const float *P0, *p0, *P3, *P5;
+  int32_t num_q;
+} desco_gossip_fold_params;
+typedef struct desco_gossip_fold_out {
+  float *V0, *V1, *Vp, *wt1, *wtp, *w3t, *w5t, *g0, *g1, *g1c, *a, *h0, *h1;
+} desco_gossip_fold_out;
+typedef struct desco_gossip_fold_grads {
+  const float *dV0, *dV1, *dVp, *dwt1, *dwtp, *dw3t, *dw5t, *dg1;
+  float *dC0, *dcb0, *dD0, *ddb0, *dC1, *dcb1, *dD1, *ddb1;
+  float *dG0[2], *dgb0[2], *dg2[2], *dgb2[2];
+  float *dP0, *dp0, *dP3, *dP5;
+  float* scratch;
+} desco_gossip_fold_grads;
+int desco_gossip_fold_fwd_f32(const desco_gossip_fold_params* p, const desco_gossip_fold_out* o, desco_stream_t stream);
+int desco_gossip_fold_bwd_f32(const desco_gossip_fold_params* p, const desco_gossip_fold_out* o,
+                              const desco_gossip_fold_grads* d, desco_stream_t stream);
 
 #ifdef __cplusplus
 }

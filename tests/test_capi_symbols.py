@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/desco_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert L.desco_abi_version() == _lib.ABI_VERSION == 4
+    assert L.desco_abi_version() == _lib.ABI_VERSION == 5
     assert L.desco_count_head_bwd_workspace(512, 29, 256) == 32 * 30 * 256 * 4
     assert L.desco_count_head_bwd_workspace(10 ** 6, 29, 256) == 1024 * 30 * 256 * 4
 

@@ -3,14 +3,23 @@
 # the warm-up boundary, so the check is differential: the same bench command with 2 and with 6 timed steps -- every
 # kernel that is NOT one of this library's must have the SAME call count in both traces (it runs in set-up only), and
 # every kernel whose count grows with the steps must be one of ours.
-#   tools/check_pass_is_native.sh [out dir under gpurun_out]
-OUT=${1:-gpurun_out/native_pass}
+#   tools/check_pass_is_native.sh [out dir under gpurun_out]            the inference pass
+#   tools/check_pass_is_native.sh --train [out dir]                       the training steps: the
+#       neighborhood leg (fp32, eager and hipGraph replay) and the gossip leg of bench.py --train-only, 1 against 3 timed
+#       passes over the same batches (the untimed first pass -- indices, address tables, caches -- is the same in both)
+MODE=pass
+if [ "$1" = "--train" ]; then MODE=train; shift; fi
+OUT=${1:-gpurun_out/native_$MODE}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--warmup 1 --no-cpu-baseline --no-train --no-secondary --no-x1 --no-attainable --no-profile"
 for K in 2 6; do
   rm -rf $GRAFT_REPO_ROOT/$OUT/s$K
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/s$K -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K $COMMON > $GRAFT_REPO_ROOT/$OUT/bench_s$K.log 2>&1
+  if [ $MODE = train ]; then
+    rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/s$K -- python3 $GRAFT_REPO_ROOT/bench.py --train-only --train-precision fp32 --train-stride 16 --train-epochs $((K / 2)) > $GRAFT_REPO_ROOT/$OUT/bench_s$K.log 2>&1
+  else
+    rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/s$K -- python3 $GRAFT_REPO_ROOT/bench.py --steps $K $COMMON > $GRAFT_REPO_ROOT/$OUT/bench_s$K.log 2>&1
+  fi
 done
 cd $GRAFT_REPO_ROOT
 python3 - "$OUT" <<'PY'
