@@ -790,8 +790,36 @@ def main():
                     if tr2 >= 0.9 * alg2:
                         entry["gather"].update({"algorithmic_bytes_per_launch": alg2, "traffic": tr2,
                                                 "traffic_over_algorithmic": tr2 / alg2})
+            # Scaling evidence one GPU can give: the 8 cost-balanced shards a strong-scaling run over
+            # 8 GPUs would hand out (distributed.contiguous_shards on graph_costs), run one after another HERE; the
+            # slowest shard bounds the 8-GPU pass, so (mean shard time) / (slowest shard time) is the efficiency the cost
+            # model delivers (inference has no data-path collective: only the final gather of [G, 29] counts is added).
+            if world == 1:
+                del p2
+                torch.cuda.empty_cache()
+                cuts = D.contiguous_shards(D.graph_costs(g2, 29), 8)
+                shard_ms = []
+                for lo_, hi_ in cuts:
+                    ps = InferencePipeline(nm2, gm2, g2.subset(lo_, hi_), depth=4, device=device,
+                                           max_neigh_rows=args.neigh_rows, max_gossip_rows=args.gossip_rows, rank=0, world=1)
+                    ps.run()
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        ps.run()
+                    sync()
+                    shard_ms.append(1e3 * (time.perf_counter() - t0) / 3)
+                    del ps
+                    torch.cuda.empty_cache()
+                entry["strong_scaling_8"] = {
+                    "per_shard_ms": [round(v, 3) for v in shard_ms], "graphs_per_shard": [hi_ - lo_ for lo_, hi_ in cuts],
+                    "predicted_8gpu_efficiency": (sum(shard_ms) / 8) / max(shard_ms),
+                    "single_gpu_ms": entry["ms_per_step"],
+                    "note": "8 cost-balanced shards timed one after another on this GPU; efficiency = mean / slowest"}
+            else:
+                del p2
             secondary[f"{wname}_x{wrep}"] = entry
-            del p2, g2
+            del g2
             torch.cuda.empty_cache()
         del nm2, gm2
 

@@ -514,6 +514,7 @@ extern "C" int desco_colsum_f32(const float* x, int64_t ldx, int64_t m, int n, f
 
 // pre_mp's backward (desco_linear_smallk_bwd_f32): partial[s][k][n] = sum over slab s of feat[m, k] dout[m, n] (k < K),
 // partial[s][K][n] = sum of dout[m, n] -- the weight rows and the bias row of one tiny-K Linear in one pass over dout
+namespace desco {
 __global__ __launch_bounds__(256) void smallk_bwd_partial_kernel(const float* __restrict__ feat, int64_t ldf, int K,
                                                                 const float* __restrict__ dout, int64_t ldd,
                                                                 int64_t M, int64_t slab,
@@ -541,6 +542,8 @@ __global__ __launch_bounds__(256) void smallk_bwd_partial_kernel(const float* __
   }
 }
 
+}  // namespace desco
+
 extern "C" int desco_linear_smallk_bwd_f32(const float* feat, int64_t ldf, int k, const float* dout, int64_t ldd,
                                            int64_t m, float* dwb, float* workspace, desco_stream_t stream) {
   if (!feat || !dout || !dwb || !workspace || m < 0 || k < 1 || k > 16 || ldd % 4 ||
@@ -560,6 +563,7 @@ extern "C" int desco_linear_smallk_bwd_f32(const float* feat, int64_t ldf, int k
 }
 
 // dz = (dout x w) * relu'(y), per-block partials of dw = y^T dout and db = sum dout (desco_rowdot_bwd_f32)
+namespace desco {
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ y, int64_t ldy, int n,
                                                         const float* __restrict__ w, const float* __restrict__ dout,
                                                         int64_t R, int64_t slab, float* __restrict__ dz, int64_t lddz,
@@ -604,6 +608,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     out[n] = t;
   }
 }
+
+}  // namespace desco
 
 extern "C" int desco_rowdot_bwd_f32(const float* y, int64_t ldy, int n, const float* w, const float* dout,
                                     int64_t num_rows, float* dz, int64_t lddz, float* dwb, float* workspace,
