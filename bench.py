@@ -300,6 +300,17 @@ def cpu_baseline_processes(procs, sd_n, sd_g, sample, queries):
     return len(sample) / wall, wall, max(per), min(per)
 
 
+def train_traffic(key, kernel):
+    """HBM bytes per launch of a training leg's dominant kernel from the committed PMC passes of that leg
+    (profiles/pmc_traffic.json, tools/profile_round.sh: FETCH_SIZE / WRITE_SIZE of `bench.py --train-only --train-leg ...`,
+    averaged over every launch of the kernel in that run), or None."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][key]["kernels"][kernel]
+        return e["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def train_leg(device, batch_size=512, stride=4, precision="fp32", epochs=1):
     """BASELINE configs 3 / 4 (Syn_1827 training): the neighborhood model's training step -- forward,
     backward (every op a C-ABI kernel, desco_amd.autograd), Adam -- on REAL-size batches: all 1 827
@@ -406,7 +417,7 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32", epochs=1):
         roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS}
     roof.update({"launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"], "share_of_kernel_time": d["ms"] / tot,
-                 "traffic": None})
+                 "traffic": train_traffic(f"train_{precision}", name)})
     AG.set_precision("fp32")
     return {
         "metric": "neighborhoods/s (neighborhood-model training step: forward, backward, Adam)",
@@ -495,7 +506,7 @@ def train_gossip_leg(device, batch_graphs=256, epochs=2):
         roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS}
     roof.update({"launches": d["calls"], "avg_launch_ms": d["ms"] / d["calls"], "share_of_kernel_time": d["ms"] / tot,
-                 "traffic": None})
+                 "traffic": train_traffic("train_gossip", name)})
     return {
         "metric": "nodes/s (gossip-model training step: forward, backward, Adam; 29 queries per node)",
         "value": nodes / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
@@ -617,6 +628,8 @@ def main():
     ap.add_argument("--train-precision", default="both", choices=["fp32", "bf16", "both"])
     ap.add_argument("--train-only", action="store_true",
                     help="run the training legs only and print their records as one JSON line (tools/check_pass_is_native.sh)")
+    ap.add_argument("--train-leg", default="all", choices=["all", "fp32", "bf16", "gossip"],
+                    help="--train-only: run one leg only (the PMC passes of tools/profile_round.sh take them one at a time)")
     ap.add_argument("--train-epochs", type=int, default=1,
                     help="timed passes over the training legs' batches (default 1; the gossip leg runs twice as many)")
     ap.add_argument("--selftest-nccl", action="store_true",
@@ -653,9 +666,14 @@ def main():
     assert D.world_size() == args.gpus, (D.world_size(), args.gpus)
     if args.train_only:
         precisions = ["fp32", "bf16"] if args.train_precision == "both" else [args.train_precision]
-        rec = {"train_syn_1827": {p_: train_leg(device, stride=args.train_stride, precision=p_, epochs=args.train_epochs)
-                                  for p_ in precisions},
-               "train_gossip": train_gossip_leg(device, epochs=2 * args.train_epochs)}
+        if args.train_leg in ("fp32", "bf16"):
+            precisions = [args.train_leg]
+        rec = {}
+        if args.train_leg != "gossip":
+            rec["train_syn_1827"] = {p_: train_leg(device, stride=args.train_stride, precision=p_, epochs=args.train_epochs)
+                                     for p_ in precisions}
+        if args.train_leg in ("all", "gossip"):
+            rec["train_gossip"] = train_gossip_leg(device, epochs=2 * args.train_epochs)
         print(json.dumps(rec))
         return
     # self-proof of the collective path: which backend is live and how many ranks it reaches
@@ -791,13 +809,13 @@ def main():
                         entry["gather"].update({"algorithmic_bytes_per_launch": alg2, "traffic": tr2,
                                                 "traffic_over_algorithmic": tr2 / alg2})
             # Scaling evidence one GPU can give: the 8 cost-balanced shards a strong-scaling run over
-            # 8 GPUs would hand out (distributed.contiguous_shards on graph_costs), run one after another HERE; the
+            # 8 GPUs would hand out (distributed.contiguous_shards on graph_costs: exact neighborhood rows), run one after another HERE; the
             # slowest shard bounds the 8-GPU pass, so (mean shard time) / (slowest shard time) is the efficiency the cost
             # model delivers (inference has no data-path collective: only the final gather of [G, 29] counts is added).
             if world == 1:
                 del p2
                 torch.cuda.empty_cache()
-                cuts = D.contiguous_shards(D.graph_costs(g2, 29), 8)
+                cuts = D.contiguous_shards(D.graph_costs(g2, 29, device), 8)
                 shard_ms = []
                 for lo_, hi_ in cuts:
                     ps = InferencePipeline(nm2, gm2, g2.subset(lo_, hi_), depth=4, device=device,
@@ -885,6 +903,20 @@ def main():
                 return t
 
             mp = mfma_peak(name)
+            # a kernel that both streams rows and multiplies them (the fused SHMP layer) is priced against the roof it
+            # is NEARER to: the binding one.  (The gather launches run at 0.4 of the HBM peak and 0.2 of the f16x3 matrix
+            # rate: HBM-bound, as BASELINE.json's north_star names them; the gossip kernel at 0.04 / 0.38: matrix-bound.)
+            other_roof = None
+            if mp is not None and d["bytes"] > 0:
+                f_h = d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+                f_m = d["flops"] / (d["ms"] * 1e-3) / 1e12 / mp[0]
+                if f_h > f_m:
+                    other_roof = {"bound": "mfma", "achieved": f_m * mp[0], "peak": mp[0], "unit": "TFLOP/s", "frac": f_m,
+                                  "pipe": mp[1]}
+                    mp = None
+                else:
+                    other_roof = {"bound": "hbm", "achieved": f_h * PEAK_HBM_GBS, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": f_h}
             if mp is not None:
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": mp[0],
@@ -901,6 +933,8 @@ def main():
                 ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": traffic(name, d["bytes"] / calls, hbm_bound=True)}
+            if other_roof:
+                roof["other_roof"] = other_roof
             roof.update({"kernel": name, "launches": calls, "avg_launch_ms": d["ms"] / calls,
                          "share_of_kernel_time": d["ms"] / tot,
                          "algorithmic_per_launch": (d["flops"] if roof["bound"] == "mfma" else d["bytes"]) / calls,

@@ -299,15 +299,36 @@ def gather_rows(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
 # ------------------------------------------------------------------------------------------------
 # inference: graph sharding
 # ------------------------------------------------------------------------------------------------
-def graph_costs(graphs: GraphSet, num_queries: int = 29) -> np.ndarray:
-    """Cheap per-graph cost proxy c(g) ~ neighborhood work + gossip work:
-    sum over nodes of (1 + deg)^2 bounded, plus Q*(n + e)."""
+def graph_costs(graphs: GraphSet, num_queries: int = 29, device=None, depth: int = 4) -> np.ndarray:
+    """Per-graph cost c(g) of one inference pass, for cutting a dataset into ranks' shards.
+
+    The pass is dominated by the neighborhood stage, whose work is the number of neighborhood ROWS of the graph (every
+    node of every canonical neighborhood is a row of every SHMP layer); the gossip stage adds Q rows per node at about a
+    sixth of the price.  Measured on MI355X (bench.py secondary.*.strong_scaling_8, Syn_1827 x2): shard time =
+    2.0 ms + 1.4 ms per million neighborhood rows.  With a CUDA ``device`` the rows are EXACT: the device partition
+    builder (csrc/partition_dev.hip; 0.1 s for Syn_1827) counts them -- a size proxy cannot (the neighborhood of a
+    node of a dense 700-node graph has hundreds of rows, of a molecule nine: round 4's degree proxy gave the 8
+    Syn_1827 shards times between 2.7 and 16.5 ms, a predicted 8-GPU efficiency of 0.54).  Without a device (CPU
+    tests, planning tools) the proxy below stands in: sum over nodes of min(rank + 1, 4-hop ball bound) rows."""
     deg = np.diff(graphs.rowptr).astype(np.float64)
-    node_cost = np.minimum((1.0 + deg) ** 2, 4096.0)
     gid = graphs.node_graph_ids()
-    c = np.zeros(graphs.num_graphs)
-    np.add.at(c, gid, node_cost + num_queries * (1.0 + deg))
-    return c
+    n_g = np.diff(graphs.graph_ptr).astype(np.float64)
+    rows = None
+    if device is not None and str(device).startswith("cuda"):
+        from .partition import build_partition_device
+        try:
+            part = build_partition_device(graphs, depth, device)
+            rows = np.bincount(part.neigh_index[:, 0], weights=np.diff(part.count_ptr).astype(np.float64) + 1.0,
+                               minlength=graphs.num_graphs)
+        except RuntimeError:          # a graph beyond the device builder's workspace: fall back to the proxy
+            rows = None
+    if rows is None:
+        rank = np.arange(graphs.num_nodes, dtype=np.float64) - graphs.graph_ptr[:-1][gid] + 1.0
+        d = np.maximum(deg, 1.0)
+        ball = np.minimum(1.0 + d * (1.0 + (d - 1.0) * (1.0 + (d - 1.0) * (1.0 + (d - 1.0)))), n_g[gid])
+        rows = np.zeros(graphs.num_graphs)
+        np.add.at(rows, gid, np.minimum(rank, ball))
+    return rows + (num_queries / 6.0) * n_g
 
 
 def contiguous_shards(costs: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
@@ -325,8 +346,8 @@ def contiguous_shards(costs: np.ndarray, world_size: int) -> List[Tuple[int, int
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-def shard_graphs(graphs: GraphSet, rank: int, world_size: int, num_queries: int = 29):
-    lo, hi = contiguous_shards(graph_costs(graphs, num_queries), world_size)[rank]
+def shard_graphs(graphs: GraphSet, rank: int, world_size: int, num_queries: int = 29, device=None):
+    lo, hi = contiguous_shards(graph_costs(graphs, num_queries, device), world_size)[rank]
     return graphs.subset(lo, hi), (lo, hi)
 
 

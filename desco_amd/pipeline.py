@@ -77,7 +77,7 @@ class InferencePipeline:
                 raise ValueError(f"chunks = {self.chunks} must be a positive multiple of world = {self.world}")
             if partition is not None:
                 raise ValueError("chunks: let the pipeline build the partition")
-            ranges = D.contiguous_shards(D.graph_costs(graphs, Q0), self.chunks)
+            ranges = D.contiguous_shards(D.graph_costs(graphs, Q0, device), self.chunks)
             per = self.chunks // self.world
             mine = ranges[self.rank * per:(self.rank + 1) * per]
             self.graph_range = (mine[0][0], mine[-1][1])
@@ -86,7 +86,7 @@ class InferencePipeline:
         elif self.world > 1:
             if partition is not None:
                 raise ValueError("pass the partition of the local shard, or let the pipeline build it")
-            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q0)
+            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q0, device)
         self.graphs = graphs
         self._chunk_cuts = chunk_cuts
         from .batch import _norm_device

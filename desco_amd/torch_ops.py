@@ -45,12 +45,45 @@ SCHEMAS = {
     "gossip_fused": "(Tensor scal4, Tensor rowptr, Tensor col, int num_nodes, int num_q, Tensor[] operands, "
                     "float b7) -> Tensor",
     "split_bf16_planes": "(Tensor w) -> Tensor",
+    # the three-product fp16 forms the product path runs since round 4 (csrc/gemm_f16x3.hip, gossip_f16.hip,
+    # shmp_layer16.hip): planes int16 [2, n, k] + scale float32 [2] of desco_split_f16x2_f32
+    "split_f16_planes": "(Tensor w) -> Tensor[]",
+    "gemm_f16x3": "(Tensor a1, Tensor planes, Tensor scale, Tensor? bias, Tensor? a2, int act, float slope) -> Tensor",
+    "shmp_layer_fused_f16x3": "(Tensor x, Tensor vrowptr, Tensor vcol, int row0, int num_rows, int slots_stored, "
+                              "int slots_mfma, Tensor planes, Tensor scale, Tensor bias, Tensor? ytab, int ytab_row0, "
+                              "Tensor(a!) out) -> Tensor(a!)",
+    "gossip_f16_stream": "(Tensor[] planes, Tensor[] scales) -> Tensor[]",
+    "gossip_fused_f16x3": "(Tensor scal4, Tensor rowptr, Tensor col, int num_nodes, int num_q, Tensor[] operands, "
+                          "float b7, Tensor(a!) queue, Tensor? tile_perm) -> Tensor",
 }
 for _name, _schema in SCHEMAS.items():
     _DEF.define(_name + _schema)
 
 GOSSIP_FUSED_OPERANDS = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "w1s", "wps", "w3s", "b3", "w5s",
                          "b5", "w7")
+
+
+GOSSIP_F16_OPERANDS = ("g1", "p", "z", "zp", "r", "t", "u", "tp", "d1", "wstream", "winv", "b3", "b5", "w7")
+
+
+def _gossip_fused_f16x3(scal4, rowptr, col, num_nodes, num_q, operands, b7, queue, tile_perm):
+    if len(operands) != len(GOSSIP_F16_OPERANDS):
+        raise RuntimeError(f"desco::gossip_fused_f16x3 expects {len(GOSSIP_F16_OPERANDS)} operands {GOSSIP_F16_OPERANDS}")
+    v = dict(zip(GOSSIP_F16_OPERANDS, operands))
+    v["b7"] = b7
+    return ops.gossip_fused_f16(scal4, rowptr, col, num_nodes, num_q, v, queue, tile_perm=tile_perm)
+
+
+def _gossip_f16_stream(planes, scales):
+    if len(planes) != 4 or len(scales) != 4:
+        raise RuntimeError("desco::gossip_f16_stream expects the planes / scales of W1, Wp, W3, W5")
+    return list(ops.gossip_f16_stream(*[ops.F16Planes(p, s) for p, s in zip(planes, scales)]))
+
+
+def _shmp_layer_fused_f16x3(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, planes, scale, bias, ytab,
+                            ytab_row0, out):
+    return ops.shmp_layer(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, ops.F16Planes(planes, scale), bias,
+                          out, ytab=ytab, ytab_row0=ytab_row0)
 
 
 def _build_canonical_partition(graph_ptr, rowptr, col, depth, quirk_batch=0, num_threads=0) -> List[torch.Tensor]:
@@ -95,3 +128,14 @@ _CUDA.impl("gossip_aggregate_backward", lambda g, rowptr, col, n, q, gate:
            ops.gossip_gather(g.contiguous(), rowptr, col, n, q, (1.0 - gate).contiguous()))
 _CUDA.impl("gossip_fused", _gossip_fused)
 _CUDA.impl("split_bf16_planes", ops.split_bf16_planes)
+def _split_f16_planes(w):
+    fp = ops.split_f16_planes(w)
+    return [fp.planes, fp.scale]
+
+
+_CUDA.impl("split_f16_planes", _split_f16_planes)
+_CUDA.impl("gemm_f16x3", lambda a1, planes, scale, bias, a2, act, slope:
+           ops.gemm_f16x3(a1, ops.F16Planes(planes, scale), bias, a2=a2, act=act, slope=slope))
+_CUDA.impl("shmp_layer_fused_f16x3", _shmp_layer_fused_f16x3)
+_CUDA.impl("gossip_f16_stream", _gossip_f16_stream)
+_CUDA.impl("gossip_fused_f16x3", _gossip_fused_f16x3)

@@ -426,7 +426,14 @@ int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr, const int3
  *     (w1, wp [2][64][128]; w3 [2][64][64]; w5 [2][256][64]) and the 1/scale of each matrix, in that order;
  *   queue: two zeroed 64-bit words owned by the caller (work-item tickets of this launch; the kernel leaves them
  *     zero).  Launches that may run CONCURRENTLY (other streams, graph replays) need queues of their own; launches
- *     on one stream can share one. */
+ *     on one stream can share one.
+ * Work per (node, query) row: 73 728 MFMA flop (x3 products); bytes the algorithm has to move per row: its 16-byte
+ * record + 4-byte result + 16 bytes per NEIGHBOUR record (deg x 16: 12 of them used) + the column ids once per node --
+ * rows * 20 + 4 * (edges * (1 + 4 Q) + nodes), which is what bench.py prices `achieved` bytes with (round 4's
+ * "16-B record + 4-B result" left the neighbour records out; they are 2/3 of the bytes on COX2 shapes).
+ * Round 5: packed fp32 selection on, weight fragments through a register ring two pair steps ahead
+ * (csrc/gossip_f16.hip); the library is only linked if no packed fp32 instruction in it has OP_SEL on src1 / src2
+ * (tools/check_isa.py, profiles/r5_a_gossip_f16_hazard.md). */
 int desco_gossip_f16_stream(const int16_t* w1_planes, const int16_t* wp_planes, const int16_t* w3_planes,
                             const int16_t* w5_planes, int16_t* wstream, desco_stream_t stream);
 int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* rowptr, const int32_t* col,

@@ -7,6 +7,7 @@
 set -u
 TAG=${1:-round}
 WLS=${2:-"cox2:64 syn_1827:4 msrc_imdb:8"}
+[ "$WLS" = "none" ] && WLS=""      # (only the training-leg PMC passes and the x1 line)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -66,4 +67,19 @@ PY
   find $OUT/stats_$K $OUT/pmc_fetch_$K $OUT/pmc_write_$K $OUT/sq_${K}_p1 $OUT/sq_${K}_p2 $OUT/sq_${K}_p3 -name "*.csv" ! -name "*kernel_stats.csv" -delete 2>/dev/null
   head -6 $OUT/kernel_stats_$K.csv
 done
+# training legs: FETCH_SIZE / WRITE_SIZE per kernel, one leg per run (their dominant kernels share names), folded into
+# pmc_traffic.json under train_fp32 / train_bf16 / train_gossip (bench.py's train_traffic)
+if [ "${PROFILE_TRAIN:-1}" = "1" ]; then
+  for LEG in fp32 bf16 gossip; do
+    TA="--train-only --train-leg $LEG --train-stride 16"
+    cd /tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train_$LEG -- python3 $ROOT/bench.py $TA > $OUT/pmc_fetch_train_$LEG.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train_$LEG -- python3 $ROOT/bench.py $TA > $OUT/pmc_write_train_$LEG.log 2>&1
+    cd $ROOT
+    F=$(find $OUT/pmc_fetch_train_$LEG -name "*counter_collection.csv" | head -1)
+    Wf=$(find $OUT/pmc_write_train_$LEG -name "*counter_collection.csv" | head -1)
+    python3 tools/pmc_summary.py "$F" "$Wf" $OUT/pmc_traffic.json "python3 bench.py $TA" train_$LEG $TAG 1 > /dev/null
+    find $OUT/pmc_fetch_train_$LEG $OUT/pmc_write_train_$LEG -name "*.csv" -delete 2>/dev/null
+  done
+fi
 python3 bench.py --steps 50 --warmup 5 --replicas 1 --no-cpu-baseline --no-train > $OUT/bench_cox2_x1.json 2>> $OUT/bench_cox2_x64.err
