@@ -182,9 +182,12 @@ def cpu_baseline(nm, gm, graphs_host, queries, target_seconds=16.0, workers=None
         #  over all of it would hand every worker graphs a hundred times dearer than the ones the rate was sized on)
         n_pp = int(max(2 * P, min(64 * len(graphs_host), 0.5 * target_seconds * runs[1] * P)))
         sample_pp = [sample[i % len(sample)] for i in range(n_pp)]
-        rate, wall, slowest, fastest = cpu_baseline_processes(workers, sd_n, sd_g, sample_pp, queries)
-        pp = {"value": rate, "processes": P, "threads_per_process": 1, "graphs": n_pp, "wall_s": wall,
-              "slowest_worker_s": slowest, "fastest_worker_s": fastest}
+        rate_wall, wall, slowest, fastest, rate = cpu_baseline_processes(workers, sd_n, sd_g, sample_pp, queries)
+        pp = {"value": rate, "value_static_shards_wall_clock": rate_wall, "processes": P, "threads_per_process": 1,
+              "graphs": n_pp, "wall_s": wall, "slowest_worker_s": slowest, "fastest_worker_s": fastest,
+              "note": "value = sum of the workers' own rates (graphs of its shard / its time): the rate of the same "
+                      "cores under dynamic work distribution; the wall-clock rate of the static equal shards is lower "
+                      "by the spread between the workers"}
         if rate > value:
             value, cores = rate, P
     return {"value": value, "unit": "graphs/s", "cores": cores, "kind": "port",
@@ -297,7 +300,13 @@ def cpu_baseline_processes(procs, sd_n, sd_g, sample, queries):
         wall = time.perf_counter() - t0
     finally:
         os.unlink(path)
-    return len(sample) / wall, wall, max(per), min(per)
+    # The shards are static and equal, the workers are not (core sharing, clocks: the slowest took 2x the fastest's time
+    # in round 4): the wall-clock rate is what this static split delivers, the SUM of the workers' own rates is what
+    # the same cores deliver with the work handed out dynamically -- the larger, and the one reported as the baseline.
+    n = len(sample)
+    shard = [(n * (i + 1)) // P - (n * i) // P for i in range(P)]
+    rate_sum = sum(c / t for c, t in zip(shard, per) if t > 0)
+    return n / wall, wall, max(per), min(per), rate_sum
 
 
 def train_traffic(key, kernel):

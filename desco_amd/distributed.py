@@ -300,35 +300,49 @@ def gather_rows(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
 # inference: graph sharding
 # ------------------------------------------------------------------------------------------------
 def graph_costs(graphs: GraphSet, num_queries: int = 29, device=None, depth: int = 4) -> np.ndarray:
-    """Per-graph cost c(g) of one inference pass, for cutting a dataset into ranks' shards.
+    """Per-graph cost c(g) of one inference pass, for cutting a dataset into ranks' shards, in units of one
+    neighborhood row:   c = rows + 0.5 edges + 8 neighborhoods + (Q / 6) nodes.
 
-    The pass is dominated by the neighborhood stage, whose work is the number of neighborhood ROWS of the graph (every
-    node of every canonical neighborhood is a row of every SHMP layer); the gossip stage adds Q rows per node at about a
-    sixth of the price.  Measured on MI355X (bench.py secondary.*.strong_scaling_8, Syn_1827 x2): shard time =
-    2.0 ms + 1.4 ms per million neighborhood rows.  With a CUDA ``device`` the rows are EXACT: the device partition
-    builder (csrc/partition_dev.hip; 0.1 s for Syn_1827) counts them -- a size proxy cannot (the neighborhood of a
-    node of a dense 700-node graph has hundreds of rows, of a molecule nine: round 4's degree proxy gave the 8
-    Syn_1827 shards times between 2.7 and 16.5 ms, a predicted 8-GPU efficiency of 0.54).  Without a device (CPU
-    tests, planning tools) the proxy below stands in: sum over nodes of min(rank + 1, 4-hop ball bound) rows."""
+    The pass is dominated by the neighborhood stage: every node of every canonical neighborhood is a ROW of every SHMP
+    layer (a 64-wide output row and its share of the folded GEMM), every directed neighborhood EDGE a gathered source
+    row, every NEIGHBORHOOD a row of the anchor GEMM, the post-MLP and the head; the gossip stage adds Q rows per NODE
+    at about a sixth of the price.  Weights from MI355X timings of cost-balanced shards run one after another
+    (bench.py secondary.*.strong_scaling_8): with the rows alone equalised, a Syn_1827
+    shard of 1 607 small graphs (178 k neighborhoods, 45 M edges) took 10.5 ms against 8.7 ms for 54 large ones (61 k,
+    36 M).  With a CUDA ``device`` all four counts are EXACT: the device partition builder (csrc/partition_dev.hip;
+    0.1 s for Syn_1827) delivers them -- a size proxy cannot (the neighborhood of a node of a dense 700-node graph has
+    hundreds of rows, a molecule's nine: round 4's degree proxy gave the 8 Syn_1827 shards times between 2.7 and
+    16.5 ms, a predicted 8-GPU efficiency of 0.54).  Without a device (CPU tests, planning tools) a bound stands in:
+    rows = sum over nodes of min(rank + 1, 4-hop ball bound), one neighborhood per node, edges = 0.7 mean degree per row."""
     deg = np.diff(graphs.rowptr).astype(np.float64)
     gid = graphs.node_graph_ids()
+    G = graphs.num_graphs
     n_g = np.diff(graphs.graph_ptr).astype(np.float64)
-    rows = None
+    rows = neigh = edges = None
     if device is not None and str(device).startswith("cuda"):
         from .partition import build_partition_device
         try:
             part = build_partition_device(graphs, depth, device)
-            rows = np.bincount(part.neigh_index[:, 0], weights=np.diff(part.count_ptr).astype(np.float64) + 1.0,
-                               minlength=graphs.num_graphs)
-        except RuntimeError:          # a graph beyond the device builder's workspace: fall back to the proxy
+            ng = part.neigh_index[:, 0]
+            B = part.num_neigh
+            rows = np.bincount(ng, weights=np.diff(part.count_ptr).astype(np.float64) + 1.0, minlength=G)
+            neigh = np.bincount(ng, minlength=G).astype(np.float64)
+            per_row = np.diff(part.vrowptr.astype(np.int64)).reshape(-1, 4).sum(1).astype(np.float64)
+            owner = np.concatenate([np.repeat(np.arange(B), np.diff(part.count_ptr)), np.arange(B)])
+            edges = np.bincount(ng[owner], weights=per_row, minlength=G)
+        except RuntimeError:          # a graph beyond the device builder's workspace: fall back to the bound
             rows = None
     if rows is None:
         rank = np.arange(graphs.num_nodes, dtype=np.float64) - graphs.graph_ptr[:-1][gid] + 1.0
         d = np.maximum(deg, 1.0)
         ball = np.minimum(1.0 + d * (1.0 + (d - 1.0) * (1.0 + (d - 1.0) * (1.0 + (d - 1.0)))), n_g[gid])
-        rows = np.zeros(graphs.num_graphs)
+        rows = np.zeros(G)
         np.add.at(rows, gid, np.minimum(rank, ball))
-    return rows + (num_queries / 6.0) * n_g
+        neigh = n_g
+        mean_deg = np.zeros(G)
+        np.add.at(mean_deg, gid, deg)
+        edges = rows * 0.7 * mean_deg / np.maximum(n_g, 1.0)
+    return rows + 0.5 * edges + 8.0 * neigh + (num_queries / 6.0) * n_g
 
 
 def contiguous_shards(costs: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
