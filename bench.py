@@ -314,7 +314,9 @@ def train_traffic(key, kernel):
     (profiles/pmc_traffic.json, tools/profile_round.sh: FETCH_SIZE / WRITE_SIZE of `bench.py --train-only --train-leg ...`,
     averaged over every launch of the kernel in that run), or None."""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][key]["kernels"][kernel]
+        ks = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"][key]["kernels"]
+        # (the bf16 training products are the <WN, 1> instantiation of gemm_split_kernel: rocprofv3's name)
+        e = ks.get(kernel) or ks[{"gemm_bf16_kernel": "gemm_split_kernel"}[kernel]]
         return e["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
