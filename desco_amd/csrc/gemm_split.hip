@@ -42,17 +42,7 @@ struct GemmSplitArgs {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
-#ifndef GS_ABL
-#define GS_ABL 0
-#endif
-#if GS_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
-#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
-#endif
-#if GS_ABL == 1      // no split arithmetic (timing only)
-#define GS_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
-#else
 #define GS_SPLIT(a_, b_, h_, m_, l_) split2_bf16x3(a_, b_, h_, m_, l_)
-#endif
 
 constexpr int SBK = 32, SST = 32;              // SST: plane row stride in bf16 (64 B, no padding)
 // 16-byte chunk c (0..3) of plane row r sits at chunk c ^ ((r >> 3) & 3): conflict-free for the fragment
@@ -89,11 +79,7 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = g.k1 + g.k2;
-#if GS_ABL == 8
-  const int nchunks = g.m < 0 ? K / SBK : 0;
-#else
   const int nchunks = K / SBK;
-#endif
 
   // staging maps: A BM rows x 8 float4 -> 4 per thread; W planes BN rows x 4 uint4 -> BJ per plane
   const int arow = tid >> 3, ac4 = tid & 7;
@@ -192,33 +178,19 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
   DESCO_LOAD_W(0)
   DESCO_LOAD_A(rn, (nchunks > 1 ? 1 : 0) * SBK)
   for (int ch = 0; ch < nchunks; ++ch) {
-#if GS_ABL != 2
     if (ch > 0) __syncthreads();          // previous chunk's fragments have been read
-#endif
-#if GS_ABL == 4 || GS_ABL == 9
-    if (ch == 0)
-#endif
     DESCO_STORE_CHUNK()
-#if GS_ABL != 4 && GS_ABL != 9
     __syncthreads();
-#endif
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
     const int chnn = ch + 2 < nchunks ? ch + 2 : chn;
     ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;
-#if GS_ABL != 4 && GS_ABL != 5 && GS_ABL != 9
     DESCO_LOAD_W(chn * SBK)                // in flight under the MFMAs
-#endif
-#if GS_ABL != 4 && GS_ABL != 6 && GS_ABL != 9
     DESCO_LOAD_A(rn, chnn * SBK)           // two chunks ahead (HBM latency)
-#endif
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
     // (row + 32 i / 32 j keeps (row >> 3) & 3, so one swizzle per lane serves every tile)
     const int fsw = (lane >> 3) & 3, fh = lane >> 5;
     const short* ap = Ap + (wr * 64 + (lane & 31)) * SST;
     const short* bp = Bp + (wc * 32 * WN + (lane & 31)) * SST;
-#if GS_ABL == 3 || (GS_ABL >= 5 && GS_ABL < 9)
-    if (g.m < 0)
-#endif
     {
 #pragma unroll
     for (int s = 0; s < SBK / 16; ++s) {
@@ -307,11 +279,7 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
       const int row = idx / (8 * WN), c4 = idx % (8 * WN);
       const float4 v = *reinterpret_cast<const float4*>(st + 4 * idx);
       const int64_t grow = grow0 + row;
-#if GS_ABL == 9
-      if (grow < 0) {
-#else
       if (grow < g.m) {
-#endif
         float* o = crow + grow * g.ldc + 4 * c4;
         if (wide) {
           __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(o));

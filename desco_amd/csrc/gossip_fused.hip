@@ -162,10 +162,6 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
 }
 
 // weight block (64 n x 64 k, three planes): thread t moves 8 bf16 of row n = t>>3, chunk t&7, per plane
-#if GF_ABL == 6
-#define GF_WLOAD(base_, rows_total_, ldk_, nrow0_, koff_) {}
-#define GF_WSTORE(wb_) {}
-#else
 #define GF_WLOAD(base_, rows_total_, ldk_, nrow0_, koff_)                                          \
   {                                                                                                \
     const short* s_ = (base_) + (int64_t)((nrow0_) + (tid >> 3)) * (ldk_) + (koff_) + 8 * (tid & 7); \
@@ -180,7 +176,6 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
     *reinterpret_cast<uint4*>(d_ + WPLN) = q1;                                         \
     *reinterpret_cast<uint4*>(d_ + 2 * WPLN) = q2;                                     \
   }
-#endif
 // MFMA shape: v_mfma_f32_16x16x32_bf16.  At equal cycles per flop the chip holds a 12-14 % higher clock
 // under it than under v_mfma_f32_32x32x16_bf16 (tools/micro/mfma_peak.hip: 2.2 vs 1.94 PFLOP/s on random
 // data), and the swizzled plane layout is conflict-free for its fragment reads as it stands.
@@ -189,17 +184,7 @@ __device__ __forceinline__ int gf_pidx(const int row, const int k) {
 // W[32 wn + 16 i + r16][32 t + 8 q4 + 0..7] and X[32 wm + 16 j + r16][32 t + 8 q4 + 0..7] (16-byte
 // fragments), and after the MFMAs D^T[feature 32 wn + 16 i + 4 q4 + e][node 32 wm + 16 j + r16].
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-#ifndef GF_ABL
-#define GF_ABL 0
-#endif
-#if GF_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
-#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
-#endif
-#if GF_ABL == 1
-#define GF_M16(a_, b_, c_) { asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_)); }
-#else
 #define GF_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
-#endif
 // the six products (smallest terms first) of one weight tile w_ with both node tiles of x_
 #define GF_MM(c0_, c1_, w_, x_)                                       \
   GF_M16(w_##l, x_##0h, c0_) GF_M16(w_##l, x_##1h, c1_)               \
@@ -209,10 +194,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
   GF_M16(w_##h, x_##0m, c0_) GF_M16(w_##h, x_##1m, c1_)               \
   GF_M16(w_##h, x_##0h, c0_) GF_M16(w_##h, x_##1h, c1_)
 // X fragments of k step t_ (both node tiles, three planes) into register set s_
-#if GF_ABL == 5
-#define GF_LDX(s_, xa_, t_) { asm volatile("" : "+v"(s_##0h), "+v"(s_##0m), "+v"(s_##0l), "+v"(s_##1h), "+v"(s_##1m), "+v"(s_##1l)); }
-#define GF_LDW(s_, wa_, i_, t_) { asm volatile("" : "+v"(s_##h), "+v"(s_##m), "+v"(s_##l)); }
-#else
 #define GF_LDX(s_, xa_, t_)                                                                   \
   {                                                                                           \
     const int c_ = (((4 * (t_) + q4) ^ swz) & 7) << 3;                                        \
@@ -231,7 +212,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
     s_##m = *reinterpret_cast<const bf16x8*>((wa_) + (i_) * 16 * 64 + WPLN + c_);             \
     s_##l = *reinterpret_cast<const bf16x8*>((wa_) + (i_) * 16 * 64 + 2 * WPLN + c_);         \
   }
-#endif
 // 48 MFMAs of one 64x64 weight block: D^T[n][node] += sum_k W[n][k] X[node][k].  The fragments of
 // the next (feature tile, k step) are read while the MFMAs of the current one run.
 #define GF_MFMA_BLOCK(wb_, img_)                                                                   \
@@ -272,11 +252,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
     acc10 = f32x4{(s0_) * ub_.x + vb_.x, (s0_) * ub_.y + vb_.y, (s0_) * ub_.z + vb_.z, (s0_) * ub_.w + vb_.w}; \
     acc11 = f32x4{(s1_) * ub_.x + vb_.x, (s1_) * ub_.y + vb_.y, (s1_) * ub_.z + vb_.z, (s1_) * ub_.w + vb_.w}; \
   }
-#if GF_ABL == 4
-#define GF_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
-#else
 #define GF_SPLIT(a_, b_, h_, m_, l_) split2_bf16x3(a_, b_, h_, m_, l_)
-#endif
 // write 4 consecutive features (fb_ .. fb_+3) of node node_ as bf16 planes into image img_
 #define GF_PUT4(img_, node_, fb_, v0_, v1_, v2_, v3_)                                    \
   {                                                                                      \
@@ -296,10 +272,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
     GF_PUT4(img_, xrow_e, fq_e + 16, ACT_(acc10[0]), ACT_(acc10[1]), ACT_(acc10[2]), ACT_(acc10[3]))       \
     GF_PUT4(img_, xrow_e + 16, fq_e + 16, ACT_(acc11[0]), ACT_(acc11[1]), ACT_(acc11[2]), ACT_(acc11[3]))  \
   }
-#if GF_ABL == 7
-#undef GF_EPI
-#define GF_EPI(img_, ACT_) { asm volatile("" :: "v"(acc00), "v"(acc01), "v"(acc10), "v"(acc11)); }
-#endif
 #define GF_RELU(v_) ((v_) > 0.f ? (v_) : 0.f)
 #define GF_LEAKY01(v_) ((v_) > 0.f ? (v_) : 0.1f * (v_))
 
@@ -309,9 +281,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // launch can be replayed; launches take the 64 slots in turn (at most 64 launches in flight per device).
 constexpr int GF_QSLOTS = 64;
 __device__ unsigned long long gf_queue[GF_QSLOTS][2];
-#ifdef GF_TAIL      // tail probe (tools/debug): per block its start and end, 100 MHz ticks
-__device__ unsigned long long gf_tail[1024][2];
-#endif
 __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, int64_t num_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
   short* I0 = reinterpret_cast<short*>(gf_lds);          // h1, later y1
@@ -338,9 +307,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
   const int64_t nitems = num_tiles * Q;           // item = tile * Q + q: neighbours share a tile
   int64_t item = blockIdx.x;
   if (item >= nitems) return;
-#ifdef GF_TAIL
-  if (threadIdx.x == 0) gf_tail[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memrealtime();
-#endif
 
   for (int i = tid; i < 64; i += GNT) {
     cst[i] = g.u[i];
@@ -457,9 +423,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
           lo = lo < 0 ? 0 : lo;
           hi = hi > cnt ? cnt : hi;
           float2 a = hh[i];
-#if GF_ABL == 2 || GF_ABL == 3
-          if (g.Q < 0)
-#endif
           for (int e = lo; e < hi; ++e) {
             const float4 sj = escal[e];
             // (three dependent FMAs, z first: also keeps hipcc from selecting a packed multiply that takes the record's
@@ -485,9 +448,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
         }
         __syncthreads();
       }
-#if GF_ABL == 3
-      if (g.Q < 0)
-#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = tperm[wave * 16 + 2 * i + half1];
@@ -606,9 +566,6 @@ __global__ __launch_bounds__(GNT) void gossip_fused_kernel(GossipFusedArgs g, in
     g.queue[0] = 0;
     g.queue[1] = 0;
   }
-#ifdef GF_TAIL
-  if (threadIdx.x == 0) gf_tail[blockIdx.x & 1023][1] = __builtin_amdgcn_s_memrealtime();
-#endif
 #undef GF_STAGE1
 #undef GF_STAGE2
 #undef GF_STAGE3
@@ -712,13 +669,3 @@ extern "C" int desco_gossip_fused_f32(const float* scal4, const int32_t* rowptr,
   return launch_status("desco_gossip_fused_f32");
 }
 
-#ifdef GF_TAIL
-extern "C" int desco_debug_gf_tail(unsigned long long* out, int reset) {
-  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(desco::gf_tail), sizeof(unsigned long long) * 2048);
-  if (reset) {
-    static unsigned long long z[2048];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(desco::gf_tail), z, sizeof(z));
-  }
-  return 0;
-}
-#endif

@@ -257,11 +257,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // rows are 64 B with no padding: the 16-byte chunk k/8 of row r sits at chunk (k/8) ^ (-(r/4) & 3), which
 // makes both this write (ds_write_b64) and the fragment read conflict-free (ds_read_b128 is served in
 // the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: tools/micro/lds_banks.py)
-#if defined(SH16_ABL) && SH16_ABL == 2
-#define DESCO_SPLIT(a_, b_, h_, m_, l_) { h_ = m_ = l_ = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u); }
-#else
 #define DESCO_SPLIT(a_, b_, h_, m_, l_) split2_bf16x3(a_, b_, h_, m_, l_)
-#endif
 #define DESCO_PUT_X6(av_, it_)                                                  \
   {                                                                             \
     uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                      \
@@ -276,17 +272,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // 24 bf16 MFMAs (6-product split) of v_mfma_f32_16x16x32_bf16 on the staged half (32 k) of block b_: lane
 // (r = lane&15, q = lane>>4) holds A[row r][k = 8 q + 0..7] and B[k = 8 q + 0..7][col 16 t + r] of every
 // plane, t = 0..3 (the four 16-column tiles of the 64 outputs)
-#ifndef SH16_ABL
-#define SH16_ABL 0
-#endif
-#if SH16_ABL != 0 && !defined(DESCO_DEBUG_ABLATION)
-#error "timing-only ablation build: compile with -DDESCO_DEBUG_ABLATION (the library then reports a debug ABI version that desco_amd._lib refuses unless DESCO_ALLOW_DEBUG_LIB=1)"
-#endif
-#if SH16_ABL == 1        // timing-only builds (tools/debug/ab_libs.sh): 1 no MFMA, 2 no split arithmetic, 3 no output stores
-#define DESCO_M16(a_, b_, c_) { asm volatile("" : "+v"(c_) : "v"(a_), "v"(b_)); }
-#else
 #define DESCO_M16(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0);
-#endif
 #define DESCO_MFMA_HALF_X6(b_, h_)                                                                \
   {                                                                                               \
     const short* ap_ = Ap + (lane & 15) * APS + ((((lane >> 4) ^ (0 - (lane >> 2))) & 3) << 3);   \
@@ -430,9 +416,6 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 // source-row addresses then need a shift instead of a 64-bit multiply per gathered row, and the stores
 // of a tile are one address with immediate offsets
 // POOL: fused pooling epilogue (instantiated for the count-row launches only)
-#ifdef SH16_TAIL     // tail probe (tools/debug): per block its start and the end of its last wave, 100 MHz ticks
-__device__ unsigned long long sh16_tail[1024][2];
-#endif
 template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16>
 __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const int32_t* __restrict__ rowptr_s,
                                                               const uint32_t* __restrict__ pool_bits_s,
@@ -472,9 +455,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   }
   if (tid < 64) biasL[tid] = g.bias ? g.bias[tid] : 0.f;
   if (tid == 0) *next_sub = 0;
-#ifdef SH16_TAIL
-  if (tid == 0) sh16_tail[blockIdx.x & 1023][0] = __builtin_amdgcn_s_memrealtime();
-#endif
   __syncthreads();
 
   const int g8 = lane >> 3, l8 = lane & 7;                 // 8 groups of 8 lanes: one half row each
@@ -793,7 +773,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     }
     const int nru = __builtin_amdgcn_readfirstlane(nr_out);
 #define DESCO_ROW(r_) ((r_) < 4 ? q0[(r_) & 3] : (r_) < 8 ? q1[(r_) & 3] : (r_) < 12 ? q2[(r_) & 3] : q3[(r_) & 3])
-    if ((!POOL || g.out) && !(SH16_ABL == 3 && g.row0 >= 0)) {
+    if (!POOL || g.out) {
       float* ob = g.out + grow_out * LDO + lane;               // LD64: row r at the immediate offset 256 r
       if (nru == 16) {
 #pragma unroll
@@ -832,9 +812,6 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_ROW
     if (!has_next) break;
   }
-#ifdef SH16_TAIL
-  if (lane == 0) atomicMax(&sh16_tail[blockIdx.x & 1023][1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
 }
 
 
@@ -942,13 +919,3 @@ bool shmp16_launch(const ShmpArgs& g, int cus, void* stream) {
 
 }  // namespace desco
 
-#ifdef SH16_TAIL
-extern "C" int desco_debug_sh16_tail(unsigned long long* out, int reset) {
-  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(desco::sh16_tail), sizeof(unsigned long long) * 2048);
-  if (reset) {
-    static unsigned long long z[2048];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(desco::sh16_tail), z, sizeof(z));
-  }
-  return 0;
-}
-#endif

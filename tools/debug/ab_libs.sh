@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B whole-library builds on the SAME box: tools/debug/ab_libs.sh A B C ... [-- extra bench.py flags]
-# expects tools/debug/_ab/lib<name>.so (built in the container with different flags / -D switches; ablation switches need
+# expects tools/debug/_ab/lib<name>.so (built in the container with different flags, or from patched copies of a kernel
+# source as tools/debug/gf16_hazard/make_ablations.py does; such timing-only builds are compiled with
 # -DDESCO_DEBUG_ABLATION, which makes the library report a debug ABI version -- accepted here only); alternates
 # them twice through bench.py (DESCO_LIB) and prints ms per launch of every kernel above 2 % plus ms per step.
 LIBS=(); EXTRA=()
