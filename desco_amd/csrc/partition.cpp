@@ -357,7 +357,8 @@ extern "C" void desco_partition_free(desco_partition* p) { delete p; }
 // DESIGN.md section 2) and no sum over a neighborhood depends on it.  The layer kernel takes, per 16-row wave tile and
 // gathered relation slot, as many two-source steps as the tile's highest-degree row needs: rows sorted by degree put
 // similar rows into one tile.  Key: the neighborhood's heavier count -> count slot first, then the other one; the
-// direction alternates with the parity of neigh_key (graph id + node id: consecutive neighborhoods of a graph alternate),
+// direction alternates with the parity of neigh_key (the caller passes the canonical node's id inside its graph: consecutive
+// neighborhoods of a graph alternate, and the key does not depend on which shard or block holds the graph),
 // so a tile that spans a boundary joins the low ends (or the high ends) of both.  Measured: shmp_layer16 -9 % on Syn_1827 shapes, -3 % on MSRC-21 + IMDB shapes, +-0 on COX2 shapes.
 extern "C" int desco_partition_degree_sort(const int32_t* count_ptr, int64_t num_neigh, const int32_t* vrowptr,
                                            const int32_t* vcol, const int32_t* count_orig,

@@ -105,7 +105,7 @@ class NeighborhoodPartition:
 
     def degree_sorted(self, num_threads: int = 0) -> "NeighborhoodPartition":
         """The same block with the count rows of every neighborhood re-ordered by decreasing / increasing (by the parity
-        of graph id + node id, so consecutive neighborhoods alternate) number of count -> count sources (``desco_partition_degree_sort``): fewer
+        of the canonical node's id inside its graph, so consecutive neighborhoods alternate) number of count -> count sources (``desco_partition_degree_sort``): fewer
         gather steps per 16-row tile of the layer kernel on dense shapes.  Row order inside a neighborhood is a
         convention of this repo; per-neighborhood results only change by fp32 summation order."""
         if self.num_count == 0:
@@ -115,9 +115,12 @@ class NeighborhoodPartition:
         vc = np.ascontiguousarray(self.vcol, dtype=np.int32)
         co = np.ascontiguousarray(self.count_orig, dtype=np.int32)
         co2, vr2, vc2 = np.empty_like(co), np.empty_like(vr), np.empty_like(vc)
-        # direction by a neighborhood-intrinsic key (graph id + node id): the same neighborhood gets the same row
-        # order -- the same fp32 summation order -- wherever the block cuts fall
-        nkey = np.ascontiguousarray(self.neigh_index[:, 0].astype(np.int64) + self.neigh_index[:, 1].astype(np.int64))
+        # direction by a neighborhood-intrinsic key, the canonical node's id INSIDE ITS GRAPH: the same neighborhood gets
+        # the same row order -- the same fp32 summation order -- wherever the block cuts fall and whichever rank's shard
+        # holds the graph.  (Until round 5 the key was graph id + node id; graph ids are relative to the shard, so a
+        # shard that started at an odd graph flipped every direction and the 2-rank chunked run differed from the 1-rank
+        # run in the last bit -- tests/test_multirank_gpu.py caught it when the shard cuts moved.)
+        nkey = np.ascontiguousarray(self.neigh_index[:, 1].astype(np.int64))
         _lib.check(_lib.lib().desco_partition_degree_sort(
             cp.ctypes.data, self.num_neigh, vr.ctypes.data, vc.ctypes.data, co.ctypes.data, co2.ctypes.data,
             vr2.ctypes.data, vc2.ctypes.data, nkey.ctypes.data, num_threads), "desco_partition_degree_sort")

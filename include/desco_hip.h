@@ -81,8 +81,8 @@ void desco_partition_free(desco_partition* p);
 
 /* Optional re-ordering of a block's count rows (host arrays, same layout in and out): inside every neighborhood the
  * count rows are sorted by their number of count -> count sources (the neighborhood's heavier relation slot first,
- * descending when neigh_key[b] is even, ascending when odd -- pass graph id + node id so that the order is a property
- * of the neighborhood, not of its place in a block; NULL = the index b), vcol is relabelled and kept ascending inside a slot, count_orig
+ * descending when neigh_key[b] is even, ascending when odd -- pass the canonical node's id inside its graph so that the
+ * order is a property of the neighborhood, not of its place in a block or of the shard its graph is in; NULL = the index b), vcol is relabelled and kept ascending inside a slot, count_orig
  * follows the rows; count_ptr, the canonical rows and every per-neighborhood quantity are unchanged.  Row order inside a
  * neighborhood is this library's convention (data.py:375-396 leaves it to CPython set order), and the fused layer kernel
  * needs as many gather steps per 16-row tile as the tile's highest-degree row: -9 % on Syn_1827 shapes. */

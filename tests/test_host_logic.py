@@ -293,11 +293,11 @@ def _degree_sorted_numpy(part):
     v = part.vrowptr.astype(np.int64)
     deg4 = np.diff(v)[:4 * Nc].reshape(Nc, 4).astype(np.int64)
     seg = np.repeat(np.arange(B, dtype=np.int64), np.diff(part.count_ptr.astype(np.int64)))
-    # primary slot and direction are per NEIGHBORHOOD: its own slot totals, the parity of graph id + node id
+    # primary slot and direction are per NEIGHBORHOOD: its own slot totals, the parity of its node id inside the graph
     tot = np.zeros((B, 2), np.int64)
     np.add.at(tot, seg, deg4[:, :2])
     ps = (tot[:, 1] >= tot[:, 0]).astype(np.int64)[seg]
-    nkey = part.neigh_index[:, 0].astype(np.int64) + part.neigh_index[:, 1].astype(np.int64)
+    nkey = part.neigh_index[:, 1].astype(np.int64)
     sign = np.where(nkey[seg] % 2 == 1, 1, -1)
     rows = np.arange(Nc)
     key = sign * ((deg4[rows, ps] << 32) + deg4[rows, 1 - ps])
@@ -351,6 +351,16 @@ def test_degree_sorted_rows_keep_every_neighborhood_intact():
     cut = 37 if part.num_neigh > 80 else part.num_neigh // 2
     a, b = part.slice(0, cut).degree_sorted(), part.slice(cut, part.num_neigh).degree_sorted()
     assert (np.concatenate([a.count_orig, b.count_orig]) == whole.count_orig).all()
+    # ... nor on which rank's shard holds the graph: the partition of a sub-dataset that starts at an ODD graph (graph ids
+    # are relative to the shard) orders every neighborhood as the partition of the whole dataset does
+    gs = synthetic.syn_1827_shaped(9)
+    whole = build_partition(gs, 4).degree_sorted()
+    for g0 in (1, 4):
+        sub = build_partition(gs.subset(g0, gs.num_graphs), 4).degree_sorted()
+        first = int(np.searchsorted(whole.neigh_index[:, 0], g0))
+        tail = whole.slice(first, whole.num_neigh)
+        off = int(gs.graph_ptr[g0])                                        # count_orig holds dataset-wide node ids
+        assert (sub.count_orig + off == tail.count_orig).all() and (sub.vcol == tail.vcol).all(), g0
 
 
 @pytest.mark.parametrize("use_tconv", [True, False])
