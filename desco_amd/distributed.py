@@ -299,17 +299,24 @@ def gather_rows(local: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
 # ------------------------------------------------------------------------------------------------
 # inference: graph sharding
 # ------------------------------------------------------------------------------------------------
+# weights of (directed neighborhood edge, neighborhood, node at 29 queries) in units of one neighborhood row;
+# DESCO_COST_WEIGHTS="e,n,v" overrides them for tuning runs (bench.py secondary.*.strong_scaling_8 measures a choice)
+COST_WEIGHTS = tuple(float(x) for x in os.environ.get("DESCO_COST_WEIGHTS", "0.5,24,12").split(","))
+
+
 def graph_costs(graphs: GraphSet, num_queries: int = 29, device=None, depth: int = 4) -> np.ndarray:
     """Per-graph cost c(g) of one inference pass, for cutting a dataset into ranks' shards, in units of one
-    neighborhood row:   c = rows + 0.5 edges + 8 neighborhoods + (Q / 6) nodes.
+    neighborhood row:   c = rows + 0.5 edges + 24 neighborhoods + 12 (Q / 29) nodes      (COST_WEIGHTS).
 
     The pass is dominated by the neighborhood stage: every node of every canonical neighborhood is a ROW of every SHMP
     layer (a 64-wide output row and its share of the folded GEMM), every directed neighborhood EDGE a gathered source
     row, every NEIGHBORHOOD a row of the anchor GEMM, the post-MLP and the head; the gossip stage adds Q rows per NODE
-    at about a sixth of the price.  Weights from MI355X timings of cost-balanced shards run one after another
-    (bench.py secondary.*.strong_scaling_8): with the rows alone equalised, a Syn_1827
-    shard of 1 607 small graphs (178 k neighborhoods, 45 M edges) took 10.5 ms against 8.7 ms for 54 large ones (61 k,
-    36 M).  With a CUDA ``device`` all four counts are EXACT: the device partition builder (csrc/partition_dev.hip;
+    and each graph its share of the fixed per-launch work.  Weights from MI355X timings of cost-balanced shards run one
+    after another (bench.py secondary.*.strong_scaling_8; sweep in
+    profiles/r5_i_cost_weights.log): with the rows alone equalised, a Syn_1827 shard of 1 607 small graphs (178 k
+    neighborhoods, 45 M edges) took 10.5 ms against 8.7 ms for 54 large ones (61 k, 36 M); with (0.5, 8, 4.8) the slowest
+    of 8 shards was 5.8 % above the mean (predicted 8-GPU efficiency 0.945), with (0.5, 24, 12) 1.9 % (0.981; MSRC-21 +
+    IMDB 0.985).  With a CUDA ``device`` all four counts are EXACT: the device partition builder (csrc/partition_dev.hip;
     0.1 s for Syn_1827) delivers them -- a size proxy cannot (the neighborhood of a node of a dense 700-node graph has
     hundreds of rows, a molecule's nine: round 4's degree proxy gave the 8 Syn_1827 shards times between 2.7 and
     16.5 ms, a predicted 8-GPU efficiency of 0.54).  Without a device (CPU tests, planning tools) a bound stands in:
@@ -342,7 +349,8 @@ def graph_costs(graphs: GraphSet, num_queries: int = 29, device=None, depth: int
         mean_deg = np.zeros(G)
         np.add.at(mean_deg, gid, deg)
         edges = rows * 0.7 * mean_deg / np.maximum(n_g, 1.0)
-    return rows + 0.5 * edges + 8.0 * neigh + (num_queries / 6.0) * n_g
+    w_e, w_n, w_v = COST_WEIGHTS
+    return rows + w_e * edges + w_n * neigh + w_v * (num_queries / 29.0) * n_g
 
 
 def contiguous_shards(costs: np.ndarray, world_size: int) -> List[Tuple[int, int]]:

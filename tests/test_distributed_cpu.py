@@ -390,7 +390,8 @@ def _true_cost(gs, q=29):
     per_row = np.diff(part.vrowptr.astype(np.int64)).reshape(-1, 4).sum(1).astype(np.float64)
     owner = np.concatenate([np.repeat(np.arange(B), np.diff(part.count_ptr)), np.arange(B)])
     edges = np.bincount(ng[owner], weights=per_row, minlength=G)
-    return rows + 0.5 * edges + 8.0 * neigh + (q / 6.0) * np.diff(gs.graph_ptr)
+    w_e, w_n, w_v = D.COST_WEIGHTS
+    return rows + w_e * edges + w_n * neigh + w_v * (q / 29.0) * np.diff(gs.graph_ptr)
 
 
 @pytest.mark.parametrize("workload,replicas", [("cox2", 8), ("syn_1827", 1), ("msrc_imdb", 2)])
