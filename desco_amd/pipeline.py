@@ -36,7 +36,7 @@ def _split_by_budget(weights: np.ndarray, budget: int) -> List[int]:
 class InferencePipeline:
     def __init__(self, neigh_model, gossip_model, graphs: GraphSet, depth: int = 4,
                  device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 32_000_000,
-                 max_gossip_rows: int = 16_000_000, num_threads: int = 0,
+                 max_gossip_rows: int = 48_000_000, num_threads: int = 0,
                  partition: Optional[NeighborhoodPartition] = None,
                  partition_backend: str = "device", rank: Optional[int] = None,
                  world: Optional[int] = None, graph_replay_rows: int = 400_000,
