@@ -624,7 +624,7 @@ def main():
                     help="skip the short runs of the other workload shapes (Syn_1827, MSRC+IMDB)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the pass from a captured hipGraph (implies --no-profile)")
-    ap.add_argument("--neigh-rows", type=int, default=32_000_000,
+    ap.add_argument("--neigh-rows", type=int, default=48_000_000,
                     help="row budget of a neighborhood block (InferencePipeline max_neigh_rows)")
     ap.add_argument("--gossip-rows", type=int, default=48_000_000,
                     help="(node x query) row budget of a gossip block (InferencePipeline max_gossip_rows)")

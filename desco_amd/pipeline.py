@@ -35,7 +35,7 @@ def _split_by_budget(weights: np.ndarray, budget: int) -> List[int]:
 
 class InferencePipeline:
     def __init__(self, neigh_model, gossip_model, graphs: GraphSet, depth: int = 4,
-                 device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 32_000_000,
+                 device="cuda", quirk_batch: int = 0, max_neigh_rows: int = 48_000_000,
                  max_gossip_rows: int = 48_000_000, num_threads: int = 0,
                  partition: Optional[NeighborhoodPartition] = None,
                  partition_backend: str = "device", rank: Optional[int] = None,
@@ -60,7 +60,7 @@ class InferencePipeline:
         ``shard_graphs`` gives it.  A chunk's launches see the same rows in the same tiles whichever rank
         runs them, so N ranks reproduce the 1-rank result BIT FOR BIT (without it they agree to fp32
         rounding: a neighborhood's pooled partial sums depend on where 16-row tiles cut it).
-        Costs one launch set per chunk instead of one per 32 M-row block: off by default."""
+        Costs one launch set per chunk instead of one per 48 M-row block: off by default."""
         from . import distributed as D
         self.nm, self.gm = neigh_model, gossip_model
         self.rank = D.rank() if rank is None else int(rank)
