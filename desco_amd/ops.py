@@ -25,6 +25,7 @@ class LaunchProfiler:
     def __init__(self):
         self.enabled = False
         self.by_shape = False  # tools: key GEMM launches by shape as well ("kernel[m x k x n]")
+        self.only = None       # a set of kernel names: bracket only those launches (bench.py's timed region)
         self.records = []      # (kernel, flops, bytes, start_event, end_event, launches)
 
     def reset(self):
@@ -55,13 +56,14 @@ class _Timed:
         self.name, self.flops, self.bytes, self.launches = name, flops, nbytes, launches
 
     def __enter__(self):
-        if PROFILER.enabled:
+        self.e0 = None
+        if PROFILER.enabled and (PROFILER.only is None or self.name in PROFILER.only):
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if PROFILER.enabled:
+        if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             PROFILER.records.append((self.name, self.flops, self.bytes, self.e0, e1, self.launches))
