@@ -8,24 +8,29 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DESCO_LIB: another build of the same library (A/B runs of kernel variants, tools/debug/ab_libs.sh)
 LIB_PATH = os.environ.get("DESCO_LIB") or os.path.join(_HERE, "libdesco_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
 i64, i32, f32, f64 = c_int64, c_int, c_float, c_double
 vp = c_void_p
 
+class Dropout(ctypes.Structure):
+    """desco_dropout (include/desco_hip.h)"""
+    _fields_ = [("key", vp), ("site", c_uint32), ("threshold", c_uint32), ("scale", f32)]
+
+
 class GemmDesc(ctypes.Structure):
     """desco_gemm_desc (include/desco_hip.h)"""
     _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32), ("a2", vp), ("lda2", i64), ("k2", i32), ("wt", vp), ("n", i32),
                 ("bias", vp), ("bias_rows", i32), ("s", vp), ("ns", i32), ("ws", vp), ("act", i32), ("slope", f32),
                 ("c", vp), ("ldc", i64), ("m", i64), ("gate", vp), ("ldg", i64), ("gate_act", i32), ("gate_slope", f32),
-                ("accum", i32)]
+                ("accum", i32), ("drop", Dropout)]
 
 
 class BwdWDesc(ctypes.Structure):
@@ -136,6 +141,10 @@ SIGNATURES = {
                                          vp, vp, vp, vp]),
     "desco_affine_rows_f32": (c_int, [vp, vp, i32, vp, i32, i32, f32, vp, i64, vp]),
     "desco_affine_rows_bwd_f32": (c_int, [vp, i32, vp, i32, i64, vp, vp, vp]),
+    "desco_rng_next": (c_int, [vp, vp, vp]),
+    "desco_dropout_mask_f32": (c_int, [POINTER(Dropout), i64, i32, vp, i64, vp]),
+    "desco_affine_rows_dropout_f32": (c_int, [vp, vp, i32, vp, i32, i32, f32, POINTER(Dropout), vp, i64, vp]),
+    "desco_act_grad_dropout_f32": (c_int, [vp, vp, i32, f32, POINTER(Dropout), vp, i64, i32, vp]),
     "desco_rowdot2_f32": (c_int, [vp, vp, i32, vp, i64, vp]),
     "desco_rowdot_add_f32": (c_int, [vp, i64, i32, vp, f32, vp, vp, i64, vp]),
     "desco_copy2d_multi_f32": (c_int, [i32, POINTER(Copy2dDesc), vp]),

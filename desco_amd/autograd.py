@@ -387,28 +387,46 @@ class GossipTrunk(torch.autograd.Function):
     gradient), g1c = 1 - g1 and the raw post_mp.3 / .5 weights ([out, in]: the operands of dA = dZ W, no gradient asked
     of them here), then tensors with gradients: V0 [Q,6,64], g1 [Q], wt1 [128,64], V1 [Q,3,64], wtp [128,64],
     Vp [Q,2,64], w3t [64,64], b3 [64], w5t [64,256], b5 [256], w7 [256], b7 [1].
-    Returns pred [R] = x + post_mp.7(...)."""
+    Returns pred [R] = x + post_mp.7(...).
+
+    ``drop`` = None, or (p_layer, p_post) in training mode with --gossip_dropout > 0 (default 0.01, config.py:316):
+    F.dropout behind each layer's relu (gnn_model.py:274; sites 0, 1) and post_mp.1 = nn.Dropout between post_mp.0 and
+    its LeakyReLU (:46; site 2) ride in the epilogues that produce h1, h2 and y -- relu / leaky commute with the
+    non-negative factor -- as a counter-based factor of (step key, site, row, col) that the backward kernels regenerate
+    (csrc/common_device.hpp); no mask tensor exists.  The step's key is drawn here (ops.rng_next: capturable)."""
+
+    SITE_H1, SITE_H2, SITE_POST = 0, 1, 2
 
     @staticmethod
-    def forward(ctx, rowptr, col, n, q, C6, C3, C2, x, g1c, w3, w5, V0, g1, wt1, V1, wtp, Vp, w3t, b3, w5t, b5, w7, b7):
+    def forward(ctx, rowptr, col, n, q, C6, C3, C2, x, g1c, w3, w5, drop, V0, g1, wt1, V1, wtp, Vp, w3t, b3, w5t, b5, w7, b7):
         V0, V1, Vp = V0.contiguous(), V1.contiguous(), Vp.contiguous()
         wt1, wtp, w3t, w5t = wt1.contiguous(), wtp.contiguous(), w3t.contiguous(), w5t.contiguous()
         g1, b3, b5, w7 = g1.contiguous(), b3.contiguous(), b5.contiguous(), w7.contiguous()
-        h1 = ops.affine_rows(None, C6, V0, ops.ACT_RELU, 0.0)                       # layer 0 (closed form)
+        d1 = d2 = dp = None
+        key = C6.new_empty(0, dtype=torch.int64)
+        if drop is not None:
+            key = ops.rng_next(C6.device)
+            d1, d2 = ops.DropSite(key, GossipTrunk.SITE_H1, drop[0]), ops.DropSite(key, GossipTrunk.SITE_H2, drop[0])
+            dp = ops.DropSite(key, GossipTrunk.SITE_POST, drop[1])
+        h1 = ops.affine_rows(None, C6, V0, ops.ACT_RELU, 0.0, d1)                   # layer 0 (closed form)
         hh = ops.gossip_gather(h1, rowptr, col, n, q, g1)                           # layer 1 aggregate
-        h2 = ops.affine_rows(ops.gemm(hh, wt1, a2=h1), C3, V1, ops.ACT_RELU, 0.0)
-        y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1)   # post_mp.0 + .2
+        h2 = ops.affine_rows(ops.gemm(hh, wt1, a2=h1), C3, V1, ops.ACT_RELU, 0.0, d2)
+        y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1, dp)   # post_mp.0 + .1 + .2
         y3 = ops.gemm(y, w3t, b3, act=ops.ACT_RELU)
         y5 = ops.gemm(y3, w5t, b5, act=ops.ACT_RELU)
         pred = ops.affine_scalar(ops.rowdot_add(y5, w7, 0.0, None), add=b7, addv=x)
-        ctx.save_for_backward(rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5)
-        ctx.n, ctx.q = n, q
+        ctx.save_for_backward(rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5, key)
+        ctx.n, ctx.q, ctx.drop = n, q, drop
         return pred
 
     @staticmethod
     def backward(ctx, dcorr):
-        rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5 = ctx.saved_tensors
+        rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5, key = ctx.saved_tensors
         n, q = ctx.n, ctx.q
+        d1 = d2 = dp = None
+        if ctx.drop is not None:      # the same factors as the forward pass, from the same key
+            d1, d2 = ops.DropSite(key, GossipTrunk.SITE_H1, ctx.drop[0]), ops.DropSite(key, GossipTrunk.SITE_H2, ctx.drop[0])
+            dp = ops.DropSite(key, GossipTrunk.SITE_POST, ctx.drop[1])
         R = h1.shape[0]
         dev = h1.device
         dz5, dwb7 = ops.rowdot_bwd(y5, w7, dcorr.contiguous())                      # [R,256], (dw7 | db7)
@@ -421,12 +439,12 @@ class GossipTrunk(torch.autograd.Function):
         dz3 = torch.empty((R, 64), device=dev)
         ops.gemm_multi([dict(a1=dz5, wt=w5, out=dz3, gate=y3, gate_act=ops.ACT_RELU)])
         dzp = torch.empty((R, 64), device=dev)
-        ops.gemm_multi([dict(a1=dz3, wt=w3, out=dzp, gate=y, gate_act=ops.ACT_LEAKY, gate_slope=0.1)])
+        ops.gemm_multi([dict(a1=dz3, wt=w3, out=dzp, gate=y, gate_act=ops.ACT_LEAKY, gate_slope=0.1, drop=dp)])
         dVp = ops.affine_rows_bwd(C2, dzp, q)
         dh1 = torch.empty((R, 64), device=dev)
         dz1 = torch.empty((R, 64), device=dev)
         ops.gemm_multi([dict(a1=dzp, wt=wp[0], out=dh1),
-                        dict(a1=dzp, wt=wp[1], out=dz1, gate=h2, gate_act=ops.ACT_RELU)])
+                        dict(a1=dzp, wt=wp[1], out=dz1, gate=h2, gate_act=ops.ACT_RELU, drop=d2)])
         dV1 = ops.affine_rows_bwd(C3, dz1, q)
         dhh = torch.empty((R, 64), device=dev)
         ops.gemm_multi([dict(a1=dz1, wt=w1[0], out=dhh),
@@ -435,7 +453,7 @@ class GossipTrunk(torch.autograd.Function):
         ops.add_rows(dh1, ops.gossip_gather(dhh, rowptr, col, n, q, g1c))
         dsig = ops.gossip_gather(h1, rowptr, col, n, q, None)                       # d out / d g1
         dg1 = ops.colsum(ops.rowdot2(dhh, dsig).view(n, q))
-        dz0 = ops.act_grad(dh1, h1, ops.ACT_RELU, 0.0)
+        dz0 = ops.act_grad(dh1, h1, ops.ACT_RELU, 0.0, d1)
         dV0 = ops.affine_rows_bwd(C6, dz0, q)
         # the four weight / bias gradients wait for nothing and nothing but the optimizer waits for them: one launch pair
         dw5t, db5 = torch.empty((64, 256), device=dev), torch.empty((256,), device=dev)
@@ -443,8 +461,8 @@ class GossipTrunk(torch.autograd.Function):
         dwtp, dwt1 = torch.empty_like(wtp), torch.empty_like(wt1)
         ops.linear_bwd_w_multi([dict(a1=y3, dz=dz5, dwt=dw5t, dbias=db5), dict(a1=y, dz=dz3, dwt=dw3t, dbias=db3),
                                 dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
-        return (None, None, None, None, None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp, dw3t,
-                db3, dw5t, db5, dwb7[:256], dwb7[256:257])
+        return (None, None, None, None, None, None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp,
+                dw3t, db3, dw5t, db5, dwb7[:256], dwb7[256:257])
 
 
 class Mlp(torch.autograd.Function):

@@ -93,6 +93,55 @@ __device__ __forceinline__ float pow2_inverse(const float s) {
   return __uint_as_float((254u << 23) - (__float_as_uint(s) & 0x7f800000u));
 }
 
+// ---- counter-based dropout (round 6) -----------------------------------------------------------------------------
+// F.dropout / nn.Dropout of the training steps (gnn_model.py:274, 44-53 of the reference) without a stored mask: the
+// 32 random bits of element (row, col) of dropout call site `site` in optimisation step `step` are word (row & 3) of
+//   Philox4x32-10( counter = { row >> 2, col | site << 24, lo32(step), hi32(step) }, key = { lo32(seed), hi32(seed) } )
+// (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 round function and constants),
+// so that forward and backward regenerate the same mask from (seed, step) in device memory -- which is what makes the
+// step replayable from a hipGraph -- and one Philox call serves the four consecutive rows a lane holds of one column
+// in the C/D layout of the 32x32 MFMAs.  The element is DROPPED iff bits < threshold (= round(p 2^32)); kept elements
+// are multiplied by scale = 1 / (1 - p).  oracle/dropout.py restates this in numpy (known-answer vectors in its test).
+struct PhiloxOut {
+  uint32_t w[4];
+};
+__device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                   uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    c0 = h1 ^ c1 ^ k0;
+    c1 = l1;
+    c2 = h0 ^ c3 ^ k1;
+    c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return PhiloxOut{{c0, c1, c2, c3}};
+}
+// by-value form of desco_dropout for kernel arguments (key == nullptr: no dropout)
+struct DropArgs {
+  const uint64_t* key;
+  uint32_t site, threshold;
+  float scale;
+};
+__device__ __forceinline__ DropArgs no_dropout() { return DropArgs{nullptr, 0u, 0u, 1.f}; }
+// random words of rows 4*(row4) .. 4*(row4)+3 of column col
+__device__ __forceinline__ PhiloxOut dropout_bits4(const DropArgs& d, const uint64_t seed, const uint64_t step,
+                                                   const uint32_t row4, const uint32_t col) {
+  return philox4x32_10(row4, col | (d.site << 24), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                       (uint32_t)(seed >> 32));
+}
+// the factor of one element: 0 (dropped) or scale
+__device__ __forceinline__ float dropout_factor(const DropArgs& d, const uint64_t seed, const uint64_t step,
+                                                const int64_t row, const int col) {
+  const PhiloxOut o = dropout_bits4(d, seed, step, (uint32_t)(row >> 2), (uint32_t)col);
+  const int s = (int)(row & 3);
+  const uint32_t bits = s == 0 ? o.w[0] : s == 1 ? o.w[1] : s == 2 ? o.w[2] : o.w[3];
+  return bits < d.threshold ? 0.f : d.scale;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -43,6 +43,8 @@ struct GemmArgs {
   int gate_act;
   float gate_slope;
   int accum;
+  // dropout factor of (row, col) on the stored value (desco_dropout; regenerated from the step's key, never stored)
+  DropArgs drop;
 };
 
 constexpr int BM = 128, BN = 64, BK = 32, ASTR = 33;
@@ -149,6 +151,19 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, float* lds, con
     float wsv[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < g.ns; ++j) wsv[j] = g.ws[(int64_t)j * g.n + gcol];
     const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
+    // registers 4j..4j+3 of a lane are four consecutive rows (aligned to 4: m0 is a multiple of 128) of one column:
+    // one Philox call per register quad
+    float fac[16];
+    if (g.drop.key) {
+      const uint64_t seed = g.drop.key[0], step = g.drop.key[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t r4 = (m0 + wave * 32 + 8 * j + 4 * (lane >> 5)) >> 2;
+        const PhiloxOut o = dropout_bits4(g.drop, seed, step, (uint32_t)r4, (uint32_t)gcol);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fac[4 * j + i] = o.w[i] < g.drop.threshold ? 0.f : g.drop.scale;
+      }
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -163,6 +178,7 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, float* lds, con
         }
         for (int j = 0; j < g.ns; ++j) v += g.s[grow * g.ns + j] * wsv[j];
         v = apply_act(v, g.act, g.slope);
+        if (g.drop.key) v *= fac[reg];
         if (g.gate) {
           const float o_ = g.gate[grow * g.ldg + gcol];
           v = o_ > 0.f ? v : (g.gate_act == DESCO_ACT_RELU ? 0.f : g.gate_act == DESCO_ACT_LEAKY ? v * g.gate_slope : v);
@@ -201,6 +217,10 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mg) {
 
 }  // namespace desco
 
+namespace desco {
+const char* dropout_check(const desco_dropout* d, int64_t num_rows, int64_t num_cols);   // dropout.hip
+}
+
 static const char* gemm_f32_check(const desco::GemmArgs& g) {
   using namespace desco;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
@@ -223,7 +243,11 @@ extern "C" int desco_gemm_f32_multi(int num, const desco_gemm_desc* d, desco_str
     if (d[i].m == 0) continue;
     GemmArgs g{d[i].a1, d[i].lda1, d[i].k1, d[i].a2, d[i].lda2, d[i].k2, d[i].wt, d[i].n, d[i].bias,
                d[i].bias ? d[i].bias_rows : 1, d[i].s, d[i].ns, d[i].ws, d[i].act, d[i].slope, d[i].c, d[i].ldc, d[i].m,
-               d[i].gate, d[i].ldg, d[i].gate_act, d[i].gate_slope, d[i].accum};
+               d[i].gate, d[i].ldg, d[i].gate_act, d[i].gate_slope, d[i].accum,
+               DropArgs{d[i].drop.key, d[i].drop.site, d[i].drop.threshold, d[i].drop.scale}};
+    if (d[i].drop.key) {
+      if (const char* why = dropout_check(&d[i].drop, d[i].m, d[i].n)) return fail(DESCO_EINVAL, why);
+    }
     if (const char* why = gemm_f32_check(g)) {
       std::string msg = std::string("desco_gemm_f32_multi: ") + why;
       return fail(DESCO_EINVAL, msg.c_str());
@@ -253,7 +277,7 @@ extern "C" int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float
       lda1 % 4 || (k2 > 0 && lda2 % 4) || mis16(a1) || (k2 > 0 && mis16(a2)) || mis16(wt))
     return fail(DESCO_EINVAL, "desco_gemm_f32: bad argument (k%32, n%64, 16-byte alignment)");
   GemmArgs g{a1, lda1, k1, a2, lda2, k2, wt, n, bias, bias ? bias_rows : 1, s, ns, ws, act, slope,
-             c, ldc, m, nullptr, 0, 0, 0.f, 0};
+             c, ldc, m, nullptr, 0, 0, 0.f, 0, DropArgs{nullptr, 0u, 0u, 1.f}};
   const int64_t gm = (m + BM - 1) / BM;
   if (gm > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_f32: m too large");
   dim3 grid((unsigned)gm, (unsigned)(n / BN));

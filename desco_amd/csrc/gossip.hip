@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gossip_gather_kernel(const float* __restr
 __global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restrict__ base,
                                                           const float* __restrict__ C, int KS,
                                                           const float* __restrict__ V, int QV,
-                                                          int act, float slope,
+                                                          int act, float slope, DropArgs drop,
                                                           float* __restrict__ out, int64_t R) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restric
   const float* v = V + (int64_t)(r % QV) * KS * 64 + lane;
   float acc = base ? base[r * 64 + lane] : 0.f;
   for (int k = 0; k < KS; ++k) acc += C[r * KS + k] * v[k * 64];
-  out[r * 64 + lane] = apply_act(acc, act, slope);
+  acc = apply_act(acc, act, slope);
+  // dropout behind the activation (gnn_model.py:273-274; post_mp.1 in front of its LeakyReLU is the same thing: relu
+  // and leaky commute with a non-negative factor); the factor is regenerated in the backward pass, not stored
+  if (drop.key) acc *= dropout_factor(drop, drop.key[0], drop.key[1], r, lane);
+  out[r * 64 + lane] = acc;
 }
 
 // partial[slab][qv][k][c] = sum over rows r = i*QV + qv of the slab of C[r,k] * dZ[r,c]
@@ -207,17 +211,42 @@ extern "C" int desco_gossip_gather_f32(const float* h, const int32_t* rowptr, co
   return launch_status("desco_gossip_gather_f32");
 }
 
+namespace desco {
+const char* dropout_check(const desco_dropout* d, int64_t num_rows, int64_t num_cols);   // dropout.hip
+}
+
+static int affine_rows_launch(const char* who, const float* base, const float* c, int ks, const float* v, int qv,
+                              int act, float slope, const desco_dropout* d, float* out, int64_t num_rows,
+                              desco_stream_t stream) {
+  using namespace desco;
+  if (num_rows == 0) return 0;
+  if (!c || !v || !out || ks < 1 || ks > 8 || qv < 1 || num_rows < 0) {
+    std::string msg = std::string(who) + ": bad argument (1 <= ks <= 8)";
+    return fail(DESCO_EINVAL, msg.c_str());
+  }
+  const int64_t blocks = (num_rows + 3) / 4;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_affine_rows_f32: too many rows");
+  DropArgs da = DropArgs{nullptr, 0u, 0u, 1.f};
+  if (d) {
+    if (const char* why = dropout_check(d, num_rows, 64)) return fail(DESCO_EINVAL, why);
+    da = DropArgs{d->key, d->site, d->threshold, d->scale};
+  }
+  hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     base, c, ks, v, qv, act, slope, da, out, num_rows);
+  return launch_status(who);
+}
+
 extern "C" int desco_affine_rows_f32(const float* base, const float* c, int ks, const float* v,
                                      int qv, int act, float slope, float* out, int64_t num_rows,
                                      desco_stream_t stream) {
-  if (num_rows == 0) return 0;
-  if (!c || !v || !out || ks < 1 || ks > 8 || qv < 1 || num_rows < 0)
-    return fail(DESCO_EINVAL, "desco_affine_rows_f32: bad argument (1 <= ks <= 8)");
-  const int64_t blocks = (num_rows + 3) / 4;
-  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_affine_rows_f32: too many rows");
-  hipLaunchKernelGGL(affine_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     base, c, ks, v, qv, act, slope, out, num_rows);
-  return launch_status("desco_affine_rows_f32");
+  return affine_rows_launch("desco_affine_rows_f32", base, c, ks, v, qv, act, slope, nullptr, out, num_rows, stream);
+}
+
+extern "C" int desco_affine_rows_dropout_f32(const float* base, const float* c, int ks, const float* v, int qv, int act,
+                                             float slope, const desco_dropout* d, float* out, int64_t num_rows,
+                                             desco_stream_t stream) {
+  if (!d) return desco::fail(DESCO_EINVAL, "desco_affine_rows_dropout_f32: NULL dropout descriptor");
+  return affine_rows_launch("desco_affine_rows_dropout_f32", base, c, ks, v, qv, act, slope, d, out, num_rows, stream);
 }
 
 extern "C" int desco_affine_rows_bwd_f32(const float* c, int ks, const float* dz, int qv,

@@ -717,6 +717,10 @@ def _post_mp_train(AG, pk, gnn, pooled, drop):
 # -------------------------------------------------------------------------------------------------
 # gossip path
 # -------------------------------------------------------------------------------------------------
+# test switch: run the dropout form of the training kernels at p = 0 too (must not change a bit: factor 1 everywhere)
+DROPOUT_AT_ZERO = False
+
+
 def pack_gossip(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     core = gnn.gnn_core
     if core.layer_num != 2 or not core.input_pattern_emb or core.input_dim != 1:
@@ -834,7 +838,6 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     Same algebra as the fused kernel as autograd Functions whose forward and
     backward are C-ABI launches.  As in the reference, the layer-0 input is detached
     (gnn_model.py:236-240): ``pre_mp`` and the query embeddings receive no gradient."""
-    import torch.nn.functional as F
     from . import autograd as AG
     core = gnn.gnn_core
     if core.layer_num != 2 or not core.input_pattern_emb or core.input_dim != 1:
@@ -864,8 +867,12 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
             C2 = torch.stack([xr, one], 1).contiguous()
         cc = batch.__dict__["_train_consts"] = ((x, x._version), C6, C3, C2)
     _, C6, C3, C2 = cc
-    drop = gnn.training and core.dropout > 0
-    if not drop and Q <= 64:
+    # --gossip_dropout (default 0.01, config.py:316): F.dropout behind each layer's relu (gnn_model.py:274) and
+    # post_mp.1 = nn.Dropout (:46), in training mode only -- counter-based factors inside GossipTrunk's epilogues
+    p_layer = float(core.dropout or 0.0) if gnn.training else 0.0
+    p_post = float(gnn.post_mp[1].p or 0.0) if gnn.training else 0.0
+    drop = (p_layer, p_post) if (p_layer > 0.0 or p_post > 0.0 or (DROPOUT_AT_ZERO and gnn.training)) else None
+    if Q <= 64:
         # The operands folded from the parameters by one kernel each way (autograd.FoldGossip, csrc/train_native.hip;
         # algebra DESIGN.md 4.2), then the whole per-(node, query) pipeline and its backward as one autograd node
         # (autograd.GossipTrunk): the step launches nothing but this library's kernels.
@@ -876,11 +883,11 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
             gl[1][0].weight, gl[1][0].bias, gl[1][2].weight, gl[1][2].bias,
             gnn.post_mp[0].weight, gnn.post_mp[0].bias, gnn.post_mp[3].weight, gnn.post_mp[5].weight)
         pred = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, x.reshape(-1), g1c,
-                                    gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(),
+                                    gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(), drop,
                                     V0, g1, wt1, V1, wtp, Vp, w3t, gnn.post_mp[3].bias, w5t, gnn.post_mp[5].bias,
                                     gnn.post_mp[7].weight.view(-1), gnn.post_mp[7].bias)
         return pred.view(N, Q)
-    # ---- operands folded from the parameters with differentiable torch ops (dropout, or more than 64 queries) ----------
+    # ---- operands folded from the parameters with differentiable torch ops (more than 64 queries) ---------------------
     g0 = c0._gate_value(E).reshape(-1)
     g1 = c1._gate_value(E).reshape(-1)
     a_q = E @ C0[:, :H].t() + (_mv(C0[:, H:], b_pre) + cb0)
@@ -900,25 +907,9 @@ def gossip_forward_train(gnn: BaseGNN, batch: GossipBatch, query_emb: torch.Tens
     tp = _mv(P0[:, H:2 * H], w_pre).expand(Q, H)
     zp = E @ P0[:, :H].t() + (_mv(P0[:, H:2 * H], b_pre) + p0)
     Vp = torch.stack([tp, zp], 1)                                                   # [Q,2,64]
-    if not drop:
-        pred = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, x.reshape(-1), (1.0 - g1).detach().contiguous(),
-                                    gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(),
-                                    V0, g1, wt1, V1, wtp, Vp, gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias,
-                                    gnn.post_mp[5].weight.t(), gnn.post_mp[5].bias, gnn.post_mp[7].weight.view(-1),
-                                    gnn.post_mp[7].bias)
-        return pred.view(N, Q)
-    # ---- dropout (--gossip_dropout > 0): op-by-op autograd Functions, F.dropout where the reference applies it --------
-    h1 = F.dropout(AG.AffineRows.apply(None, C6, V0, ops.ACT_RELU, 0.0), p=core.dropout, training=True)        # :274
-    hh = AG.GossipGather.apply(h1, batch.rowptr, batch.col, N, Q, g1)
-    lin1 = AG.Linear.apply(hh, h1, wt1, None, ops.ACT_NONE, 0.0)
-    h2 = F.dropout(AG.AffineRows.apply(lin1, C3, V1, ops.ACT_RELU, 0.0), p=core.dropout, training=True)
-    linp = AG.Linear.apply(h1, h2, wtp, None, ops.ACT_NONE, 0.0)
-    y = AG.AffineRows.apply(linp, C2, Vp, ops.ACT_NONE, 0.0)
-    y = F.leaky_relu(F.dropout(y, p=gnn.post_mp[1].p, training=True), 0.1)         # post_mp.1 Dropout
-    y = AG.Linear.apply(y, None, gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias, ops.ACT_RELU, 0.0)
-    y = AG.Linear.apply(y, None, gnn.post_mp[5].weight.t(), gnn.post_mp[5].bias, ops.ACT_RELU, 0.0)
-    # post_mp.7 (256 -> 1) as a 64-wide GEMM whose columns 1..63 are zero
-    w7 = torch.cat([gnn.post_mp[7].weight.t(), torch.zeros(256, 63, device=dev)], 1)
-    b7 = torch.cat([gnn.post_mp[7].bias, torch.zeros(63, device=dev)])
-    corr = AG.Linear.apply(y, None, w7, b7, ops.ACT_NONE, 0.0)[:, 0]
-    return (x.reshape(-1) + corr).view(N, Q)
+    pred = AG.GossipTrunk.apply(batch.rowptr, batch.col, N, Q, C6, C3, C2, x.reshape(-1), (1.0 - g1).detach().contiguous(),
+                                gnn.post_mp[3].weight.detach(), gnn.post_mp[5].weight.detach(), drop,
+                                V0, g1, wt1, V1, wtp, Vp, gnn.post_mp[3].weight.t(), gnn.post_mp[3].bias,
+                                gnn.post_mp[5].weight.t(), gnn.post_mp[5].bias, gnn.post_mp[7].weight.view(-1),
+                                gnn.post_mp[7].bias)
+    return pred.view(N, Q)

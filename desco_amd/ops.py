@@ -229,8 +229,8 @@ def gemm(a1: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor] = None
 def gemm_multi(problems) -> None:
     """Up to four independent ``gemm`` problems in one launch (desco_gemm_f32_multi).  ``problems``: dicts with the
     keyword arguments of ``gemm`` (a1, wt, bias, a2, act, slope, out -- ``out`` required) plus, for the backward pass,
-    gate / gate_act / gate_slope (out = v * act'(gate), gate = the saved activation output) and accum (out += v); empty
-    ones (no rows) are skipped."""
+    gate / gate_act / gate_slope (out = v * act'(gate), gate = the saved activation output) and accum (out += v);
+    drop (a DropSite): the stored value times the dropout factor of its (row, col); empty ones (no rows) are skipped."""
     descs = (_lib.GemmDesc * len(problems))()
     flops = nbytes = 0.0
     for d, pr in zip(descs, problems):
@@ -258,6 +258,9 @@ def gemm_multi(problems) -> None:
             d.gate, d.ldg = _rows(gate, "gate")
             d.gate_act, d.gate_slope = pr["gate_act"], pr.get("gate_slope", 0.0)
         d.accum = int(bool(pr.get("accum", False)))
+        drop = pr.get("drop")
+        if drop is not None:          # (dropout factor of (row, col) on the stored value: DropSite.desc)
+            d.drop = drop.desc()
         flops += 2.0 * m * (k1 + k2) * n
         nbytes += 4.0 * (m * (k1 + k2) + (k1 + k2) * n + m * n)
     L = _lib.lib()
@@ -995,13 +998,21 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     return out
 
 
-def act_grad(dc: torch.Tensor, c: torch.Tensor, act: int, slope: float) -> torch.Tensor:
-    """dz = dc * act'(c) with c the activation OUTPUT (contiguous tensors of equal shape)."""
-    if act == ACT_NONE:
+def act_grad(dc: torch.Tensor, c: torch.Tensor, act: int, slope: float, drop: "Optional[DropSite]" = None) -> torch.Tensor:
+    """dz = dc * act'(c) with c the activation OUTPUT (contiguous tensors of equal shape); with ``drop`` the output was
+    dropout(act(z)) and dz = dc * factor * act'(c), the factor regenerated from the step's key."""
+    if act == ACT_NONE and drop is None:
         return dc
     dc, c = dc.contiguous(), c.contiguous()
     dz = torch.empty_like(dc)
     L = _lib.lib()
+    if drop is not None:
+        assert dc.dim() == 2
+        d = drop.desc()
+        with _Timed("act_grad_dropout_kernel", float(dc.numel()), 12.0 * dc.numel()):
+            _lib.check(L.desco_act_grad_dropout_f32(_dev(dc, "dc"), _dev(c, "c"), act, slope, ctypes.byref(d), _dev(dz, "dz"),
+                                                    dc.shape[0], dc.shape[1], _stream()), "act_grad_dropout")
+        return dz
     with _Timed("act_grad_kernel", float(dc.numel()), 12.0 * dc.numel()):
         _lib.check(L.desco_act_grad_f32(_dev(dc, "dc"), _dev(c, "c"), act, slope, _dev(dz, "dz"),
                                         dc.numel(), _stream()), "act_grad")
@@ -1030,8 +1041,9 @@ def count_head_bwd(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, slope: f
 
 
 def affine_rows(base: Optional[torch.Tensor], c: torch.Tensor, v: torch.Tensor, act: int,
-                slope: float) -> torch.Tensor:
-    """out[r,:] = act(base[r,:] + sum_k c[r,k] * v[r % QV, k, :]);  v: [QV, KS, 64], c: [R, KS]."""
+                slope: float, drop: "Optional[DropSite]" = None) -> torch.Tensor:
+    """out[r,:] = act(base[r,:] + sum_k c[r,k] * v[r % QV, k, :]);  v: [QV, KS, 64], c: [R, KS]; with ``drop`` the
+    result times the dropout factor of its (row, col) (desco_affine_rows_dropout_f32)."""
     R, ks = c.shape
     qv = v.shape[0]
     assert v.shape == (qv, ks, 64) and c.is_contiguous()
@@ -1041,9 +1053,15 @@ def affine_rows(base: Optional[torch.Tensor], c: torch.Tensor, v: torch.Tensor, 
         base = base.contiguous()
     L = _lib.lib()
     with _Timed("affine_rows_kernel", 2.0 * R * ks * 64, 4.0 * R * (ks + 128)):
-        _lib.check(L.desco_affine_rows_f32(_opt(base, "base"), _dev(c, "c"), ks, _dev(v, "v"), qv,
-                                           act, slope, _dev(out, "out"), R, _stream()),
-                   "affine_rows")
+        if drop is None:
+            _lib.check(L.desco_affine_rows_f32(_opt(base, "base"), _dev(c, "c"), ks, _dev(v, "v"), qv,
+                                               act, slope, _dev(out, "out"), R, _stream()),
+                       "affine_rows")
+        else:
+            d = drop.desc()
+            _lib.check(L.desco_affine_rows_dropout_f32(_opt(base, "base"), _dev(c, "c"), ks, _dev(v, "v"), qv, act, slope,
+                                                       ctypes.byref(d), _dev(out, "out"), R, _stream()),
+                       "affine_rows_dropout")
     return out
 
 
@@ -1224,3 +1242,67 @@ def fill(t: torch.Tensor, value: float) -> torch.Tensor:
 def zeros(shape, device) -> torch.Tensor:
     """torch.zeros without torch's fill kernel"""
     return fill(torch.empty(shape, device=device, dtype=torch.float32), 0.0)
+
+
+# ---- round 6: counter-based dropout (include/desco_hip.h: desco_dropout) ----------------------------------------------
+_RNG_STATE = {}
+
+
+def rng_state(device) -> torch.Tensor:
+    """(seed, step) of this device's dropout stream: two int64 words in device memory.  Seeded from
+    ``torch.initial_seed()`` on first use (so ``torch.manual_seed`` before the first training step selects the stream);
+    ``manual_seed`` resets it."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _RNG_STATE.get(device)
+    if st is None:
+        st = _RNG_STATE[device] = torch.tensor([torch.initial_seed() & 0x7fffffffffffffff, 0], dtype=torch.int64).to(device)
+    return st
+
+
+def manual_seed(seed: int, device=None, step: int = 0) -> None:
+    """Restart the dropout stream of ``device`` (default: the current one) at (seed, step)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    rng_state(device).copy_(torch.tensor([seed & 0x7fffffffffffffff, step], dtype=torch.int64))
+
+
+def rng_next(device) -> torch.Tensor:
+    """The key of one training forward pass: a fresh [2] int64 device tensor holding (seed, step); the device's step
+    counter moves on (desco_rng_next: one launch, capturable -- a replayed step draws the next mask)."""
+    st = rng_state(device)
+    key = torch.empty((2,), device=st.device, dtype=torch.int64)
+    L = _lib.lib()
+    with _Timed("rng_next_kernel", 0.0, 32.0):
+        _lib.check(L.desco_rng_next(_dev(st, "state", torch.int64), _dev(key, "key", torch.int64), _stream()), "rng_next")
+    return key
+
+
+class DropSite:
+    """One dropout call site of a step: (key tensor, site id, p)."""
+    __slots__ = ("key", "site", "p")
+
+    def __init__(self, key: torch.Tensor, site: int, p: float):
+        assert key.dtype == torch.int64 and key.numel() == 2 and key.is_contiguous() and 0 <= site < 256 and 0.0 <= p <= 1.0
+        self.key, self.site, self.p = key, site, float(p)
+
+    def desc(self) -> "_lib.Dropout":
+        d = _lib.Dropout()
+        d.key, d.site = _dev(self.key, "dropout key", torch.int64), self.site
+        if self.p >= 1.0:
+            d.threshold, d.scale = 0xffffffff, 0.0
+        else:
+            d.threshold = min(int(round(self.p * 4294967296.0)), 0xffffffff)
+            d.scale = 1.0 / (1.0 - self.p)
+        return d
+
+
+def dropout_mask(drop: DropSite, num_rows: int, num_cols: int) -> torch.Tensor:
+    """The factor tensor [num_rows, num_cols] (0 or 1 / (1 - p)) the fused epilogues multiply by."""
+    out = torch.empty((num_rows, num_cols), device=drop.key.device, dtype=torch.float32)
+    d = drop.desc()
+    L = _lib.lib()
+    with _Timed("dropout_mask_kernel", 0.0, 4.0 * num_rows * num_cols):
+        _lib.check(L.desco_dropout_mask_f32(ctypes.byref(d), num_rows, num_cols, _dev(out, "out"), num_cols, _stream()),
+                   "dropout_mask")
+    return out

@@ -33,7 +33,7 @@ class Trainer:
         self.precision = precision
         # graph_capture: after one eager epoch, every training batch's step (forward, backward, Adam)
         # is captured in a hipGraph and replayed in later epochs -- the ~400 launches of a step are
-        # host-bound otherwise.  Single process, models without dropout (the neighborhood model).
+        # host-bound otherwise.  Single process.
         self.graph_capture = graph_capture
         self.max_epochs = max_epochs
         self.root = default_root_dir
@@ -119,8 +119,9 @@ class Trainer:
         opt, sched = cfg["optimizer"], cfg["lr_scheduler"]
         ckpt = next((c for c in self.callbacks if isinstance(c, ModelCheckpoint)), None)
         os.makedirs(self.root, exist_ok=True)
-        use_graphs = (self.graph_capture and not multi and self.device.type == "cuda"
-                      and float(getattr(model, "dropout", 0.0) or 0.0) == 0.0)
+        # (dropout does not stand in the way of replay: the masks are functions of a (seed, step) pair in device memory
+        #  that a captured launch advances -- ops.rng_next -- so every replay draws the next mask)
+        use_graphs = self.graph_capture and not multi and self.device.type == "cuda"
         # shuffle=False (main.py:195): the batch stream is the same every epoch, so the device-resident
         # batches (and their backward indices) are built once.  Data parallel: optimisation step k
         # consumes the `world` consecutive batches [k*world, (k+1)*world), one per rank, weighted by

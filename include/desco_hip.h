@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DESCO_ABI_VERSION 5
+#define DESCO_ABI_VERSION 6
 #define DESCO_H 64
 
 #define DESCO_EINVAL (-1)
@@ -180,6 +180,21 @@ int desco_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64
                    int ns, const float* ws, int act, float slope, float* c, int64_t ldc,
                    int64_t m, desco_stream_t stream);
 
+/* Counter-based dropout of the training steps (F.dropout after every layer's relu, gnn_model.py:274; nn.Dropout =
+ * post_mp.1, gnn_model.py:44-53; --gossip_dropout defaults to 0.01, config.py:316).  No mask is stored: the 32 random
+ * bits of element (row, col) are word (row & 3) of
+ *   Philox4x32-10(counter = {row >> 2, col | site << 24, lo32(step), hi32(step)}, key = {lo32(seed), hi32(seed)})
+ * with (seed, step) = key[0], key[1] read from DEVICE memory by the kernel (desco_rng_next writes them), so forward and
+ * backward of one step see the same mask and a captured step draws a fresh mask on every replay.  The element is dropped
+ * iff bits < threshold; kept elements are multiplied by scale.  key == NULL: no dropout.
+ * Limits: row < 2^34, col < 2^24, site < 256. */
+typedef struct desco_dropout {
+  const uint64_t* key;  /* device, 2 words */
+  uint32_t site;        /* which dropout call of the step (independent streams) */
+  uint32_t threshold;   /* round(p * 2^32), p < 1 */
+  float scale;          /* 1 / (1 - p)   (0 with threshold 0xffffffff stands for p >= 1) */
+} desco_dropout;
+
 /* Up to four INDEPENDENT products of desco_gemm_f32's form in one launch (the count-row and canonical-row halves of a
  * training layer, lightning_model.py:228-254 through gnn_model.py:253-277: same step, disjoint rows, different
  * weights).  Field meaning as the arguments of desco_gemm_f32; descriptors with m == 0 are skipped. */
@@ -194,6 +209,10 @@ typedef struct desco_gemm_desc {
   /* backward use: c = v * act'(gate[row, col]) for gate = the saved activation OUTPUT (gate_act / gate_slope: its
    * activation; NULL: none) -- desco_act_grad_f32 fused into the epilogue; accum != 0: c += v instead of c = v */
   const float* gate; int64_t ldg; int gate_act; float gate_slope; int accum;
+  /* drop.key != NULL: the stored value is additionally multiplied by the dropout factor of (row, col) -- forward:
+   * dropout(act(..)) (relu / leaky commute with a non-negative factor, so Linear -> Dropout -> LeakyReLU of post_mp is
+   * this too); backward with a gate: dC * factor * act'(gate), the factor regenerated, not read */
+  desco_dropout drop;
 } desco_gemm_desc;
 int desco_gemm_f32_multi(int num, const desco_gemm_desc* descs, desco_stream_t stream);
 
@@ -589,6 +608,24 @@ int desco_affine_rows_bwd_f32(const float* c, int ks, const float* dz, int qv, i
                               float* dv, float* workspace, desco_stream_t stream);
 int desco_rowdot2_f32(const float* a, const float* b, int ncols, float* out, int64_t num_rows,
                       desco_stream_t stream);
+
+/* ---- round 6: dropout of the training steps (desco_dropout above) -------------------------------------------------- */
+
+/* key_out[0..1] = state[0..1] = (seed, step); state[1] += 1.  One launch per training forward pass: the step's kernels
+ * (forward and backward) read key_out, the next step gets the next counter -- also when the step is a replayed hipGraph. */
+int desco_rng_next(uint64_t* state, uint64_t* key_out, desco_stream_t stream);
+/* out[r, c] = the factor (0 or d->scale) of element (r, c): what the fused epilogues multiply by.  For tests (the oracle
+ * takes the mask as an input) and for callers that want the mask itself. */
+int desco_dropout_mask_f32(const desco_dropout* d, int64_t num_rows, int num_cols, float* out, int64_t ldo,
+                           desco_stream_t stream);
+/* desco_affine_rows_f32 followed by dropout: out = factor(r, c) * act(base + sum_k c[r,k] v[r % qv][k][:]) */
+int desco_affine_rows_dropout_f32(const float* base, const float* c, int ks, const float* v, int qv, int act,
+                                  float slope, const desco_dropout* d, float* out, int64_t num_rows,
+                                  desco_stream_t stream);
+/* desco_act_grad_f32 through a dropout: dz[r, c] = dc[r, c] * factor(r, c) * act'(c[r, c]) for c = factor * act(z)
+ * (contiguous [num_rows, num_cols]) */
+int desco_act_grad_dropout_f32(const float* dc, const float* c, int act, float slope, const desco_dropout* d,
+                               float* dz, int64_t num_rows, int num_cols, desco_stream_t stream);
 
 /* ---- round 5: the glue of the training steps (lightning_model.py:228-254, 285-289, 585-608, 630-635) ----------------- */
 

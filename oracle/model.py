@@ -79,9 +79,13 @@ def gnn_core_hetero(sd, prefix, feats: Dict[str, torch.Tensor], edge_index: Dict
     return emb
 
 
-def post_mp(sd, prefix, emb):
-    """BaseGNN.post_mp, gnn_model.py:44-53 (Dropout is the identity at inference / p=0)."""
+def post_mp(sd, prefix, emb, mask=None):
+    """BaseGNN.post_mp, gnn_model.py:44-53 (Dropout is the identity at inference / p=0).  ``mask``: the factor tensor
+    (0 or 1 / (1 - p) per element) of post_mp.1 = nn.Dropout in training mode, given by the caller -- torch draws it
+    from its own generator, the HIP path from a counter (oracle/dropout.py), so parity tests inject the HIP mask."""
     h = _lin(sd, f"{prefix}.post_mp.0", emb)
+    if mask is not None:
+        h = h * mask                                                                 # :46  (x * mask / (1 - p))
     h = F.leaky_relu(h, 0.1)
     h = F.relu(_lin(sd, f"{prefix}.post_mp.3", h))
     h = F.relu(_lin(sd, f"{prefix}.post_mp.5", h))
@@ -183,10 +187,12 @@ def gossip_gate(sd, key, query_emb):
     return F.leaky_relu(g)
 
 
-def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2):
+def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2, layer_masks=None, post_mask=None):
     """BaseGNN.forward (baseline == "gossip") for ONE query, gnn_model.py:58-109, 230-277, 303-350.
 
     ``x_col`` [N,1] neighborhood counts of this query, ``query_emb`` [1,H].  Returns [N,1].
+    Training mode with dropout (--gossip_dropout, default 0.01, config.py:316): ``layer_masks[l]`` [N,H] is the factor
+    tensor of F.dropout behind layer l's relu (:274), ``post_mask`` [N,H] that of post_mp.1 (:46).
     """
     N = x_col.shape[0]
     x = _lin(sd, "emb_model.gnn_core.pre_mp.0", x_col)                               # :231
@@ -203,8 +209,10 @@ def gossip_single_query(sd, x_col, edge_index, query_emb, layer_num=2):
         aggr = torch.zeros(N, msg.shape[1], dtype=msg.dtype).index_add_(0, ei[1], msg)               # aggr="add"
         x = _lin(sd, key + ".lin_update", torch.cat((aggr, x), dim=-1))             # :347-348
         x = F.relu(x)                                                               # :273
+        if layer_masks is not None:
+            x = x * layer_masks[l]                                                  # :274 (F.dropout, training)
         emb = torch.cat((emb, x), dim=1)                                            # :275
-    return post_mp(sd, "emb_model", emb)                                            # :102-103
+    return post_mp(sd, "emb_model", emb, post_mask)                                 # :102-103
 
 
 def gossip_query_loop(emb_fn, x, query_emb):
@@ -225,15 +233,25 @@ def gossip_loss_from_pred(pred, y):
                                   for q in range(pred.shape[1])]))
 
 
-def gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num=2):
-    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: 29 sequential passes."""
-    return gossip_query_loop(
-        lambda x_col, qe: gossip_single_query(sd, x_col, edge_index, qe, layer_num), x, query_emb)
+def gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num=2, masks=None):
+    """GossipCountingModel.graph_to_count, lightning_model.py:613-628: 29 sequential passes.
+    ``masks``: None, or (layer_masks, post_mask) with layer_masks[l] and post_mask of shape [N, Q, H] -- the dropout
+    factors of query q's pass are the [:, q, :] slices."""
+    if masks is None:
+        return gossip_query_loop(
+            lambda x_col, qe: gossip_single_query(sd, x_col, edge_index, qe, layer_num), x, query_emb)
+    lm, pm = masks
+    outs = []
+    for q in range(query_emb.shape[0]):                                             # gossip_query_loop with the q-th masks
+        x_col = x[:, q].view(-1, 1)
+        outs.append(x_col + gossip_single_query(sd, x_col, edge_index, query_emb[q, :].view(1, -1), layer_num,
+                                                [m[:, q, :] for m in lm], pm[:, q, :]))
+    return torch.cat(outs, dim=-1)
 
 
-def gossip_loss(sd, x, y, edge_index, query_emb, layer_num=2):
+def gossip_loss(sd, x, y, edge_index, query_emb, layer_num=2, masks=None):
     """train_forward + criterion, lightning_model.py:585-608, 630-635 (sum, not mean)."""
-    return gossip_loss_from_pred(gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num), y)
+    return gossip_loss_from_pred(gossip_graph_to_count(sd, x, edge_index, query_emb, layer_num, masks), y)
 
 
 def gossip_gate_values(sd, query_emb, layer_num=2):

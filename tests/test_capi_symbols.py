@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/desco_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert L.desco_abi_version() == _lib.ABI_VERSION == 5
+    assert L.desco_abi_version() == _lib.ABI_VERSION == 6
     assert L.desco_count_head_bwd_workspace(512, 29, 256) == 32 * 30 * 256 * 4
     assert L.desco_count_head_bwd_workspace(10 ** 6, 29, 256) == 1024 * 30 * 256 * 4
 
@@ -139,3 +139,25 @@ def test_shipped_isa_passes_the_operand_selection_rule():
     r = subprocess.run([sys.executable, tool, name], capture_output=True, text=True)
     os.unlink(name)
     assert r.returncode == 1 and "4 packed-fp32 instructions scanned, 2 with OP_SEL" in r.stdout, r.stdout
+
+
+def test_round6_entry_points_validate_their_arguments():
+    """Dropout entry points: bad arguments come back as DESCO_EINVAL with a message (no launch, no crash)."""
+    L = _lib.lib()
+    assert L.desco_rng_next(None, None, None) == -1 and b"desco_rng_next" in L.desco_last_error()
+    d = _lib.Dropout()
+    one = np.zeros(4, np.float32)
+    assert L.desco_dropout_mask_f32(ctypes.byref(d), 4, 1, one.ctypes.data, 1, None) == -1      # no key
+    assert b"dropout" in L.desco_last_error()
+    assert L.desco_dropout_mask_f32(ctypes.byref(d), 0, 64, None, 64, None) == 0                # nothing to do
+    key = np.zeros(2, np.uint64)
+    d.key, d.site = key.ctypes.data, 256
+    assert L.desco_dropout_mask_f32(ctypes.byref(d), 4, 1, one.ctypes.data, 1, None) == -1      # site out of range
+    assert b"site" in L.desco_last_error()
+    assert L.desco_affine_rows_dropout_f32(None, one.ctypes.data, 1, one.ctypes.data, 1, 0, 0.0, None,
+                                           one.ctypes.data, 1, None) == -1
+    assert b"desco_affine_rows_dropout_f32" in L.desco_last_error()
+    assert L.desco_act_grad_dropout_f32(None, None, 1, 0.0, ctypes.byref(d), None, 4, 64, None) == -1
+    assert b"desco_act_grad_dropout_f32" in L.desco_last_error()
+    g = (_lib.GemmDesc * 1)()
+    assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0 and _lib.GemmDesc.drop.offset % 8 == 0
