@@ -640,6 +640,7 @@ class FoldSpec:
             row += [add(core.convs[l][k].lin.bias) for k in uniq]
             rows.append(row)
         self.params = params
+        self._core, self._t, self._keys, self._uniq = core, t, keys, uniq
         offs, total = [], 0
         for p in params:
             if not p.is_contiguous() or p.dtype != torch.float32:
@@ -653,7 +654,23 @@ class FoldSpec:
         self.goff = torch.tensor([[offs[i] for i in row] for row in rows], dtype=torch.int64).to(dev)
 
     def valid(self):
-        return self.key == tuple(p.data_ptr() for p in self.params)
+        """Still the table of the module's LIVE parameters?  The module is walked again: a Parameter object replaced
+        since the table was built (load_state_dict(assign=True), a re-initialisation) leaves the captured object --
+        and its address -- untouched, so comparing the captured objects' addresses alone would keep folding the stale
+        storage and hand the gradients to orphaned tensors."""
+        core, t = self._core, self._t
+        live = []
+        for l in range(self.L):
+            live += [core.updates[l][t].weight, core.updates[l][t].bias]
+            live += [core.convs[l][k].lin.weight for k in self._keys]
+            live += [core.convs[l][k].lin.bias for k in self._uniq]
+        seen, uniq_live = set(), []
+        for p in live:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq_live.append(p)
+        return (len(uniq_live) == len(self.params) and all(a is b for a, b in zip(uniq_live, self.params))
+                and self.key == tuple(p.data_ptr() for p in self.params))
 
 
 class FoldShmp(torch.autograd.Function):
@@ -694,14 +711,21 @@ class FoldGossip(torch.autograd.Function):
     def forward(ctx, E, w_pre, b_pre, *ps):
         P = FoldGossip._pack(E, w_pre, b_pre, ps)
         O = ops.gossip_fold_fwd(P)
-        ctx.P, ctx.O = P, O
+        # inputs and outputs through save_for_backward (an output kept as a plain ctx attribute is a reference cycle
+        # output -> grad_fn -> ctx -> output: the step's autograd graph and its AccumulateGrad nodes then live until the
+        # cyclic collector runs -- on whatever stream that is -- which breaks a later capture on another stream)
+        ctx.okeys = tuple(O.keys())
+        ctx.save_for_backward(E, w_pre, b_pre, *ps, *[O[k] for k in ctx.okeys])
         ctx.mark_non_differentiable(O["g1c"])
         ctx.set_materialize_grads(False)        # (an absent gradient arrives as None, not as a zero fill of torch's)
         return O["V0"], O["g1"], O["g1c"], O["wt1"], O["V1"], O["wtp"], O["Vp"], O["w3t"], O["w5t"]
 
     @staticmethod
     def backward(ctx, dV0, dg1, _dg1c, dwt1, dV1, dwtp, dVp, dw3t, dw5t):
-        P, O = ctx.P, ctx.O
+        sv = ctx.saved_tensors
+        n_in = 3 + len(_GF_ORDER)
+        P = FoldGossip._pack(sv[0], sv[1], sv[2], sv[3:n_in])
+        O = dict(zip(ctx.okeys, sv[n_in:]))
         z = lambda t, like: ops.zeros(tuple(like.shape), like.device) if t is None else t.contiguous()   # noqa: E731
         dO = dict(dV0=z(dV0, O["V0"]), dV1=z(dV1, O["V1"]), dVp=z(dVp, O["Vp"]), dwt1=z(dwt1, O["wt1"]),
                   dwtp=z(dwtp, O["wtp"]), dw3t=z(dw3t, O["w3t"]), dw5t=z(dw5t, O["w5t"]),

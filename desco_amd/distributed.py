@@ -337,7 +337,12 @@ def graph_costs(graphs: GraphSet, num_queries: int = 29, device=None, depth: int
             per_row = np.diff(part.vrowptr.astype(np.int64)).reshape(-1, 4).sum(1).astype(np.float64)
             owner = np.concatenate([np.repeat(np.arange(B), np.diff(part.count_ptr)), np.arange(B)])
             edges = np.bincount(ng[owner], weights=per_row, minlength=G)
-        except RuntimeError:          # a graph beyond the device builder's workspace: fall back to the bound
+        except RuntimeError as e:
+            # ONLY "a graph beyond the device builder's per-wave LDS workspace" falls back to the bound; anything else
+            # (out of memory, a HIP error, a bad argument) is an error of this rank and must not silently give it other
+            # costs -- and so other shard cuts -- than its peers (shard_cuts lets one rank decide for all besides)
+            if isinstance(e, torch.cuda.OutOfMemoryError) or "does not fit the LDS workspace" not in str(e):
+                raise
             rows = None
     if rows is None:
         rank = np.arange(graphs.num_nodes, dtype=np.float64) - graphs.graph_ptr[:-1][gid] + 1.0
@@ -368,8 +373,34 @@ def contiguous_shards(costs: np.ndarray, world_size: int) -> List[Tuple[int, int
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-def shard_graphs(graphs: GraphSet, rank: int, world_size: int, num_queries: int = 29, device=None):
-    lo, hi = contiguous_shards(graph_costs(graphs, num_queries, device), world_size)[rank]
+def shard_cuts(graphs: GraphSet, parts: int, num_queries: int = 29, device=None, depth: int = 4,
+               agree: bool = False) -> List[Tuple[int, int]]:
+    """The ``parts`` contiguous graph ranges of equal cost.  ``agree=True`` (callers that act as a rank of the process
+    group: every rank makes this call): rank 0 computes the cuts and broadcasts them, so that all ranks use the SAME
+    cuts whatever happens to one of them (a rank that fell back to the cost bound, or that runs another weight setting,
+    would otherwise drop or duplicate the graphs between its cuts and its neighbours'); a failure on rank 0 is raised
+    on every rank instead of leaving the others in the collective."""
+    if not (agree and is_initialized() and world_size() > 1):
+        return contiguous_shards(graph_costs(graphs, num_queries, device, depth), parts)
+    res = None
+    if rank() == 0:
+        try:
+            res = ("ok", contiguous_shards(graph_costs(graphs, num_queries, device, depth), parts))
+        except Exception as e:          # noqa: BLE001  (handed to every rank below)
+            res = ("error", f"{type(e).__name__}: {e}")
+    res = broadcast_object(res, 0)
+    if res[0] != "ok":
+        raise RuntimeError("rank 0 could not compute the shard cuts: " + res[1])
+    cuts = [tuple(c) for c in res[1]]
+    if len(cuts) != parts or cuts[0][0] != 0 or cuts[-1][1] != graphs.num_graphs:
+        raise RuntimeError(f"shard cuts from rank 0 do not cover this rank's dataset ({graphs.num_graphs} graphs): "
+                           "the ranks hold different datasets")
+    return cuts
+
+
+def shard_graphs(graphs: GraphSet, rank: int, world_size: int, num_queries: int = 29, device=None, depth: int = 4,
+                 agree: bool = False):
+    lo, hi = shard_cuts(graphs, world_size, num_queries, device, depth, agree)[rank]
     return graphs.subset(lo, hi), (lo, hi)
 
 

@@ -247,6 +247,68 @@ class BaseGNNCore(nn.Module):
                     raise KeyError(f"edge type {et} not in model metadata")
         return keys
 
+    def forward(self, x, edge_index, query_emb=None):
+        """``BaseGNNCore.forward(x, edge_index, query_emb=None)`` with the reference's arguments and return value
+        (gnn_model.py:230-277): pre_mp, then per layer conv -> (SAGE: updates[i](cat(x_neigh, x))) -> relu -> dropout
+        -> running cat, op by op on this library's kernels (the stand-alone ``SAGEConv.forward`` /
+        ``GossipConv.forward`` + ``ops.gemm``).  Inference only (no autograd); ``BaseGNN.forward`` -- what the models
+        call -- runs the same layers as fused kernels on the canonical-partition batches.
+
+        SAGE after ``to_hetero``: ``x`` = {node type: [n_t, input_dim]}, ``edge_index`` = {(src, rel, dst): [2, E]} with
+        indices local to their node types; returns {node type: [n_t, 64 (L + 1)]}; the relations into one destination
+        type are summed pairwise in metadata order (pyg.nn.to_hetero(aggr="sum")).  GOSSIP: ``x`` [N, input_dim],
+        ``edge_index`` [2, E], ``query_emb`` [1, 64] of ONE query; returns [N, 64 (L + 2)]."""
+        from collections import deque
+        with torch.no_grad():
+            if self.conv_type == "GOSSIP":
+                dev = x.device
+                lin = self.pre_mp[0]
+                h = ops.linear_smallk(x.float().contiguous(), ops.transposed(lin.weight), lin.bias)       # :231
+                if self.input_pattern_emb:                                                                # :233-240
+                    if query_emb is None:
+                        raise AssertionError("query_emb is required (input_pattern_emb)")
+                    h = torch.cat((query_emb.reshape(1, -1).float().to(dev).expand(h.shape[0], -1), h), dim=-1)
+                ei = edge_index[:, edge_index[0] != edge_index[1]] if edge_index.numel() else edge_index  # :246
+                ei = torch.unique(torch.cat([ei, ei.flip(0)], 1), dim=1) if ei.numel() else ei            # :247
+                ew = ei[0] < ei[1]                                                                        # :248
+                emb = h
+                for l, conv in enumerate(self.convs):
+                    h = conv(h.contiguous(), ei, edge_weight=ew, query_emb=query_emb)                     # :257-260
+                    h = self._relu_dropout(h, l)                                                          # :273-274
+                    emb = torch.cat((emb, h), 1)                                                          # :275
+                return emb
+            if self.node_types is None:
+                raise NotImplementedError("homogeneous SAGE (ablation) is out of the hot path; call to_hetero first")
+            xs = {t: ops.linear_smallk(x[t].float().contiguous(), ops.transposed(self.pre_mp[0][t].weight),
+                                       self.pre_mp[0][t].bias) for t in self.node_types}
+            emb = dict(xs)
+            for l in range(self.layer_num):
+                outs = {t: deque() for t in self.node_types}
+                for (s, r, d) in self.edge_types:
+                    ei = edge_index.get((s, r, d))
+                    outs[d].append(self.convs[l]["__".join((s, r, d))]((xs[s], xs[d]), ei))               # :262
+                new = {}
+                for t in self.node_types:
+                    q = outs[t]
+                    while len(q) >= 2:                      # to_hetero's pairwise sum over a common destination
+                        q.append(q.popleft() + q.popleft())
+                    up = self.updates[l][t]
+                    hcat = ops.gemm(q[0], ops.transposed(up.weight), up.bias, a2=xs[t].contiguous())      # :264
+                    new[t] = self._relu_dropout(hcat, l, t)
+                xs = new
+                emb = {t: torch.cat((emb[t], xs[t]), dim=1) for t in self.node_types}
+            return emb
+
+    def _relu_dropout(self, h, layer, node_type=None):
+        """relu (gnn_model.py:273) and, in training mode with dropout > 0, F.dropout (:274) as this library's
+        counter-based factor (ops.dropout_mask) -- one key per call, the site id separates layers / node types."""
+        h = torch.relu(h)
+        p = float(self.dropout or 0.0)
+        if self.training and p > 0.0 and h.numel():
+            site = 16 * layer + (0 if node_type is None else 1 + self.node_types.index(node_type))
+            h = h * ops.dropout_mask(ops.DropSite(ops.rng_next(h.device), site % 256, p), h.shape[0], h.shape[1])
+        return h
+
 
 class BaseGNN(nn.Module):
     """core + anchor MLP + pool + post MLP (gnn_model.py:18-112)."""
@@ -614,6 +676,9 @@ def fold_shmp_native(gnn: BaseGNN, t: str):
     specs = gnn.__dict__.setdefault("_fold_specs", {})
     sp = specs.get(t)
     if sp is None or not sp.valid():
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fold_shmp_native: the parameter address table has to be (re)built, which uploads it -- "
+                               "not inside a hipGraph capture; run one eager step after replacing parameters")
         sp = specs[t] = AG.FoldSpec(gnn.gnn_core, t)
     return AG.FoldShmp.apply(sp, *sp.params)
 

@@ -1140,16 +1140,15 @@ def fold_shmp_bwd(table: torch.Tensor, goff: torch.Tensor, L: int, S: int, NU: i
                                                       _stream()), "fold_shmp_bwd")
 
 
-_LOSS_WS = {}
-
-
 def loss_fwd(pred: torch.Tensor, y: torch.Tensor, mode: int):
     """(loss [] , dpred) of desco_loss_f32: mode 0 = mean smooth_l1(pred - log2(y + 1)), mode 1 = sum log2(|pred - y| + 1)"""
-    assert pred.is_contiguous() and y.is_contiguous() and pred.shape == y.shape and pred.numel() > 0
+    assert pred.is_contiguous() and y.is_contiguous() and pred.shape == y.shape
     dev = pred.device
-    ws = _LOSS_WS.get(dev)
-    if ws is None:
-        ws = _LOSS_WS[dev] = torch.empty(1024, device=dev, dtype=torch.float32)
+    if pred.numel() == 0:               # an empty batch: the loss of nothing is 0 (what the torch criterion's sum gives)
+        return zeros((), dev), torch.empty_like(pred)
+    # the partial sums' workspace (4 KB) is allocated per call from torch's stream-aware caching allocator: one buffer
+    # per device would be shared by every stream that trains on it (Trainer's side stream, two models side by side)
+    ws = torch.empty(1024, device=dev, dtype=torch.float32)
     loss = torch.empty((), device=dev, dtype=torch.float32)
     dpred = torch.empty_like(pred)
     with _Timed("loss_partial_kernel", 0.0, 12.0 * pred.numel()):

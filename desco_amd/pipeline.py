@@ -63,6 +63,8 @@ class InferencePipeline:
         Costs one launch set per chunk instead of one per 48 M-row block: off by default."""
         from . import distributed as D
         self.nm, self.gm = neigh_model, gossip_model
+        # rank / world taken from the process group: every rank builds its pipeline, and rank 0 decides the cuts for all
+        agree = rank is None and world is None
         self.rank = D.rank() if rank is None else int(rank)
         self.world = D.world_size() if world is None else int(world)
         if not 0 <= self.rank < self.world:
@@ -77,7 +79,7 @@ class InferencePipeline:
                 raise ValueError(f"chunks = {self.chunks} must be a positive multiple of world = {self.world}")
             if partition is not None:
                 raise ValueError("chunks: let the pipeline build the partition")
-            ranges = D.contiguous_shards(D.graph_costs(graphs, Q0, device), self.chunks)
+            ranges = D.shard_cuts(graphs, self.chunks, Q0, device, depth, agree)
             per = self.chunks // self.world
             mine = ranges[self.rank * per:(self.rank + 1) * per]
             self.graph_range = (mine[0][0], mine[-1][1])
@@ -86,7 +88,7 @@ class InferencePipeline:
         elif self.world > 1:
             if partition is not None:
                 raise ValueError("pass the partition of the local shard, or let the pipeline build it")
-            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q0, device)
+            graphs, self.graph_range = D.shard_graphs(graphs, self.rank, self.world, Q0, device, depth, agree)
         self.graphs = graphs
         self._chunk_cuts = chunk_cuts
         from .batch import _norm_device

@@ -131,6 +131,19 @@ def _worker(rank, world, port, q, tmp):
         res["full"] = D.gather_rows(_fake_stage(shard), dst=0)
         res["full_all"] = D.allgather_rows(_fake_stage(shard))
         res["range"] = (lo, hi)
+        # agree=True: rank 0 decides the cuts.  Rank 1 is given other cost weights (the stand-in for "fell back to the
+        # bound" / "ran short of memory"): alone it cuts elsewhere, in agreement it uses rank 0's cuts
+        if rank == 1:
+            D.COST_WEIGHTS = (5.0, 0.0, 300.0)
+        res["cuts_alone"] = D.shard_cuts(gs, 3)
+        res["cuts_agreed"] = D.shard_cuts(gs, 3, agree=True)
+        D.COST_WEIGHTS = (0.5, 24.0, 12.0)
+        sub = gs if rank == 0 else gs.subset(0, gs.num_graphs - 1)      # ranks holding different datasets: an error
+        try:
+            D.shard_cuts(sub, 3, agree=True)
+            res["cuts_mismatch"] = "no error"
+        except RuntimeError as e:
+            res["cuts_mismatch"] = str(e)
         # one-shot gradient all-reduce
         torch.manual_seed(0)
         lin = torch.nn.Linear(4, 3)
@@ -224,6 +237,31 @@ def test_sharded_inference_gather_and_grad_allreduce(world2):
     # mean of per-rank grads: rank r contributes 5*(r+1) per weight entry
     assert torch.allclose(r0["wgrad"], torch.full((3, 4), 5 * (1 + 2) / 2))
     assert torch.equal(r0["ugrad"], torch.zeros(2, 2))                   # unused params -> zeros
+
+
+def test_shard_cuts_are_decided_by_rank_0_for_all(world2):
+    """nothing checked that ranks agree on the shard cuts."""
+    a0, a1 = world2[0]["cuts_alone"], world2[1]["cuts_alone"]
+    assert a0 != a1                                        # the divergent rank would have cut elsewhere
+    assert world2[0]["cuts_agreed"] == world2[1]["cuts_agreed"] == a0
+    assert world2[0]["cuts_mismatch"] == "no error" and "different datasets" in world2[1]["cuts_mismatch"]
+
+
+def test_graph_costs_reraises_everything_but_the_workspace_error(monkeypatch):
+    """Only "largest graph does not fit the LDS workspace" may fall back to the cost bound."""
+    import desco_amd.partition as P
+    gs = GraphSet.from_edge_lists(golden_graphs(max_n=20))
+
+    def boom(msg):
+        def f(*a, **k):
+            raise RuntimeError(msg)
+        return f
+    monkeypatch.setattr(P, "build_partition_device", boom("libdesco_hip x failed (code -1): desco_partition_dev: largest "
+                                                          "graph does not fit the LDS workspace (n = 9999)"))
+    assert np.array_equal(D.graph_costs(gs, 29, "cuda:0"), D.graph_costs(gs, 29))
+    monkeypatch.setattr(P, "build_partition_device", boom("HIP error: out of memory"))
+    with pytest.raises(RuntimeError, match="out of memory"):
+        D.graph_costs(gs, 29, "cuda:0")
 
 
 def test_bucketed_weighted_gradients_equal_union_batch_gradient(world2):

@@ -40,7 +40,7 @@ def test_driver_trains_and_writes_reference_artifacts(tmp_path):
     config.parse_gossip(p)
     args = p.parse_args(["--train_dataset", "TOY_train", "--valid_dataset", "TOY_val", "--test_dataset",
                          "TOY_test", "--neigh_epoch_num", "2", "--gossip_epoch_num", "2",
-                         "--gossip_dropout", "0.0", "--neigh_batch_size", "64", "--gossip_batch_size", "4",
+                         "--neigh_batch_size", "64", "--gossip_batch_size", "4",      # (--gossip_dropout: default 0.01)
                          "--neigh_model_path", str(tmp_path / "ckpt_n"), "--gossip_model_path",
                          str(tmp_path / "ckpt_g"), "--train_neigh", "--train_gossip", "--test_gossip",
                          "--output_dir", str(tmp_path / "out")])
@@ -80,7 +80,7 @@ def test_driver_with_two_gpus_starts_its_own_ranks(tmp_path):
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(repo, "main.py"), "--gpu", "0", "1", "--data_root", root,
            "--train_dataset", "TOY_train", "--valid_dataset", "TOY_val", "--test_dataset", "TOY_test",
-           "--neigh_epoch_num", "2", "--gossip_epoch_num", "1", "--gossip_dropout", "0.0",
+           "--neigh_epoch_num", "2", "--gossip_epoch_num", "1",
            "--neigh_batch_size", "32", "--gossip_batch_size", "2",
            "--neigh_model_path", str(tmp_path / "ckpt_n"), "--gossip_model_path", str(tmp_path / "ckpt_g"),
            "--train_neigh", "--train_gossip", "--test_gossip", "--output_dir", str(tmp_path / "out")]

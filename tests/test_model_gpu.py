@@ -945,3 +945,77 @@ def test_gossip_kernel_200_launches_bit_identical(setup):
             bad += int((gm.graph_to_count(gb).view(torch.int32) != ref.view(torch.int32)).sum())
     print(f"[stress] 200 launches x {N * Q} results: {bad} differ from the first launch")
     assert bad == 0
+
+
+def test_logit_error_split_by_arithmetic_form(setup):
+    """where the 1.5e-5 logit error against the oracle comes from.  The same batch through the three
+    arithmetic forms of the matrix products -- f16x3 (default), bf16x6, and the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32:
+    bitwise an fmaf chain) -- all three with this library's summation orders (folded weights, fused gathers, pooling
+    partials).  If the fp32-MFMA form is as far from the oracle as the split forms, the error is re-association, not
+    the split arithmetic; the forms' distance from EACH OTHER is the arithmetic's share."""
+    import desco_amd.gnn_model as GM
+    nm, _, qids, queries = setup
+    graphs = golden_graphs(max_n=41)[:16]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    batch = NeighborhoodBatch(part.slice(0, min(512, part.num_neigh)), DEV)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs[:batch.num_graphs]), OP.query_batch(queries),
+                                    emulate_quirk=False)
+    saved = (GM.GEMM_F16X3, GM.SHMP_F16X3, GM.GEMM_BF16X6, GM.SHMP_BF16X6)
+    outs = {}
+    try:
+        for name, flags in (("f16x3", (True, True, True, True)), ("bf16x6", (False, False, True, True)),
+                            ("f32 MFMA", (False, False, False, False))):
+            GM.GEMM_F16X3, GM.SHMP_F16X3, GM.GEMM_BF16X6, GM.SHMP_BF16X6 = flags
+            nm.invalidate_caches()
+            with torch.no_grad():
+                outs[name] = nm._logits(batch, exp2=False).cpu().double()
+    finally:
+        GM.GEMM_F16X3, GM.SHMP_F16X3, GM.GEMM_BF16X6, GM.SHMP_BF16X6 = saved
+        nm.invalidate_caches()
+    r = ref.double()
+    err = lambda a, b: float(((a - b).abs() / (1.0 + b.abs())).max())      # noqa: E731
+    for name, o in outs.items():
+        print(f"[split] {name:9s} vs oracle: {err(o, r):.2e}   vs f32 MFMA form: {err(o, outs['f32 MFMA']):.2e}")
+        assert err(o, r) <= LOGIT_TOL
+    # the split forms are no further from the oracle than the exact-fp32 form is (2x margin for noise): the error against
+    # the oracle is the summation order, which all three share
+    base = max(err(outs["f32 MFMA"], r), 1e-6)
+    assert err(outs["f16x3"], r) <= 2.0 * base and err(outs["bf16x6"], r) <= 2.0 * base
+
+
+def test_empty_loss_and_replaced_parameters(setup):
+    """the loss of an empty batch is 0 (no abort); a Parameter object replaced after the first training step
+    (load_state_dict(assign=True)) is picked up by the weight folding's address table."""
+    from desco_amd import ops
+    from desco_amd import autograd as AG
+    for mode in (0, 1):
+        l = AG.Loss.apply(torch.empty(0, 29, device=DEV, requires_grad=True), torch.empty(0, 29, device=DEV), mode)
+        assert float(l.detach()) == 0.0
+    nm, _ = make_models(seed=3)
+    nm = nm.to(DEV)
+    qids, queries = standard_queries()
+    nm.set_queries(qids)
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=30)[:6]), 4)
+    g = torch.Generator().manual_seed(1)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) * 9)
+    batch = NeighborhoodBatch(part, DEV, y=y)
+
+    def grads():
+        nm.zero_grad(set_to_none=True)
+        nm.train_forward(batch, 0).backward()
+        return {n: p.grad.detach().clone() for n, p in nm.named_parameters() if p.grad is not None}
+    g0 = grads()
+    # same values, NEW Parameter objects (and new storage)
+    sd = {k: v.detach().clone() for k, v in nm.state_dict().items()}
+    nm.load_state_dict(sd, assign=True)
+    nm.invalidate_caches()
+    g1 = grads()
+    assert g0.keys() == g1.keys() and len(g1) > 20
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    # and the new objects are the ones that learn: halve one layer's weights -> other gradients
+    with torch.no_grad():
+        nm.emb_model.gnn_core.updates[3]["count"].weight.mul_(0.5)
+    g2 = grads()
+    assert not torch.equal(g2["emb_model.gnn_core.updates.3.count.weight"], g1["emb_model.gnn_core.updates.3.count.weight"])
