@@ -453,6 +453,101 @@ def train_leg(device, batch_size=512, stride=4, precision="fp32", epochs=1):
     }
 
 
+def ddp_world1_child(stride=4, batch_size=512, epochs=2):
+    """Child of ``ddp_world1_leg`` (a fresh process that has not touched the GPU; WORLD_SIZE=1,
+    DESCO_FORCE_COLLECTIVES=1): the neighborhood training leg's steps through the DATA-PARALLEL code path against real
+    RCCL -- init_process_group("nccl", device_id=...), parameter broadcast, the hook-driven eager step (asynchronous
+    bucket all-reduces issued from autograd hooks on the training stream), then trainer.DDPReplay (graph A, bucket
+    all-reduces, graph B).  One rank reduces with itself, so the numbers price the path, not the wire."""
+    import torch
+    from desco_amd import autograd as AG, distributed as D, synthetic
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.data import STANDARD_QUERY_IDS, graph_atlas_plus
+    from desco_amd.groundtruth import canonical_counts
+    from desco_amd.partition import build_partition_device
+    from desco_amd.trainer import DDPReplay
+    device = torch.device("cuda", 0)
+    assert D.init_from_env(device, backend="nccl") and D.collectives_on()
+    ones = torch.ones(1, device=device)
+    D.all_reduce_(ones, "sum")
+    backend = torch.distributed.get_backend()
+    nm, _ = build_models(device, gains=(0.8, 1.2))
+    nm.set_queries(STANDARD_QUERY_IDS)
+    gs = synthetic.WORKLOADS["syn_1827"]()
+    part = build_partition_device(gs, 4, device)
+    truth = canonical_counts(gs, [graph_atlas_plus(i) for i in STANDARD_QUERY_IDS], backend="auto").float()
+    y_all = truth[torch.from_numpy(part.indicator)]
+    starts = list(range(0, part.num_neigh, batch_size))[::stride]
+    batches = [NeighborhoodBatch(part.slice(b0, b0 + batch_size), device, y=y_all[b0:b0 + batch_size]) for b0 in starts]
+    D.broadcast_params(nm)
+    opt = nm.configure_optimizers()["optimizer"]
+    buckets = D.GradBuckets(list(nm.parameters()), 4)
+    ddp = DDPReplay(nm, opt, buckets, device)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    losses = []
+    with torch.cuda.stream(side):
+        t_eager = None
+        for ep in range(2):                       # hook-driven eager steps (the first one settles the bucket layout)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i, b in enumerate(batches):
+                buckets.zero()
+                loss = nm.train_forward(b, i)
+                AG.backward(loss, 1.0)
+                buckets.finish()
+                opt.step()
+                if ep == 0 and i == 0:
+                    losses.append(float(loss.detach()))
+            torch.cuda.synchronize(device)
+            t_eager = time.perf_counter() - t0
+        for k, b in enumerate(batches):           # capture (graph A per batch, graph B once) + first replay
+            ddp.step(k, k, b, 1.0, stream=side)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            for k, b in enumerate(batches):
+                ddp.step(k, k, b, 1.0, stream=side)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / epochs
+    torch.cuda.current_stream(device).wait_stream(side)
+    nm.invalidate_caches()
+    with torch.no_grad():
+        losses.append(float(nm.train_forward(batches[0], 0)))
+    n = sum(b.num_graphs for b in batches)
+    rec = {"value": n / dt, "unit": "neighborhoods/s", "ms_per_step": 1e3 * dt / len(batches), "steps": len(batches),
+           "launch_mode": "hipGraph replay: graph A (zero, forward, backward, pack) + bucket all-reduces + graph B (Adam)",
+           "eager_hooks": {"ms_per_step": 1e3 * t_eager / len(batches),
+                           "note": "hook-driven asynchronous bucket all-reduces during backward, eager launches"},
+           "collective": {"backend": backend, "world_size": D.world_size(), "ranks_seen": int(round(float(ones.item()))),
+                          "buckets": len(buckets.buckets), "bucket_bytes": [int(4 * f.numel()) for f in buckets.buckets],
+                          "device_id_bound": True},
+           "loss_first_batch_before": losses[0], "loss_first_batch_after": losses[1]}
+    buckets.close()
+    D.barrier()
+    torch.distributed.destroy_process_group()
+    print(json.dumps({"ddp_world1_nccl": rec}))
+
+
+def ddp_world1_leg(stride=4):
+    """``train_syn_1827.ddp_world1_nccl``: start ``ddp_world1_child`` as a fresh process (RCCL wants its communicator
+    made before anything else used the device in that process, and an exec from a process that initialised the GPU is
+    not allowed on this pool: the child is spawned, never exec'd into)."""
+    from desco_amd import distributed as D
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(D.free_port()), DESCO_FORCE_COLLECTIVES="1")
+    env.pop("DESCO_SHARE_GPU", None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--ddp-child", "--train-stride", str(stride)],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"ddp_world1_nccl"')]
+        if p.returncode != 0 or not lines:
+            return {"status": "error", "returncode": p.returncode, "stderr_tail": p.stderr[-600:]}
+        return json.loads(lines[-1])["ddp_world1_nccl"]
+    except Exception as e:      # noqa: BLE001  (a failing side leg must not cost the measurement)
+        return {"status": "error", "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def train_gossip_leg(device, batch_graphs=256, epochs=2):
     """BASELINE config 4's second stage (Syn_1827 full training): the gossip model's training step -- forward, backward
     (every op a C-ABI kernel, desco_amd.autograd), Adam -- on all 1 827 Syn_1827-shaped graphs in the reference's batches
@@ -678,9 +773,13 @@ def main():
     ap.add_argument("--selftest-nccl", action="store_true",
                     help="2-rank RCCL gradient all-reduce check (needs 2 visible GPUs; skips otherwise)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--ddp-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         sys.exit(cpu_worker_main())
+    if args.ddp_child:
+        ddp_world1_child(stride=args.train_stride)
+        return
     if args.selftest_nccl:
         sys.exit(nccl_selftest(args))
 
@@ -715,6 +814,9 @@ def main():
         if args.train_leg != "gossip":
             rec["train_syn_1827"] = {p_: train_leg(device, stride=args.train_stride, precision=p_, epochs=args.train_epochs)
                                      for p_ in precisions}
+            if args.train_leg == "all":
+                torch.cuda.empty_cache()
+                rec["train_syn_1827"]["ddp_world1_nccl"] = ddp_world1_leg(stride=args.train_stride)
         if args.train_leg in ("all", "gossip"):
             rec["train_gossip"] = train_gossip_leg(device, epochs=2 * args.train_epochs)
         print(json.dumps(rec))
@@ -1088,6 +1190,11 @@ def main():
             for p_ in precisions[1:]:
                 result["train_syn_1827"][p_] = legs[p_]
             torch.cuda.empty_cache()
+            # the same steps through the data-parallel path against real RCCL, world of one rank (a fresh child process)
+            ddp = ddp_world1_leg(stride=args.train_stride)
+            if "ms_per_step" in ddp:
+                ddp["vs_single_process_replay"] = ddp["ms_per_step"] / result["train_syn_1827"]["ms_per_step"]
+            result["train_syn_1827"]["ddp_world1_nccl"] = ddp
             result["train_gossip"] = train_gossip_leg(device)
         # ---- CPU baseline (N=1 only) + parity of the sample ------------------------------------
         if world == 1 and not args.no_cpu_baseline:

@@ -524,12 +524,21 @@ class Mlp(torch.autograd.Function):
 _ONES = {}
 
 
-def backward(loss: torch.Tensor) -> None:
-    """``loss.backward()`` seeded with a cached one (torch's implicit seed is a ones_like fill launch per step)."""
-    one = _ONES.get(loss.device)
-    if one is None:
-        one = _ONES[loss.device] = ops.fill(torch.empty((), device=loss.device, dtype=torch.float32), 1.0)
-    loss.backward(gradient=one)
+def backward(loss: torch.Tensor, weight: float = 1.0) -> None:
+    """``(loss * weight).backward()`` seeded with a cached device scalar (torch's implicit seed is a ones_like fill
+    launch per step, the product another launch); ``weight``: a rank's share of a data-parallel step's mean loss
+    (distributed.mean_loss_weight)."""
+    if not loss.is_cuda:
+        (loss if weight == 1.0 else loss * weight).backward()
+        return
+    key = (loss.device, float(weight))
+    seed = _ONES.get(key)
+    if seed is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("autograd.backward: the seed of this weight has to be made outside a capture "
+                               "(run the step eagerly once)")
+        seed = _ONES[key] = ops.fill(torch.empty((), device=loss.device, dtype=torch.float32), float(weight))
+    loss.backward(gradient=seed)
 
 
 class Loss(torch.autograd.Function):

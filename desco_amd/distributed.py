@@ -58,6 +58,20 @@ def is_initialized() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def force_collectives() -> bool:
+    """DESCO_FORCE_COLLECTIVES=1: run the data-parallel code path -- process group, gradient buckets, all-reduces,
+    broadcasts -- also in a world of ONE rank.  A 1-GPU box can then execute the RCCL path end to end
+    (``init_process_group("nccl", device_id=...)``, asynchronous work handles, stream ordering against the training
+    stream): bench.py's ``ddp_world1_nccl`` leg."""
+    return os.environ.get("DESCO_FORCE_COLLECTIVES") == "1"
+
+
+def collectives_on() -> bool:
+    """A process group exists and its collectives are to be executed (more than one rank, or forced)."""
+    import torch.distributed as dist
+    return is_initialized() and (dist.get_world_size() > 1 or force_collectives())
+
+
 def world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if is_initialized() else 1
@@ -92,7 +106,7 @@ def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] 
     r, w, _ = env_world()
     if device is not None and device.type == "cuda":
         torch.cuda.set_device(device)
-    if w <= 1:
+    if w <= 1 and not force_collectives():
         return False
     if dist.is_initialized():
         if dist.get_world_size() != w:
@@ -115,7 +129,7 @@ def init_from_env(device: Optional[torch.device] = None, backend: Optional[str] 
         dist.init_process_group(backend, rank=r, world_size=w, timeout=timeout)
     if dist.get_world_size() != w:      # pragma: no cover
         raise RuntimeError("process group size mismatch")
-    return True
+    return w > 1 or force_collectives()
 
 
 def launch(argv: Sequence[str], nprocs: int, env: Optional[dict] = None,
@@ -186,7 +200,7 @@ class _StagedWork:
 def all_reduce_(t: torch.Tensor, op: str = "sum", async_op: bool = False):
     """In-place all-reduce; returns a handle with .wait() when async_op (None if already done)."""
     import torch.distributed as dist
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return None
     rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
     if _staged(t):
@@ -204,7 +218,7 @@ def all_reduce_(t: torch.Tensor, op: str = "sum", async_op: bool = False):
 
 def barrier():
     import torch.distributed as dist
-    if is_initialized() and dist.get_world_size() > 1:
+    if collectives_on():
         dist.barrier()
 
 
@@ -242,7 +256,7 @@ def rank0_first(fn: Callable, key: str = "desco_rank0_done", timeout_s: float = 
 
 def broadcast_object(obj, src: int = 0):
     import torch.distributed as dist
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not collectives_on():
         return obj
     box = [obj]
     dist.broadcast_object_list(box, src=src)
@@ -516,6 +530,58 @@ class GradBuckets:
         self._handles = []                  # rank (collectives are matched by order)
         self.active = True
 
+    # -- the replayable form of a step (Trainer's DDPReplay): gradients land in fresh tensors (p.grad = None before the
+    #    backward: autograd stores, it does not accumulate -- no add launch per parameter), ONE copy launch per 24
+    #    tensors packs them into the buckets, the buckets are all-reduced between the two captured graphs, and the
+    #    optimizer reads the bucket views -------------------------------------------------------------------------
+    def views(self):
+        """{id(p): the view of p's gradient inside its bucket} (the layout of this moment)."""
+        out = {}
+        for flat, members in zip(self.buckets, self._members):
+            off = 0
+            for p in members:
+                out[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += (p.numel() + 3) // 4 * 4
+        return out
+
+    def fill_zero(self):
+        """Zero every bucket (parameters without a gradient contribute zeros); on the GPU one launch of this library's
+        per bucket, capturable."""
+        for flat in self.buckets:
+            if flat.is_cuda:
+                from . import ops
+                ops.fill(flat, 0.0)
+            else:
+                flat.zero_()
+
+    def pack_from_grads(self):
+        """bucket view of p = p.grad for every parameter that has one (copy2d launches on the GPU: 24 tensors each)."""
+        vs = self.views()
+        pairs = [(p.grad, vs[id(p)]) for p in self.params if p.grad is not None and p.grad.data_ptr() != vs[id(p)].data_ptr()]
+        if not pairs:
+            return
+        if pairs[0][1].is_cuda:
+            from . import ops
+            as2d = lambda t: t.reshape(1, -1) if t.dim() != 2 else t          # noqa: E731
+            ops.copy2d_multi([(as2d(g.contiguous()), as2d(v)) for g, v in pairs])
+        else:
+            for g, v in pairs:
+                v.copy_(g)
+
+    def attach_views(self):
+        """p.grad = its bucket view (what the optimizer is to read)."""
+        vs = self.views()
+        for p in self.params:
+            p.grad = vs[id(p)]
+
+    def allreduce_all(self):
+        """All buckets, asynchronously in index order, then wait (the un-overlapped form: a captured backward cannot
+        issue collectives from its hooks)."""
+        hs = [all_reduce_(flat, "sum", async_op=True) for flat in self.buckets]
+        for h in hs:
+            if h is not None:
+                h.wait()
+
     def _issue_ready(self, force: bool = False):
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
             h = all_reduce_(self.buckets[self._next], "sum", async_op=True)
@@ -563,7 +629,7 @@ class GradBuckets:
 def broadcast_params(module: torch.nn.Module, src: int = 0) -> None:
     """Every rank starts from rank ``src``'s parameters and buffers (what DDP does at construction)."""
     import torch.distributed as dist
-    if world_size() == 1:
+    if not collectives_on():
         return
     ts = [t for t in list(module.parameters()) + list(module.buffers())]
     if not ts:

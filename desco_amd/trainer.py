@@ -23,6 +23,67 @@ class ModelCheckpoint:
         self.best_score: Optional[float] = None
 
 
+class DDPReplay:
+    """A data-parallel optimisation step at replay speed (main.py:242-255 of the reference hands the devices to a "ddp"
+    Trainer).  A collective cannot be issued from inside a captured backward, so the step is cut in two graphs around it:
+
+        graph A[k]  zero the gradient buckets, forward, backward, pack the gradients into the buckets   (per batch k)
+        all-reduce  every bucket over RCCL, asynchronously in index order, then wait                     (not captured)
+        graph B     the optimizer step reading the bucket views                                          (one for all k)
+
+    Gradients are produced into fresh tensors (p.grad = None at capture: autograd stores instead of accumulating -- the
+    hook-driven eager form pays one add launch per parameter for its views) and packed by copy2d launches of 24 tensors
+    each; a rank without a batch in a step replays the zero fill alone and still joins the collectives.  The arithmetic
+    is the eager DDP step's (same seed weight, same bucket layout and order), so parameters agree bit for bit
+    (tests/test_multirank_gpu.py).  On a CPU device the same sequence runs eagerly (gloo tests)."""
+
+    def __init__(self, model, opt, buckets: "D.GradBuckets", device: torch.device):
+        self.model, self.opt, self.buckets, self.device = model, opt, buckets, device
+        self.use_graphs = device.type == "cuda"
+        self.graphs = {}
+        self.adam = None
+        self.layout = None          # the bucket layout the graphs were captured for
+
+    def _forward_backward(self, i, batch, w):
+        from . import autograd as AG
+        self.buckets.fill_zero()
+        if batch is not None:
+            for p in self.buckets.params:
+                p.grad = None
+            AG.backward(self.model.train_forward(batch, i), w)
+            self.buckets.pack_from_grads()
+
+    def step(self, k, i, batch, w, stream=None):
+        """step k of the epoch (batch index i, weight w of this rank's loss); call it on the training stream."""
+        bk = self.buckets
+        if self.layout is not None and self.layout is not bk.buckets:
+            raise RuntimeError("the gradient buckets were laid out again after a step was captured")
+        if not self.use_graphs:
+            self._forward_backward(i, batch, w)
+        else:
+            g = self.graphs.get(k)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                # (capture_error_mode "thread_local": RCCL's watchdog thread polls its work events with hipEventQuery
+                #  while this thread captures -- in the default "global" mode that call invalidates the capture)
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    self._forward_backward(i, batch, w)        # (the capture does not execute the step)
+                self.graphs[k] = g
+                self.layout = bk.buckets
+            g.replay()
+        bk.allreduce_all()
+        if not self.use_graphs:
+            bk.attach_views()
+            self.opt.step()
+            return
+        if self.adam is None:
+            bk.attach_views()
+            self.adam = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.adam, stream=stream, capture_error_mode="thread_local"):
+                self.opt.step()
+        self.adam.replay()
+
+
 class Trainer:
     def __init__(self, max_epochs: int = 1, accelerator: str = "gpu", devices=None,
                  default_root_dir: str = ".", callbacks=None, strategy: Optional[str] = None,
@@ -33,7 +94,7 @@ class Trainer:
         self.precision = precision
         # graph_capture: after one eager epoch, every training batch's step (forward, backward, Adam)
         # is captured in a hipGraph and replayed in later epochs -- the ~400 launches of a step are
-        # host-bound otherwise.  Single process.
+        # host-bound otherwise.  Data parallel: two graphs around the gradient all-reduces (DDPReplay).
         self.graph_capture = graph_capture
         self.max_epochs = max_epochs
         self.root = default_root_dir
@@ -81,6 +142,25 @@ class Trainer:
             tot, cnt = float(t[0]), float(t[1])
         return tot / max(cnt, 1)
 
+    def _ddp_epoch(self, model, opt, steps, buckets, ddp, side, capture: bool):
+        """One data-parallel epoch on the side stream: the hook-driven eager step (epoch 0: it also settles the bucket
+        layout), then DDPReplay's two graphs around the bucket all-reduces."""
+        from . import autograd as AG
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for k, (i, batch, w) in enumerate(steps):
+                if capture:
+                    ddp.step(k, i, batch, w, stream=side)
+                    continue
+                buckets.zero()
+                if batch is not None:
+                    AG.backward(model.training_step(batch, i), w)     # bucket all-reduces start from the hooks
+                buckets.finish()
+                opt.step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        if capture:
+            model.invalidate_caches()
+
     def _graph_epoch(self, model, opt, batches, graphs, side, capture: bool):
         """One epoch on the side stream: eager (epoch 0), then capture-once / replay per batch."""
         from . import autograd as AG
@@ -112,7 +192,7 @@ class Trainer:
         AG.set_precision(self.precision)
         model.to(self.device)
         world, rank = D.world_size(), D.rank()
-        multi = world > 1
+        multi = D.collectives_on()             # (a world of one rank too under DESCO_FORCE_COLLECTIVES=1)
         if multi:
             D.broadcast_params(model)          # every replica starts from rank 0's weights
         cfg = model.configure_optimizers()
@@ -121,7 +201,7 @@ class Trainer:
         os.makedirs(self.root, exist_ok=True)
         # (dropout does not stand in the way of replay: the masks are functions of a (seed, step) pair in device memory
         #  that a captured launch advances -- ops.rng_next -- so every replay draws the next mask)
-        use_graphs = self.graph_capture and not multi and self.device.type == "cuda"
+        use_graphs = self.graph_capture and self.device.type == "cuda"
         # shuffle=False (main.py:195): the batch stream is the same every epoch, so the device-resident
         # batches (and their backward indices) are built once.  Data parallel: optimisation step k
         # consumes the `world` consecutive batches [k*world, (k+1)*world), one per rank, weighted by
@@ -136,20 +216,22 @@ class Trainer:
             steps.append((i, None if i is None else host_batches[i].to(self.device), w))
         del host_batches
         buckets = D.GradBuckets(list(model.parameters()), self.num_buckets) if multi else None
+        ddp = DDPReplay(model, opt, buckets, self.device) if (multi and use_graphs) else None
         graphs = {}
         # capture happens on a side stream, and autograd's AccumulateGrad nodes must have been created
         # on that same stream: with graph_capture the whole training loop runs on it
         side = torch.cuda.Stream(self.device) if use_graphs else None
         for epoch in range(self.max_epochs):
             model.train()
-            if use_graphs:
+            if use_graphs and multi:
+                self._ddp_epoch(model, opt, steps, buckets, ddp, side, capture=epoch >= 1)
+            elif use_graphs:
                 self._graph_epoch(model, opt, [b for _, b, _ in steps], graphs, side, capture=epoch >= 1)
             elif multi:
                 for i, batch, w in steps:
                     buckets.zero()
                     if batch is not None:
-                        loss = model.training_step(batch, i)
-                        (loss if w == 1.0 else loss * w).backward()   # bucket all-reduces start here
+                        AG.backward(model.training_step(batch, i), w)   # bucket all-reduces start from the hooks
                     buckets.finish()
                     opt.step()
             else:

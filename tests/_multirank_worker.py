@@ -110,6 +110,38 @@ def main():
                      callbacks=[ModelCheckpoint(monitor="gossip_counting_val_loss")], grad_reduce="sum")
         tg.fit(gm, gl)
         res["gparams"] = {k: v.detach().cpu().clone() for k, v in gm.state_dict().items()}
+    elif mode == "fit_replay":
+        # Trainer(strategy="ddp") with and without graph_capture: the replayed data-parallel step (two hipGraphs around
+        # the bucket all-reduces, trainer.DDPReplay) must leave the parameters of the eager one, bit for bit
+        from desco_amd import ops
+        from desco_amd.lightning_data import LightningDataLoader
+        from desco_amd.trainer import Trainer
+        from desco_amd.workload import Workload
+        gs = GraphSet.from_edge_lists(C.mixed_graphs()[:C.TRAIN_GRAPHS])
+        w = Workload(gs, root=None)
+        w.generate_pipeline_datasets(depth_neigh=4)
+        nd = w.neighborhood_dataset
+        x, yg = C.gossip_inputs(gs.num_nodes, 29)
+        for capture in (False, True):
+            nm, gm, qids, queries = C.models(dev, gossip_dropout=0.01)
+            nd.y = C.neigh_labels(len(nd), len(queries))
+            loader = LightningDataLoader(train_dataset=nd, val_dataset=nd, test_dataset=nd, batch_size=C.NEIGH_BATCH)
+            tr = Trainer(max_epochs=3, devices=[0, 1], strategy="ddp", default_root_dir=out_path + f".ck{int(capture)}",
+                         graph_capture=capture)
+            tr.fit(nm, loader)
+            key = f"{'replay' if capture else 'eager'}"
+            res[key + "_params"] = {k: v.detach().cpu().clone() for k, v in nm.state_dict().items()}
+            res[key + "_history"] = tr.history
+            gd = w.gossip_dataset
+            gd.x, gd.y = x, yg
+            gm.set_query_emb(nm.get_query_emb().detach())
+            ops.manual_seed(77)
+            gl = LightningDataLoader(train_dataset=gd, val_dataset=gd, test_dataset=gd, batch_size=C.GOSSIP_BATCH)
+            tg = Trainer(max_epochs=3, devices=[0, 1], strategy="ddp", default_root_dir=out_path + f".cg{int(capture)}",
+                         grad_reduce="sum", graph_capture=capture)
+            tg.fit(gm, gl)
+            res[key + "_gparams"] = {k: v.detach().cpu().clone() for k, v in gm.state_dict().items()}
+            res[key + "_rng"] = ops.rng_state(dev).cpu().tolist()
     else:
         raise SystemExit(f"unknown mode {mode}")
     torch.save(res, f"{out_path}.rank{rank}")

@@ -15,10 +15,13 @@ def mixed_graphs():
     return g + m + [s[i] for i in (20, 30, 40, 44, 48)]
 
 
-def models(device, gains=(0.8, 1.2), seed=0):
+def models(device, gains=(0.8, 1.2), seed=0, gossip_dropout=0.0):
     # (narrower weights than the molecule-sized tests: the dense graphs sum over more neighbours per
     #  row, and 2**logit must stay finite for the count comparison)
     nm, gm = make_models(seed=seed, gains=gains)
+    if gossip_dropout:          # --gossip_dropout (reference default 0.01): same weights, dropout on in training mode
+        gm.dropout = gm.emb_model.dropout = gm.emb_model.gnn_core.dropout = gossip_dropout
+        gm.emb_model.post_mp[1].p = gossip_dropout
     qids, queries = standard_queries()
     nm, gm = nm.to(device), gm.to(device)
     nm.set_queries(qids)

@@ -83,6 +83,8 @@ class _Model(torch.nn.Module):
     def training_step(self, b, i):
         return self._loss(b)
 
+    train_forward = training_step
+
     def validation_step(self, b, i):
         return self._loss(b)
 
@@ -169,6 +171,32 @@ def _worker(rank, world, port, q, tmp):
                                 len(bk.buckets), issued)
         bk.close()
         res["bucket_grads"] = grads
+        # DDPReplay's step sequence (on a CPU device it runs eagerly: fresh gradients packed into the buckets, all
+        # buckets reduced after the backward, optimizer on the bucket views) == the hook-driven step, bit for bit
+        from desco_amd.trainer import DDPReplay
+        finals = []
+        for replay in (False, True):
+            m = _Model("mean")
+            data = _Data(SIZES)
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            bk = D.GradBuckets(list(m.parameters()), num_buckets=3)
+            ddp = DDPReplay(m, opt, bk, torch.device("cpu"))
+            for epoch in range(3):
+                for k, group in enumerate(D.step_groups(SIZES, world)):
+                    i = group[rank]
+                    b = None if i is None else data.batches[i]
+                    w = D.mean_loss_weight(SIZES, group, rank)
+                    if replay and epoch >= 1:
+                        ddp.step(k, i, b, w)
+                        continue
+                    bk.zero()
+                    if b is not None:
+                        (m._loss(b) * w).backward()
+                    bk.finish()
+                    opt.step()
+            bk.close()
+            finals.append([p.detach().clone() for p in m.parameters()])
+        res["ddp_replay_equal"] = all(torch.equal(a, b) for a, b in zip(*finals))
         # Trainer.fit / predict in ddp mode
         for reduce in ("mean", "sum"):
             m = _Model(reduce)
@@ -237,6 +265,10 @@ def test_sharded_inference_gather_and_grad_allreduce(world2):
     # mean of per-rank grads: rank r contributes 5*(r+1) per weight entry
     assert torch.allclose(r0["wgrad"], torch.full((3, 4), 5 * (1 + 2) / 2))
     assert torch.equal(r0["ugrad"], torch.zeros(2, 2))                   # unused params -> zeros
+
+
+def test_ddp_replay_sequence_equals_the_hook_driven_step(world2):
+    assert world2[0]["ddp_replay_equal"] and world2[1]["ddp_replay_equal"]
 
 
 def test_shard_cuts_are_decided_by_rank_0_for_all(world2):

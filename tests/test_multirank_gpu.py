@@ -188,6 +188,27 @@ def test_two_rank_trainer_fit_equals_one_rank_union_steps(tmp_path):
     assert worst < 2e-3          # lr 1e-3, 2 steps; query embeddings differ by the 1e-5 of the stage before
 
 
+def test_two_rank_replayed_ddp_equals_eager_ddp_bit_for_bit(tmp_path):
+    """Trainer(strategy="ddp", graph_capture=True): epochs >= 1 run trainer.DDPReplay -- graph A (zero, forward,
+    backward, pack into the buckets), the bucket all-reduces, graph B (Adam on the bucket views).  After 3 epochs (2
+    steps each; the second step's group is short: rank 1 has no batch and replays the zero fill alone) the parameters
+    equal the eager hook-driven DDP run's bit for bit -- neighborhood model, and the gossip model at the reference's
+    default dropout 0.01 (whose masks come from the (seed, step) pair a captured launch advances)."""
+    r0, r1 = _run2("fit_replay", tmp_path)
+    for r in (r0, r1):
+        for stage in ("_params", "_gparams"):
+            for k in r["eager" + stage]:
+                assert torch.equal(r["eager" + stage][k], r["replay" + stage][k]), (stage, k)
+        assert r["eager_history"] == r["replay_history"]
+        assert r["eager_rng"] == r["replay_rng"] and r["eager_rng"][0] == 77 and r["eager_rng"][1] >= 3
+    for k in r0["replay_params"]:
+        assert torch.equal(r0["replay_params"][k], r1["replay_params"][k]), k          # replicas in sync
+    # the run did train: parameters moved from their initial values
+    nm, gm, *_ = C.models("cpu")
+    moved = max(float((r0["replay_params"][k] - v).abs().max()) for k, v in nm.state_dict().items())
+    assert moved > 1e-5
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_starts_its_own_ranks(scaling):
     env = dict(os.environ, DESCO_SHARE_GPU="1", DESCO_BENCH_GRAD_CHECK="1" if scaling == "weak" else "0")
