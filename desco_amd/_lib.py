@@ -132,6 +132,9 @@ SIGNATURES = {
     "desco_shmp_trunk_small_max_rows": (c_int, []),
     "desco_shmp_trunk_small_fwd_f32": (c_int, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp]),
     "desco_shmp_trunk_small_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
+    "desco_shmp_trunk_graphs_max_rows": (c_int, []),
+    "desco_shmp_trunk_graphs_fwd_f32": (c_int, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, i64, vp]),
+    "desco_shmp_trunk_graphs_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp]),
     "desco_linear_smallk_bwd_f32": (c_int, [vp, i64, i32, vp, i64, i64, vp, vp, vp]),
     "desco_rowdot_bwd_f32": (c_int, [vp, i64, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "desco_adam_step_f32": (c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp]),

@@ -21,6 +21,9 @@ from . import ops
 # product per multiply-add, fp32 accumulation; activations, gathers, pooling, the loss, the weight
 # gradients' accumulation and the master weights stay fp32).
 PRECISION = "fp32"
+# ShmpTrunkSmall: one workgroup per graph (csrc/shmp_small.hip, round 6) when the graphs are small enough; False: the
+# one-workgroup kernels (their cross-check)
+GRAPH_TRUNK_KERNEL = True
 
 
 def set_precision(p: str) -> None:
@@ -256,10 +259,24 @@ class ShmpTrunkSmall(torch.autograd.Function):
     Products are fp32 in either training precision (1.7 MFLOP per layer: nothing to gain from bf16 operands)."""
 
     @staticmethod
+    def per_graph(batch) -> bool:
+        """One workgroup per graph (round 6: 29 workgroups instead of one) when every graph of the batch has at most
+        ops.shmp_trunk_graphs_max_rows() rows -- the standard queries have 3..5."""
+        pg = batch.__dict__.get("_small_per_graph")
+        if pg is None:
+            import numpy as np
+            gp = getattr(batch, "graph_ptr_host", None)
+            sizes = np.diff(np.asarray(batch.graph_ptr.cpu()) if gp is None else np.asarray(gp))
+            pg = batch.__dict__["_small_per_graph"] = bool(GRAPH_TRUNK_KERNEL and len(sizes) and
+                                                           int(sizes.max()) <= ops.shmp_trunk_graphs_max_rows())
+        return pg
+
+    @staticmethod
     def forward(ctx, x0, batch, wt, bias):
         x0, wt, bias = x0.contiguous(), wt.contiguous(), bias.contiguous()
-        xall, pooled = ops.shmp_trunk_small_fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr,
-                                                batch.num_graphs)
+        ctx.per_graph = ShmpTrunkSmall.per_graph(batch)
+        fwd = ops.shmp_trunk_graphs_fwd if ctx.per_graph else ops.shmp_trunk_small_fwd
+        xall, pooled = fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr, batch.num_graphs)
         ctx.batch = batch
         ctx.save_for_backward(x0, xall, wt)
         return pooled
@@ -269,6 +286,10 @@ class ShmpTrunkSmall(torch.autograd.Function):
         x0, xall, wt = ctx.saved_tensors
         batch = ctx.batch
         ti = batch.train_index()
+        if ctx.per_graph:
+            dwt, dbias, dx0 = ops.shmp_trunk_graphs_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],
+                                                        batch.graph_ptr, batch.num_graphs, wt, dpooled.contiguous())
+            return dx0, None, dwt, dbias
         wt_t = torch.empty((wt.shape[0], wt.shape[2], wt.shape[1]), device=wt.device)
         ops.copy2d_multi([(wt[l], wt_t[l], True) for l in range(wt.shape[0])])
         dwt, dbias, dx0 = ops.shmp_trunk_small_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],

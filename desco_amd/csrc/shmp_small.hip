@@ -232,6 +232,249 @@ __global__ __launch_bounds__(NT) void shmp_small_bwd_kernel(const BwdArgs g) {
 
 constexpr size_t kShmem = sizeof(float) * (size_t)NMAX * (64 + KA);
 
+// ---- round 6: one workgroup per GRAPH -----------------------------------------------------------------------------------
+// The query graphs are independent of each other (no edge crosses a graph) and have at most 5 rows: the one-workgroup
+// kernels above spend their time waiting for the weight stream (48 dependent trips to L2 per layer for 135 rows' worth of
+// FMAs on ONE of 256 CUs: 0.23 ms forward + 0.49 ms backward per training step, 29 % of it).  Here graph b's rows
+// (at most GMAX) live in the LDS of workgroup b; per layer a thread fetches its whole share of the 192 x 64 weight block
+// in four 16-byte loads issued together, and the next layer's share is requested before this layer's barrier.
+//   forward   thread (k group kg of 48, 16 column lanes): 4 weight rows x float4, partial products of all rows of the
+//             graph; the 4 k groups of a wave are added with two shuffles, the 12 waves through LDS in wave order.
+//   backward  D = dZ Wt^T straight from Wt (thread (k, quarter of the 64 columns): 64 contiguous bytes; the 4 quarters of
+//             a k sit in adjacent lanes: two shuffles) -- no transposed weight copy; dZ_l goes to a workspace from which
+//             a second launch, one workgroup per (layer, 16 weight rows), forms dWt_l = A_l^T dZ_l over ALL rows in row
+//             order (the one-workgroup kernel's order) with A_l gathered on the fly, and db_l.
+constexpr int GT = 768;       // threads per graph workgroup: 12 waves
+constexpr int GMAX = 8;       // rows per graph
+
+struct GFwdArgs {
+  const float* x0;
+  const int32_t* vrowptr;
+  const int32_t* vcol;
+  int L;
+  const float* wt;
+  const float* bias;
+  const int32_t* seg_ptr;
+  float* xall;
+  int64_t n;
+  float* pooled;
+  int64_t ldp;
+};
+
+__global__ __launch_bounds__(GT) void shmp_graphs_fwd_kernel(const GFwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float X[GMAX * 64];
+  __shared__ __attribute__((aligned(16))) float A[GMAX * KA];
+  __shared__ __attribute__((aligned(16))) float P[12 * GMAX * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  const int r0 = g.seg_ptr[b];
+  int nb = g.seg_ptr[b + 1] - r0;
+  nb = nb > GMAX ? GMAX : nb;
+  for (int u = t; u < nb * 16; u += GT)
+    *reinterpret_cast<float4*>(X + 4 * u) = *reinterpret_cast<const float4*>(g.x0 + (int64_t)r0 * 64 + 4 * u);
+  const int col4 = 4 * (lane & 15), kg = wave * 4 + (lane >> 4);          // k rows 4 kg .. 4 kg + 3
+  float4 w0, w1, w2, w3;
+#define SG_LOADW(l_)                                                                         \
+  {                                                                                          \
+    const float* W_ = g.wt + ((int64_t)(l_)*KA + 4 * kg) * 64 + col4;                        \
+    w0 = *reinterpret_cast<const float4*>(W_);                                               \
+    w1 = *reinterpret_cast<const float4*>(W_ + 64);                                          \
+    w2 = *reinterpret_cast<const float4*>(W_ + 128);                                         \
+    w3 = *reinterpret_cast<const float4*>(W_ + 192);                                         \
+  }
+  SG_LOADW(0)
+  __syncthreads();
+  for (int l = 0;; ++l) {
+    if (t < 16) {                                                          // pooled block l of this graph
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < nb; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(X + r * 64 + 4 * t);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(g.pooled + (int64_t)b * g.ldp + l * 64 + 4 * t) = s;
+    }
+    if (l == g.L) break;
+    for (int u = t; u < nb * 3 * 16; u += GT) {                            // A = [agg_0 | agg_1 | self] of the graph's rows
+      const int c4 = 4 * (u & 15), v = u >> 4, i = v / 3, sl = v - 3 * i;
+      float4 acc;
+      if (sl == 2) {
+        acc = *reinterpret_cast<const float4*>(X + i * 64 + c4);
+      } else {
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int e1 = g.vrowptr[(r0 + i) * 2 + sl + 1];
+        for (int e = g.vrowptr[(r0 + i) * 2 + sl]; e < e1; ++e) {
+          int j = g.vcol[e] - r0;
+          j = (j < 0 || j >= nb) ? i : j;                                  // (a source outside the graph cannot happen)
+          const float4 x = *reinterpret_cast<const float4*>(X + j * 64 + c4);
+          acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+      }
+      *reinterpret_cast<float4*>(A + i * KA + sl * 64 + c4) = acc;
+    }
+    __syncthreads();
+    for (int r = 0; r < nb; ++r) {
+      const float4 a = *reinterpret_cast<const float4*>(A + r * KA + 4 * kg);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      f4fma(acc, a.x, w0);
+      f4fma(acc, a.y, w1);
+      f4fma(acc, a.z, w2);
+      f4fma(acc, a.w, w3);
+      acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+      acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+      acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+      acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+      if (lane < 16) *reinterpret_cast<float4*>(P + (wave * GMAX + r) * 64 + col4) = acc;
+    }
+    if (l + 1 < g.L) SG_LOADW(l + 1)                                       // in flight across the barrier and the epilogue
+    __syncthreads();
+    if (t < nb * 16) {
+      const int r = t >> 4, c4 = 4 * (t & 15);
+      float4 s = *reinterpret_cast<const float4*>(g.bias + l * 64 + c4);
+#pragma unroll
+      for (int w = 0; w < 12; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(P + (w * GMAX + r) * 64 + c4);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+      }
+      s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+      *reinterpret_cast<float4*>(X + r * 64 + c4) = s;
+      *reinterpret_cast<float4*>(g.xall + ((int64_t)l * g.n + r0 + r) * 64 + c4) = s;
+    }
+    __syncthreads();
+  }
+#undef SG_LOADW
+}
+
+struct GBwdArgs {
+  const float* xall;          // [L][n][64]
+  const int32_t* t_rowptr;    // [n + 1]
+  const int32_t* t_col;       // virtual rows k * 3 + s (global k)
+  const int32_t* seg_ptr;
+  int L;
+  int64_t n;
+  const float* wt;            // [L][192][64]
+  const float* dpooled;
+  int64_t ldp;
+  float* dz_all;              // [L][n][64] workspace
+  float* dx0;
+};
+
+__global__ __launch_bounds__(GT) void shmp_graphs_bwd_kernel(const GBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float G[GMAX * 64];             // gradient of the layer's output rows, then dZ
+  __shared__ __attribute__((aligned(16))) float D[GMAX * KA];
+  const int t = threadIdx.x, b = blockIdx.x, L = g.L;
+  const int r0 = g.seg_ptr[b];
+  int nb = g.seg_ptr[b + 1] - r0;
+  nb = nb > GMAX ? GMAX : nb;
+  const int k = t >> 2, cq = t & 3;                                        // weight row k, columns 16 cq .. 16 cq + 15
+  float4 w0, w1, w2, w3;
+#define SG_LOADW(l_)                                                                         \
+  {                                                                                          \
+    const float* W_ = g.wt + ((int64_t)(l_)*KA + k) * 64 + 16 * cq;                          \
+    w0 = *reinterpret_cast<const float4*>(W_);                                               \
+    w1 = *reinterpret_cast<const float4*>(W_ + 4);                                           \
+    w2 = *reinterpret_cast<const float4*>(W_ + 8);                                           \
+    w3 = *reinterpret_cast<const float4*>(W_ + 12);                                          \
+  }
+  SG_LOADW(L - 1)
+  const float* seed = g.dpooled + (int64_t)b * g.ldp;
+  if (t < nb * 16) *reinterpret_cast<float4*>(G + 4 * t) = *reinterpret_cast<const float4*>(seed + L * 64 + 4 * (t & 15));
+  for (int l = L - 1; l >= 0; --l) {
+    if (t < nb * 16) {                                                     // dZ = G * relu'(X_{l+1}), kept and stored
+      const int r = t >> 4, c4 = 4 * (t & 15);
+      const float4 x = *reinterpret_cast<const float4*>(g.xall + ((int64_t)l * g.n + r0 + r) * 64 + c4);
+      float4 v = *reinterpret_cast<const float4*>(G + 4 * t);
+      v.x = x.x > 0.f ? v.x : 0.f;
+      v.y = x.y > 0.f ? v.y : 0.f;
+      v.z = x.z > 0.f ? v.z : 0.f;
+      v.w = x.w > 0.f ? v.w : 0.f;
+      *reinterpret_cast<float4*>(G + 4 * t) = v;
+      *reinterpret_cast<float4*>(g.dz_all + ((int64_t)l * g.n + r0 + r) * 64 + c4) = v;
+    }
+    __syncthreads();
+    for (int r = 0; r < nb; ++r) {                                         // D[r][k] = sum_c dZ[r][c] Wt[k][c]
+      const float* z = G + r * 64 + 16 * cq;
+      const float4 z0 = *reinterpret_cast<const float4*>(z), z1 = *reinterpret_cast<const float4*>(z + 4);
+      const float4 z2 = *reinterpret_cast<const float4*>(z + 8), z3 = *reinterpret_cast<const float4*>(z + 12);
+      float s = 0.f;
+      s = fmaf(z0.x, w0.x, s); s = fmaf(z0.y, w0.y, s); s = fmaf(z0.z, w0.z, s); s = fmaf(z0.w, w0.w, s);
+      s = fmaf(z1.x, w1.x, s); s = fmaf(z1.y, w1.y, s); s = fmaf(z1.z, w1.z, s); s = fmaf(z1.w, w1.w, s);
+      s = fmaf(z2.x, w2.x, s); s = fmaf(z2.y, w2.y, s); s = fmaf(z2.z, w2.z, s); s = fmaf(z2.w, w2.w, s);
+      s = fmaf(z3.x, w3.x, s); s = fmaf(z3.y, w3.y, s); s = fmaf(z3.z, w3.z, s); s = fmaf(z3.w, w3.w, s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (cq == 0) D[r * KA + k] = s;
+    }
+    if (l > 0) SG_LOADW(l - 1)
+    __syncthreads();
+    if (t < nb * 16) {                                                     // gradient of X_l
+      const int r = t >> 4, c4 = 4 * (t & 15);
+      float4 acc = *reinterpret_cast<const float4*>(D + r * KA + 128 + c4);
+      const int e1 = g.t_rowptr[r0 + r + 1];
+      for (int e = g.t_rowptr[r0 + r]; e < e1; ++e) {
+        int v = g.t_col[e] - 3 * r0;                                       // local virtual row
+        v = (v < 0 || v >= 3 * nb) ? 3 * r + 2 : v;
+        const float4 d = *reinterpret_cast<const float4*>(D + v * 64 + c4);
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+      }
+      const float4 p = *reinterpret_cast<const float4*>(seed + l * 64 + c4);
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+      *reinterpret_cast<float4*>(G + 4 * t) = acc;
+      if (l == 0) *reinterpret_cast<float4*>(g.dx0 + ((int64_t)r0 + r) * 64 + c4) = acc;
+    }
+    // (the next iteration's first phase touches only the elements the same thread just wrote; D is rewritten after its barrier)
+  }
+#undef SG_LOADW
+}
+
+// dWt[l][16 kb + kk][:] = sum_i A_l[i][16 kb + kk] dZ_l[i][:] over all rows i in row order; db[l] = colsum dZ_l
+struct GBwdWArgs {
+  const float* x0;
+  const float* xall;
+  const int32_t* vrowptr;
+  const int32_t* vcol;
+  int64_t n;
+  const float* dz_all;
+  float* dwt;
+  float* dbias;
+};
+
+__global__ __launch_bounds__(256) void shmp_graphs_bwd_w_kernel(const GBwdWArgs g) {
+  constexpr int CH = 128;
+  __shared__ __attribute__((aligned(16))) float Z[CH * 64];
+  __shared__ float Ab[CH * 16];
+  const int t = threadIdx.x, kb = blockIdx.x, l = blockIdx.y;
+  const int kk = t >> 4, col4 = 4 * (t & 15);
+  const int sl = kb >> 2, c0 = 16 * (kb & 3);                              // relation slot (2 = self) and column of the block
+  const float* Xl = l ? g.xall + (int64_t)(l - 1) * g.n * 64 : g.x0;
+  const float* dz = g.dz_all + (int64_t)l * g.n * 64;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bs = 0.f;
+  for (int64_t i0 = 0; i0 < g.n; i0 += CH) {
+    const int m = (int)((g.n - i0) < CH ? (g.n - i0) : CH);
+    __syncthreads();
+    for (int u = t; u < m * 16; u += 256)
+      *reinterpret_cast<float4*>(Z + 4 * u) = *reinterpret_cast<const float4*>(dz + i0 * 64 + 4 * u);
+    for (int u = t; u < m * 16; u += 256) {
+      const int i = u >> 4, c = c0 + (u & 15);
+      const int64_t row = i0 + i;
+      float a;
+      if (sl == 2) {
+        a = Xl[row * 64 + c];
+      } else {
+        a = 0.f;
+        const int e1 = g.vrowptr[row * 2 + sl + 1];
+        for (int e = g.vrowptr[row * 2 + sl]; e < e1; ++e) a += Xl[(int64_t)g.vcol[e] * 64 + c];
+      }
+      Ab[i * 16 + (u & 15)] = a;
+    }
+    __syncthreads();
+    for (int i = 0; i < m; ++i) f4fma(acc, Ab[i * 16 + kk], *reinterpret_cast<const float4*>(Z + i * 64 + col4));
+    if (kb == 0 && t < 64)
+      for (int i = 0; i < m; ++i) bs += Z[i * 64 + t];
+  }
+  *reinterpret_cast<float4*>(g.dwt + ((int64_t)l * KA + 16 * kb + kk) * 64 + col4) = acc;
+  if (kb == 0 && t < 64) g.dbias[l * 64 + t] = bs;
+}
+
 }  // namespace small
 }  // namespace desco
 
@@ -282,4 +525,45 @@ extern "C" int desco_shmp_trunk_small_bwd_f32(const float* x0, const float* xall
   BwdArgs g{x0, xall, vrowptr, vcol, t_rowptr, t_col, seg_id, num_rows, num_layers, wt_t, dpooled, ldp, dwt, dbias, dx0};
   hipLaunchKernelGGL(shmp_small_bwd_kernel, dim3(1), dim3(NT), kShmem, (hipStream_t)stream, g);
   return launch_status("desco_shmp_trunk_small_bwd_f32");
+}
+
+extern "C" int desco_shmp_trunk_graphs_max_rows(void) { return desco::small::GMAX; }
+
+extern "C" int desco_shmp_trunk_graphs_fwd_f32(const float* x0, const int32_t* vrowptr, const int32_t* vcol,
+                                               int64_t num_rows, int num_layers, const float* wt, const float* bias,
+                                               const int32_t* seg_ptr, int num_seg, float* xall, float* pooled,
+                                               int64_t ldp, desco_stream_t stream) {
+  using namespace desco;
+  using namespace desco::small;
+  if (num_rows == 0 || num_seg == 0) return 0;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (!x0 || !vrowptr || !vcol || !wt || !bias || !seg_ptr || !xall || !pooled || num_rows < 0 || num_layers < 1 ||
+      num_seg < 0 || ldp < 64 * (num_layers + 1) || ldp % 4 || mis16(x0) || mis16(wt) || mis16(bias) || mis16(xall) ||
+      mis16(pooled))
+    return fail(DESCO_EINVAL, "desco_shmp_trunk_graphs_fwd_f32: bad argument (16-byte alignment, ldp >= 64 (L + 1))");
+  GFwdArgs g{x0, vrowptr, vcol, num_layers, wt, bias, seg_ptr, xall, num_rows, pooled, ldp};
+  hipLaunchKernelGGL(shmp_graphs_fwd_kernel, dim3((unsigned)num_seg), dim3(GT), 0, (hipStream_t)stream, g);
+  return launch_status("desco_shmp_trunk_graphs_fwd_f32");
+}
+
+extern "C" int desco_shmp_trunk_graphs_bwd_f32(const float* x0, const float* xall, const int32_t* vrowptr,
+                                               const int32_t* vcol, const int32_t* t_rowptr, const int32_t* t_col,
+                                               const int32_t* seg_ptr, int num_seg, int64_t num_rows, int num_layers,
+                                               const float* wt, const float* dpooled, int64_t ldp, float* dwt,
+                                               float* dbias, float* dx0, float* workspace, desco_stream_t stream) {
+  using namespace desco;
+  using namespace desco::small;
+  if (num_rows == 0 || num_seg == 0) return 0;
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (!x0 || !xall || !vrowptr || !vcol || !t_rowptr || !t_col || !seg_ptr || !wt || !dpooled || !dwt || !dbias || !dx0 ||
+      !workspace || num_rows < 0 || num_seg < 0 || num_layers < 1 || ldp < 64 * (num_layers + 1) || ldp % 4 ||
+      mis16(x0) || mis16(xall) || mis16(wt) || mis16(dpooled) || mis16(dwt) || mis16(dx0) || mis16(workspace))
+    return fail(DESCO_EINVAL, "desco_shmp_trunk_graphs_bwd_f32: bad argument (16-byte alignment, ldp >= 64 (L + 1))");
+  GBwdArgs g{xall, t_rowptr, t_col, seg_ptr, num_layers, num_rows, wt, dpooled, ldp, workspace, dx0};
+  hipLaunchKernelGGL(shmp_graphs_bwd_kernel, dim3((unsigned)num_seg), dim3(GT), 0, (hipStream_t)stream, g);
+  int rc = launch_status("desco_shmp_trunk_graphs_bwd_f32");
+  if (rc) return rc;
+  GBwdWArgs w{x0, xall, vrowptr, vcol, num_rows, workspace, dwt, dbias};
+  hipLaunchKernelGGL(shmp_graphs_bwd_w_kernel, dim3(12, (unsigned)num_layers), dim3(256), 0, (hipStream_t)stream, w);
+  return launch_status("desco_shmp_trunk_graphs_bwd_f32 (weights)");
 }

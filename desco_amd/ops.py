@@ -904,6 +904,45 @@ def shmp_trunk_small_bwd(x0, xall, vrowptr, vcol, t_rowptr, t_col_s1, seg_id, wt
     return dwt, dbias, dx0
 
 
+def shmp_trunk_graphs_max_rows() -> int:
+    return int(_lib.lib().desco_shmp_trunk_graphs_max_rows())
+
+
+def shmp_trunk_graphs_fwd(x0, vrowptr, vcol, wt, bias, seg_ptr, num_seg):
+    """The SHMP trunk with one workgroup per graph (desco_shmp_trunk_graphs_fwd_f32; graphs of at most
+    shmp_trunk_graphs_max_rows() rows): returns (xall [L, n, 64], pooled [num_seg, 64 (L + 1)])."""
+    n, L = x0.shape[0], wt.shape[0]
+    assert x0.is_contiguous() and wt.is_contiguous() and bias.is_contiguous() and tuple(wt.shape) == (L, 192, 64)
+    xall = torch.empty((L, n, 64), device=x0.device, dtype=torch.float32)
+    pooled = torch.empty((num_seg, 64 * (L + 1)), device=x0.device, dtype=torch.float32)
+    with _Timed("shmp_graphs_fwd_kernel", 2.0 * n * 192 * 64 * L, 4.0 * (num_seg * L * 192 * 64 + (L + 1) * n * 64)):
+        _lib.check(_lib.lib().desco_shmp_trunk_graphs_fwd_f32(
+            _dev(x0, "x0"), _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), n, L, _dev(wt, "wt"),
+            _dev(bias, "bias"), _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, _dev(xall, "xall"),
+            _dev(pooled, "pooled"), pooled.shape[1], _stream()), "shmp_trunk_graphs_fwd")
+    return xall, pooled
+
+
+def shmp_trunk_graphs_bwd(x0, xall, vrowptr, vcol, t_rowptr, t_col_s1, seg_ptr, num_seg, wt, dpooled):
+    """Backward of shmp_trunk_graphs_fwd: (dwt [L, 192, 64], dbias [L, 64], dx0 [n, 64]); two launches."""
+    L, n = xall.shape[0], xall.shape[1]
+    assert wt.is_contiguous() and tuple(wt.shape) == (L, 192, 64)
+    dev = x0.device
+    dwt = torch.empty((L, 192, 64), device=dev, dtype=torch.float32)
+    dbias = torch.empty((L, 64), device=dev, dtype=torch.float32)
+    dx0 = torch.empty((n, 64), device=dev, dtype=torch.float32)
+    ws = torch.empty((L, n, 64), device=dev, dtype=torch.float32)
+    dp, ldp = _rows(dpooled, "dpooled")
+    with _Timed("shmp_graphs_bwd_kernel", 6.0 * n * 192 * 64 * L, 4.0 * (2 * num_seg * L * 192 * 64 + (L + 1) * n * 64),
+                launches=2):
+        _lib.check(_lib.lib().desco_shmp_trunk_graphs_bwd_f32(
+            _dev(x0, "x0"), _dev(xall, "xall"), _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32),
+            _dev(t_rowptr, "t_rowptr", torch.int32), _dev(t_col_s1, "t_col", torch.int32),
+            _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, n, L, _dev(wt, "wt"), dp, ldp, _dev(dwt, "dwt"),
+            _dev(dbias, "dbias"), _dev(dx0, "dx0"), _dev(ws, "workspace"), _stream()), "shmp_trunk_graphs_bwd")
+    return dwt, dbias, dx0
+
+
 def linear_smallk_bwd(feat: torch.Tensor, dout: torch.Tensor):
     """(dwt [K, 64], dbias [64]) of out = feat @ wt + bias (tiny K, 64 output columns) given dout [M, 64]."""
     m, k = feat.shape

@@ -570,6 +570,21 @@ int desco_shmp_trunk_small_bwd_f32(const float* x0, const float* xall, const int
                                    int num_layers, const float* wt_t, const float* dpooled, int64_t ldp, float* dwt,
                                    float* dbias, float* dx0, desco_stream_t stream);
 
+/* round 6: the same trunk with ONE WORKGROUP PER GRAPH (segment), for batches whose graphs have at most
+ * desco_shmp_trunk_graphs_max_rows() (8) rows each -- the 29 query graphs (3..5 nodes; lightning_model.py:204-207): the
+ * graphs are independent of each other, so 29 workgroups stream the layers' weights side by side instead of one
+ * workgroup walking 135 rows behind one weight stream.  Arguments as the _small_ entry points; rows of a segment beyond
+ * the limit are ignored (the caller checks its segment sizes); the backward takes wt itself ([L][192][64], no transposed
+ * copy), seg_ptr instead of seg_id, and a workspace of num_layers * num_rows * 64 floats; no limit on num_rows. */
+int desco_shmp_trunk_graphs_max_rows(void);
+int desco_shmp_trunk_graphs_fwd_f32(const float* x0, const int32_t* vrowptr, const int32_t* vcol, int64_t num_rows,
+                                    int num_layers, const float* wt, const float* bias, const int32_t* seg_ptr,
+                                    int num_seg, float* xall, float* pooled, int64_t ldp, desco_stream_t stream);
+int desco_shmp_trunk_graphs_bwd_f32(const float* x0, const float* xall, const int32_t* vrowptr, const int32_t* vcol,
+                                    const int32_t* t_rowptr, const int32_t* t_col, const int32_t* seg_ptr, int num_seg,
+                                    int64_t num_rows, int num_layers, const float* wt, const float* dpooled, int64_t ldp,
+                                    float* dwt, float* dbias, float* dx0, float* workspace, desco_stream_t stream);
+
 /* Backward of desco_linear_smallk_f32 with n = 64 (pre_mp, gnn_model.py:131; feat carries no gradient):
  * dwb[k][0:64] = sum_m feat[m, k] dout[m, :] for k < K, dwb[K][0:64] = sum_m dout[m, :] (the bias gradient), in one
  * pass over dout and one reduce.  workspace: 512 * (k + 1) * 64 floats. */

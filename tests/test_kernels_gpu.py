@@ -664,6 +664,7 @@ def test_small_trunk_matches_the_layerwise_trunk(layers):
     for small in (True, False):
         a, w, b = (t.clone().to(DEV).requires_grad_() for t in (x0, wt, bias))
         if small:
+            qb.__dict__["_small_per_graph"] = False          # (the per-graph form has its own test below)
             pooled = AG.ShmpTrunkSmall.apply(a, qb, w, b)
         else:
             pooled = AG.ShmpTrunk.apply(a, qb, [("union_node", 0, n, 2)], False, w, b)
@@ -675,6 +676,42 @@ def test_small_trunk_matches_the_layerwise_trunk(layers):
         worst = max(worst, err)
         assert err < 2e-6, (name, err)
     print(f"[parity] single-workgroup trunk vs layer-wise trunk, L={layers}: worst max|d| / max|ref| = {worst:.2e}")
+
+
+@pytest.mark.parametrize("layers", [1, 8])
+def test_per_graph_trunk_matches_the_one_workgroup_trunk(layers):
+    """autograd.ShmpTrunkSmall's two forms: one workgroup per graph (round 6) against the one-workgroup kernels, on the
+    29 standard query graphs and on a batch with 1-row, 2-row and 8-row graphs (the per-graph limit)."""
+    from helpers import standard_queries
+    from desco_amd import autograd as AG
+    from desco_amd.batch import QueryBatch
+    ring8 = (8, [(i, (i + 1) % 8) for i in range(8)] + [(0, 4), (1, 5), (0, 2)])
+    extra = [(1, []), (2, [(0, 1)]), ring8, (3, [(0, 1), (1, 2), (0, 2)]), ring8]
+    for name, graphs in (("standard queries", standard_queries()[1]), ("1..8-row graphs", extra)):
+        qb = QueryBatch(graphs, DEV)
+        n, B = qb.num_rows, qb.num_graphs
+        assert AG.ShmpTrunkSmall.per_graph(qb)
+        g = torch.Generator().manual_seed(layers)
+        x0 = torch.randn(n, 64, generator=g)
+        wt = torch.randn(layers, 192, 64, generator=g) / 10
+        bias = torch.randn(layers, 64, generator=g) / 4
+        seed = torch.randn(B, 64 * (layers + 1), generator=g)
+        res = []
+        for per_graph in (True, False):
+            qb.__dict__["_small_per_graph"] = per_graph
+            a, w, b = (t.clone().to(DEV).requires_grad_() for t in (x0, wt, bias))
+            pooled = AG.ShmpTrunkSmall.apply(a, qb, w, b)
+            (pooled * seed.to(DEV)).sum().backward()
+            res.append((pooled.detach(), a.grad, w.grad, b.grad))
+        worst = 0.0
+        for what, u, v in zip(("pooled", "dx0", "dWt", "dbias"), res[0], res[1]):
+            err = float((u - v).abs().max() / (1e-6 + v.abs().max()))
+            worst = max(worst, err)
+            assert err < 2e-6, (name, what, err)
+        print(f"[parity] per-graph trunk vs one-workgroup trunk, {name}, L={layers}: worst max|d| / max|ref| = {worst:.2e}")
+    # a graph above the limit keeps the one-workgroup form
+    big = QueryBatch([(9, [(i, i + 1) for i in range(8)])], DEV)
+    assert not AG.ShmpTrunkSmall.per_graph(big)
 
 
 def test_small_trunk_refuses_large_batches():
