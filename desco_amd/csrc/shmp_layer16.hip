@@ -103,12 +103,13 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #define DESCO_ANY_STAGED()                                                                    \
   __any((c0 < (n0 < WCAP ? n0 : WCAP)) | (c1 < (n1 < WCAP ? n1 : WCAP)))
 // the row itself: rows beyond nr re-read the wave's last valid row (never stored)
+// (round 6, SHMP16_SELF_EARLY: into registers of their own -- s -- at the tile top, next to the first relation step)
 #define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
     const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDX;                          \
-    u##it_##0 = *reinterpret_cast<const float4*>(p_);                                          \
-    u##it_##1 = *reinterpret_cast<const float4*>(p_ + 32);                                     \
+    DESCO_SELF_REG(it_, 0) = *reinterpret_cast<const float4*>(p_);                             \
+    DESCO_SELF_REG(it_, 1) = *reinterpret_cast<const float4*>(p_ + 32);                        \
   }
 // table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
 #define DESCO_TAB_CUR(it_)                                                                  \
@@ -231,6 +232,35 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 // first step of the first LIVE block after block a_ (a_ = -1: of the tile); dead slots are left
 // out of the software pipeline altogether, so the block behind one is not issued late.  The slot
 // index is a wave-uniform runtime value here (one copy of the gather issue code per site).
+#ifndef SHMP16_SELF_LATE
+#define SHMP16_SELF_EARLY 1
+#endif
+#ifdef SHMP16_SELF_EARLY
+// The rows themselves (the self block's operand) need no index: they are requested at the tile top, together with the
+// first step of the first live relation block, into registers of their own -- one exposed round trip per tile less
+// (the self rows used to be requested under the MFMAs of the last relation block, which are 200 cycles long); the table
+// step moves up with them: it goes out behind the LAST relation block instead of behind the self block.
+#define DESCO_SELF_REG(it_, h_) s##it_##h_
+#define DESCO_ISSUE_AFTER(a_)                                                              \
+  {                                                                                        \
+    if ((a_) < KB - 1) {                                                                   \
+      int nb_ = KB - 1;                                                                    \
+      if ((a_) + 3 < KB - 1 && ((live >> ((a_) + 3)) & 1)) nb_ = (a_) + 3;                  \
+      if ((a_) + 2 < KB - 1 && ((live >> ((a_) + 2)) & 1)) nb_ = (a_) + 2;                  \
+      if ((a_) + 1 < KB - 1 && ((live >> ((a_) + 1)) & 1)) nb_ = (a_) + 1;                  \
+      if (nb_ < KB - 1) {                                                                  \
+        DESCO_CURS(nb_)                                                                    \
+        DESCO_ISSUE2(0, xb, LDX) DESCO_ISSUE2(1, xb, LDX)                                  \
+      } else if (ST > 0 && (live & 0x300)) {                                               \
+        DESCO_ISSUE_TAB(0) DESCO_ISSUE_TAB(1)                                              \
+      }                                                                                    \
+      if ((a_) < 0) {                                                                      \
+        DESCO_ISSUE_SELF(0) DESCO_ISSUE_SELF(1)                                            \
+      }                                                                                    \
+    }                                                                                      \
+  }
+#else
+#define DESCO_SELF_REG(it_, h_) u##it_##h_
 #define DESCO_ISSUE_AFTER(a_)                                                              \
   {                                                                                        \
     if ((a_) < KB - 1) {                                                                   \
@@ -248,6 +278,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
       DESCO_ISSUE_BLOCK((a_) + 1)                                                          \
     }                                                                                      \
   }
+#endif
 // write one fp32 half image (every lane writes: row = it*8 + g8, 4 floats at 4*l8)
 #define DESCO_PUT_F32(av_, it_)                         \
   {                                                     \
@@ -534,6 +565,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   float4 u00, u01, u10, u11;                               // in flight: first source (lo, hi) of row it
   float4 w00, w01, w10, w11;                               // in flight: second source
   w00 = w01 = w10 = w11 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef SHMP16_SELF_EARLY
+  float4 s00, s01, s10, s11;                               // in flight: the rows themselves (requested at the tile top)
+#endif
   int c0 = 0, c1 = 0, n0 = 0, n1 = 0;                      // cursors [c, n) rel. to ebase
   // bit b: relation slot b has at least one source among this wave's 16 rows.  A slot that is empty
   // for the whole wave tile (triangle edges in molecule graphs, tride edges in clique unions) is an
@@ -596,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
       if (b < KB - 1) {
         DESCO_FINISH(xb, LDX)
       } else if (b == KB - 1) {
-        lo0 = u00; hi0 = u01; lo1 = u10; hi1 = u11;
+        lo0 = DESCO_SELF_REG(0, 0); hi0 = DESCO_SELF_REG(0, 1); lo1 = DESCO_SELF_REG(1, 0); hi1 = DESCO_SELF_REG(1, 1);
       } else {
         // canonical->count relations have at most one source per row: one step covers both table
         // slots; anything beyond that (general inputs) takes the cooperative path
@@ -611,6 +645,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
           DESCO_COOP(0, yb + 64, LDY) DESCO_COOP(1, yb + 64, LDY)
         }
       }
+      // (round 6: issuing them one block earlier, behind the gather of the last live relation block, measured 1-2 % SLOWER on
+      //  all three shapes -- profiles/r6_j_ab_dma_early_*.log: the table step then queues behind them)
       if (b == KB - 1 && has_next && S > 0) {
         // CSR slice of the next tile, global -> LDS directly (no staging registers): lane i's dword lands
         // at rpn[i] / ecn[i].  Issued behind the last relation-slot block: vector memory returns in order,
@@ -825,6 +861,7 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_ZERO_SUMS
 #undef DESCO_ANY_STAGED
 #undef DESCO_ISSUE_SELF
+#undef DESCO_SELF_REG
 #undef DESCO_TAB_CUR
 #undef DESCO_ISSUE_TAB
 #undef DESCO_CONSUME_TAB
