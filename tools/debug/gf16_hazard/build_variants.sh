@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p _build
+python3 materialize.py      # the variant sources are kept as patches (gossip_f16_var.patch, old_0d06b19/*.ed)
 CS=../../../desco_amd/csrc
 BASE="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -mllvm -pragma-unroll-threshold=200000 -I$CS"
 g++ -O2 -fPIC -c stub.cpp -o _build/stub.o
