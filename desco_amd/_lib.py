@@ -119,7 +119,7 @@ SIGNATURES = {
     "desco_gossip_f16_stream": (c_int, [vp, vp, vp, vp, vp, vp]),
     "desco_gossip_fused_f16x3_f32": (c_int, [vp, vp, vp, i64, i32] + [vp] * 14 + [f32, vp, vp, vp, vp]),
     "desco_csr_gather_sum_add_f32": (c_int, [vp, i64, vp, vp, i64, vp, i64, vp, i64, vp]),
-    "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]),
+    "desco_shmp_bwd_dx_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp, i64, vp, f32, vp, vp]),
     "desco_add_rows_f32": (c_int, [vp, i64, vp, i64, i64, i32, vp]),
     "desco_gemm_tn_workspace": (ctypes.c_size_t, [i64, i32, i32, POINTER(c_int)]),
     "desco_gemm_tn_f32": (c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, vp]),
@@ -133,8 +133,8 @@ SIGNATURES = {
     "desco_shmp_trunk_small_fwd_f32": (c_int, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp]),
     "desco_shmp_trunk_small_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
     "desco_shmp_trunk_graphs_max_rows": (c_int, []),
-    "desco_shmp_trunk_graphs_fwd_f32": (c_int, [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp, i64, vp]),
-    "desco_shmp_trunk_graphs_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp]),
+    "desco_shmp_trunk_graphs_fwd_f32": (c_int, [vp, vp, vp, i64, i32, vp, vp, vp, i32, POINTER(Dropout), vp, vp, i64, vp]),
+    "desco_shmp_trunk_graphs_bwd_f32": (c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
     "desco_linear_smallk_bwd_f32": (c_int, [vp, i64, i32, vp, i64, i64, vp, vp, vp]),
     "desco_rowdot_bwd_f32": (c_int, [vp, i64, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "desco_adam_step_f32": (c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp]),

@@ -125,14 +125,19 @@ class ShmpTrunk(torch.autograd.Function):
     node owns -- no torch.cat / slice / accumulate kernels between them (the per-op autograd wiring of round 2
     spent as much GPU time in ~900 torch glue launches per step as in the 216 kernels that do the work).
 
-    args: x0, batch (NeighborhoodBatch / QueryBatch), groups [(type, r0, r1, su)], has_anchor, then tensors:
+    ``drop`` = None, or (key, p): F.dropout behind every layer's relu (gnn_model.py:274; --neigh_dropout, default 0.0) as
+    the counter-based factor of (key, site 2 l + row type, row inside the row type, column) in the epilogue of the layer's
+    product (desco_gemm_desc.drop); its backward is the scale 1 / (1 - p) on the relu mask (the kept elements of
+    dropout(relu(z)) are its positive ones).  Layer products of a dropout step run in fp32 in either precision mode.
+
+    args: x0, batch (NeighborhoodBatch / QueryBatch), groups [(type, r0, r1, su)], has_anchor, drop, then tensors:
           [anchor wt (K-major [P, P]), anchor bias] if has_anchor, then per group Wt [L, (su+1) 64, 64] and
           bias [L, 64] (gnn_model.pack_shmp_stacked).
     Gradient of a row of X_l = pooling broadcast + (canonical rows) its column block of d(anchor operand) +
     self block + transposed gather of the aggregate blocks of layer l: assembled in one buffer per layer."""
 
     @staticmethod
-    def forward(ctx, x0, batch, groups, has_anchor, *w):
+    def forward(ctx, x0, batch, groups, has_anchor, drop, *w):
         N, S = batch.num_rows, batch.slots
         dev = x0.device
         H = 64
@@ -150,10 +155,12 @@ class ShmpTrunk(torch.autograd.Function):
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
             xn = xall[l]
-            if PRECISION == "fp32" and len(groups) > 1:
+            if drop is not None or (PRECISION == "fp32" and len(groups) > 1):
                 # the row types' products of one layer are independent: one launch (desco_gemm_f32_multi)
                 ops.gemm_multi([dict(a1=agg[r0:r1, :su * H], a2=X[-1][r0:r1], wt=Wt[g][l], bias=Bs[g][l],
-                                     act=ops.ACT_RELU, out=xn[r0:r1]) for g, (t, r0, r1, su) in enumerate(groups)])
+                                     act=ops.ACT_RELU, out=xn[r0:r1],
+                                     drop=None if drop is None else ops.DropSite(drop[0], 2 * l + g, drop[1]))
+                                for g, (t, r0, r1, su) in enumerate(groups)])
             else:
                 for g, (t, r0, r1, su) in enumerate(groups):
                     if r1 > r0:
@@ -169,6 +176,7 @@ class ShmpTrunk(torch.autograd.Function):
         ops.segment_sum(X[0][:Nc], seg_ptr, B, extra=None if anch is None else anch[:, :H], out=pooled[:, :H])
         ops.segment_sum_layers(xall, Nc, seg_ptr, B, None if anch is None else anch[:, H:], pooled[:, H:])
         ctx.batch, ctx.groups, ctx.has_anchor = batch, groups, has_anchor
+        ctx.mask_scale = 1.0 if drop is None else ops.DropSite(drop[0], 0, drop[1]).scale
         ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
         ctx.save_for_backward(*w)
         return pooled
@@ -212,7 +220,7 @@ class ShmpTrunk(torch.autograd.Function):
             block + transposed gather of the slot blocks of d_rows, times relu'(X_l) (one launch)"""
             return ops.shmp_bwd_dx(d_rows, ti["t_rowptr"], ti["t_col_s1"], Nc, off_count, off_canon,
                                    dpooled[:, l * H:(l + 1) * H], ti["seg_id"],
-                                   None if dcanon is None else dcanon[:, l * H:(l + 1) * H], mask)
+                                   None if dcanon is None else dcanon[:, l * H:(l + 1) * H], mask, ctx.mask_scale)
 
         # dZ of the last layer: its rows feed only the pooling / the anchor operand (one zero row stands in for D:
         # row stride 0, no transposed edges)
@@ -222,7 +230,7 @@ class ShmpTrunk(torch.autograd.Function):
         zero_d, empty_ptr = ti["zero_d"].expand(N, -1), ti["empty_ptr"]
         dz = ops.shmp_bwd_dx(zero_d, empty_ptr, ti["t_col_s1"], Nc, off_count, off_canon,
                              dpooled[:, L * H:(L + 1) * H], ti["seg_id"],
-                             None if dcanon is None else dcanon[:, L * H:(L + 1) * H], X[L])
+                             None if dcanon is None else dcanon[:, L * H:(L + 1) * H], X[L], ctx.mask_scale)
         D = torch.empty((N, (S + 1) * H), device=dev)
         fp32 = PRECISION == "fp32"
         # transposed weights of all layers in one copy per row type (dA = dZ Wt^T wants the n-major operand)
@@ -249,7 +257,7 @@ class ShmpTrunk(torch.autograd.Function):
         for l in range(L):
             AGG[l] = None
         dxn = dz
-        return (dxn, None, None, None) + tuple(grads)
+        return (dxn, None, None, None, None) + tuple(grads)
 
 
 class ShmpTrunkSmall(torch.autograd.Function):
@@ -272,11 +280,19 @@ class ShmpTrunkSmall(torch.autograd.Function):
         return pg
 
     @staticmethod
-    def forward(ctx, x0, batch, wt, bias):
+    def forward(ctx, x0, batch, drop, wt, bias):
         x0, wt, bias = x0.contiguous(), wt.contiguous(), bias.contiguous()
         ctx.per_graph = ShmpTrunkSmall.per_graph(batch)
-        fwd = ops.shmp_trunk_graphs_fwd if ctx.per_graph else ops.shmp_trunk_small_fwd
-        xall, pooled = fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr, batch.num_graphs)
+        ctx.mask_scale = 1.0
+        if drop is not None:          # (key, p): dropout behind every layer's relu -- the per-graph kernels only
+            assert ctx.per_graph
+            site = ops.DropSite(drop[0], 0, drop[1])
+            ctx.mask_scale = site.scale
+            xall, pooled = ops.shmp_trunk_graphs_fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr,
+                                                     batch.num_graphs, drop=site)
+        else:
+            fwd = ops.shmp_trunk_graphs_fwd if ctx.per_graph else ops.shmp_trunk_small_fwd
+            xall, pooled = fwd(x0, batch.vrowptr, batch.vcol, wt, bias, batch.graph_ptr, batch.num_graphs)
         ctx.batch = batch
         ctx.save_for_backward(x0, xall, wt)
         return pooled
@@ -288,13 +304,14 @@ class ShmpTrunkSmall(torch.autograd.Function):
         ti = batch.train_index()
         if ctx.per_graph:
             dwt, dbias, dx0 = ops.shmp_trunk_graphs_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],
-                                                        batch.graph_ptr, batch.num_graphs, wt, dpooled.contiguous())
-            return dx0, None, dwt, dbias
+                                                        batch.graph_ptr, batch.num_graphs, wt, dpooled.contiguous(),
+                                                        ctx.mask_scale)
+            return dx0, None, None, dwt, dbias
         wt_t = torch.empty((wt.shape[0], wt.shape[2], wt.shape[1]), device=wt.device)
         ops.copy2d_multi([(wt[l], wt_t[l], True) for l in range(wt.shape[0])])
         dwt, dbias, dx0 = ops.shmp_trunk_small_bwd(x0, xall, batch.vrowptr, batch.vcol, ti["t_rowptr"], ti["t_col_s1"],
                                                    ti["seg_id"], wt_t, dpooled.contiguous())
-        return dx0, None, dwt, dbias
+        return dx0, None, None, dwt, dbias
 
 
 class SmallKLinear(torch.autograd.Function):
@@ -495,22 +512,32 @@ class Mlp(torch.autograd.Function):
     all weight / bias gradients in one launch pair."""
 
     @staticmethod
-    def forward(ctx, x, acts, w_nk, *wb):
+    def forward(ctx, x, acts, w_nk, drop, *wb):
+        """``drop`` = None, or a DropSite: post_mp.1 = nn.Dropout between post_mp.0 and its LeakyReLU (gnn_model.py:44-53)
+        as the factor of the first layer's epilogue (leaky commutes with a non-negative factor); regenerated in the
+        backward product's epilogue."""
         hs = [x.contiguous()]
         wts = []
         for i, (act, slope) in enumerate(acts):
             wt, b = wb[2 * i].contiguous(), wb[2 * i + 1]
             wts.append(wt)
-            hs.append(_mm_fwd(hs[-1], None, wt, b, act, slope))
-        ctx.acts = acts
-        ctx.save_for_backward(*hs, *[w.detach() for w in w_nk], *wts)
+            if i == 0 and drop is not None:
+                out = torch.empty((hs[-1].shape[0], wt.shape[1]), device=x.device)
+                ops.gemm_multi([dict(a1=hs[-1], wt=wt, bias=b, act=act, slope=slope, out=out, drop=drop)])
+                hs.append(out)
+            else:
+                hs.append(_mm_fwd(hs[-1], None, wt, b, act, slope))
+        ctx.acts, ctx.drop = acts, drop
+        key = x.new_empty(0, dtype=torch.int64) if drop is None else drop.key
+        ctx.save_for_backward(*hs, *[w.detach() for w in w_nk], *wts, key)
         return hs[-1]
 
     @staticmethod
     def backward(ctx, dout):
         n = len(ctx.acts)
         sv = ctx.saved_tensors
-        hs, w_nk, wts = sv[:n + 1], sv[n + 1:2 * n + 1], sv[2 * n + 1:]
+        hs, w_nk, wts = sv[:n + 1], sv[n + 1:2 * n + 1], sv[2 * n + 1:3 * n + 1]
+        drop = None if ctx.drop is None else ops.DropSite(sv[3 * n + 1], ctx.drop.site, ctx.drop.p)
         dev = dout.device
         dz = dout.contiguous()
         act, slope = ctx.acts[n - 1]
@@ -526,18 +553,19 @@ class Mlp(torch.autograd.Function):
                 break
             da = torch.empty((dz.shape[0], wts[i].shape[0]), device=dev)
             w = w_nk[i]
+            dsite = drop if i == 1 else None          # hs[1] = dropout(act_0(z)): its gradient carries the factor again
             if PRECISION == "bf16" and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
                 _mm_bwd_da(dz, wts[i], out=da)
-                if i > 0 and ctx.acts[i - 1][0] != ops.ACT_NONE:
-                    da = ops.act_grad(da, hs[i], *ctx.acts[i - 1])
+                if i > 0 and (ctx.acts[i - 1][0] != ops.ACT_NONE or dsite is not None):
+                    da = ops.act_grad(da, hs[i], *ctx.acts[i - 1], drop=dsite)
             else:
                 pr = dict(a1=dz, wt=w if w.is_contiguous() else w.contiguous(), out=da)
-                if i > 0 and ctx.acts[i - 1][0] != ops.ACT_NONE:
-                    pr.update(gate=hs[i], gate_act=ctx.acts[i - 1][0], gate_slope=ctx.acts[i - 1][1])
+                if i > 0 and (ctx.acts[i - 1][0] != ops.ACT_NONE or dsite is not None):
+                    pr.update(gate=hs[i], gate_act=ctx.acts[i - 1][0], gate_slope=ctx.acts[i - 1][1], drop=dsite)
                 ops.gemm_multi([pr])
             dz = da
         ops.linear_bwd_w_multi(wgrad)
-        return (dz if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+        return (dz if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
 
 
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void shmp_bwd_dx_kernel(const float* __restric
                                                           const float* __restrict__ dpool, int64_t ld_pool,
                                                           const int32_t* __restrict__ seg_id,
                                                           const float* __restrict__ dcanon, int64_t ld_canon,
-                                                          const float* __restrict__ relu_src,
+                                                          const float* __restrict__ relu_src, float mask_scale,
                                                           float* __restrict__ out) {
   const int lane = threadIdx.x & 63, l16 = lane & 15;
   const int64_t row_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
@@ -184,10 +184,12 @@ __global__ __launch_bounds__(256) void shmp_bwd_dx_kernel(const float* __restric
   if (live) {
     if (relu_src) {
       const float4 c = *reinterpret_cast<const float4*>(relu_src + row * 64 + 4 * l16);
-      acc.x = c.x > 0.f ? acc.x : 0.f;
-      acc.y = c.y > 0.f ? acc.y : 0.f;
-      acc.z = c.z > 0.f ? acc.z : 0.f;
-      acc.w = c.w > 0.f ? acc.w : 0.f;
+      // (mask_scale: relu_src = dropout(relu(z)) is positive exactly where the element was kept and z > 0, and the
+      //  gradient passes through the dropout's factor 1 / (1 - p) there -- no mask to regenerate for a relu)
+      acc.x = c.x > 0.f ? acc.x * mask_scale : 0.f;
+      acc.y = c.y > 0.f ? acc.y * mask_scale : 0.f;
+      acc.z = c.z > 0.f ? acc.z * mask_scale : 0.f;
+      acc.w = c.w > 0.f ? acc.w * mask_scale : 0.f;
     }
     *reinterpret_cast<float4*>(out + row * 64 + 4 * l16) = acc;
   }
@@ -649,7 +651,7 @@ extern "C" int desco_shmp_bwd_dx_f32(const float* d, int64_t ldd, const int32_t*
                                      int64_t num_rows, int64_t num_count, int self_off_count,
                                      int self_off_canon, const float* dpool, int64_t ld_pool,
                                      const int32_t* seg_id, const float* dcanon, int64_t ld_canon,
-                                     const float* relu_src, float* out, desco_stream_t stream) {
+                                     const float* relu_src, float mask_scale, float* out, desco_stream_t stream) {
   if (num_rows == 0) return 0;
   auto al16 = [](const void* p_) { return (reinterpret_cast<uintptr_t>(p_) & 15) == 0; };
   if (!d || !t_rowptr || !t_col || !dpool || !seg_id || !out || num_rows < 0 || num_count < 0 ||
@@ -661,7 +663,7 @@ extern "C" int desco_shmp_bwd_dx_f32(const float* d, int64_t ldd, const int32_t*
   if (!grid_ok(blocks)) return fail(DESCO_EINVAL, "desco_shmp_bwd_dx_f32: too many rows");
   hipLaunchKernelGGL(shmp_bwd_dx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d, ldd,
                      t_rowptr, t_col, num_rows, num_count, self_off_count, self_off_canon, dpool, ld_pool,
-                     seg_id, dcanon, ld_canon, relu_src, out);
+                     seg_id, dcanon, ld_canon, relu_src, mask_scale, out);
   return launch_status("desco_shmp_bwd_dx_f32");
 }
 

@@ -259,6 +259,7 @@ struct GFwdArgs {
   int64_t n;
   float* pooled;
   int64_t ldp;
+  DropArgs drop;              // key == nullptr: no dropout; layer l uses site drop.site + 2 l
 };
 
 __global__ __launch_bounds__(GT) void shmp_graphs_fwd_kernel(const GFwdArgs g) {
@@ -335,6 +336,15 @@ __global__ __launch_bounds__(GT) void shmp_graphs_fwd_kernel(const GFwdArgs g) {
         s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
       }
       s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+      if (g.drop.key) {                                                    // F.dropout behind the relu (gnn_model.py:274)
+        DropArgs d = g.drop;
+        d.site += 2 * l;
+        const uint64_t seed = d.key[0], step = d.key[1];
+        s.x *= dropout_factor(d, seed, step, r0 + r, c4);
+        s.y *= dropout_factor(d, seed, step, r0 + r, c4 + 1);
+        s.z *= dropout_factor(d, seed, step, r0 + r, c4 + 2);
+        s.w *= dropout_factor(d, seed, step, r0 + r, c4 + 3);
+      }
       *reinterpret_cast<float4*>(X + r * 64 + c4) = s;
       *reinterpret_cast<float4*>(g.xall + ((int64_t)l * g.n + r0 + r) * 64 + c4) = s;
     }
@@ -355,6 +365,7 @@ struct GBwdArgs {
   int64_t ldp;
   float* dz_all;              // [L][n][64] workspace
   float* dx0;
+  float mask_scale;           // 1, or the dropout factor 1 / (1 - p) of the kept elements
 };
 
 __global__ __launch_bounds__(GT) void shmp_graphs_bwd_kernel(const GBwdArgs g) {
@@ -382,10 +393,10 @@ __global__ __launch_bounds__(GT) void shmp_graphs_bwd_kernel(const GBwdArgs g) {
       const int r = t >> 4, c4 = 4 * (t & 15);
       const float4 x = *reinterpret_cast<const float4*>(g.xall + ((int64_t)l * g.n + r0 + r) * 64 + c4);
       float4 v = *reinterpret_cast<const float4*>(G + 4 * t);
-      v.x = x.x > 0.f ? v.x : 0.f;
-      v.y = x.y > 0.f ? v.y : 0.f;
-      v.z = x.z > 0.f ? v.z : 0.f;
-      v.w = x.w > 0.f ? v.w : 0.f;
+      v.x = x.x > 0.f ? v.x * g.mask_scale : 0.f;
+      v.y = x.y > 0.f ? v.y * g.mask_scale : 0.f;
+      v.z = x.z > 0.f ? v.z * g.mask_scale : 0.f;
+      v.w = x.w > 0.f ? v.w * g.mask_scale : 0.f;
       *reinterpret_cast<float4*>(G + 4 * t) = v;
       *reinterpret_cast<float4*>(g.dz_all + ((int64_t)l * g.n + r0 + r) * 64 + c4) = v;
     }
@@ -531,17 +542,23 @@ extern "C" int desco_shmp_trunk_graphs_max_rows(void) { return desco::small::GMA
 
 extern "C" int desco_shmp_trunk_graphs_fwd_f32(const float* x0, const int32_t* vrowptr, const int32_t* vcol,
                                                int64_t num_rows, int num_layers, const float* wt, const float* bias,
-                                               const int32_t* seg_ptr, int num_seg, float* xall, float* pooled,
-                                               int64_t ldp, desco_stream_t stream) {
+                                               const int32_t* seg_ptr, int num_seg, const desco_dropout* drop,
+                                               float* xall, float* pooled, int64_t ldp, desco_stream_t stream) {
   using namespace desco;
   using namespace desco::small;
   if (num_rows == 0 || num_seg == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  DropArgs da = DropArgs{nullptr, 0u, 0u, 1.f};
+  if (drop) {
+    if (!drop->key || drop->site + 2u * (unsigned)num_layers >= 256u || num_rows > ((int64_t)1 << 34))
+      return fail(DESCO_EINVAL, "desco_shmp_trunk_graphs_fwd_f32: dropout descriptor (key, site + 2 L < 256)");
+    da = DropArgs{drop->key, drop->site, drop->threshold, drop->scale};
+  }
   if (!x0 || !vrowptr || !vcol || !wt || !bias || !seg_ptr || !xall || !pooled || num_rows < 0 || num_layers < 1 ||
       num_seg < 0 || ldp < 64 * (num_layers + 1) || ldp % 4 || mis16(x0) || mis16(wt) || mis16(bias) || mis16(xall) ||
       mis16(pooled))
     return fail(DESCO_EINVAL, "desco_shmp_trunk_graphs_fwd_f32: bad argument (16-byte alignment, ldp >= 64 (L + 1))");
-  GFwdArgs g{x0, vrowptr, vcol, num_layers, wt, bias, seg_ptr, xall, num_rows, pooled, ldp};
+  GFwdArgs g{x0, vrowptr, vcol, num_layers, wt, bias, seg_ptr, xall, num_rows, pooled, ldp, da};
   hipLaunchKernelGGL(shmp_graphs_fwd_kernel, dim3((unsigned)num_seg), dim3(GT), 0, (hipStream_t)stream, g);
   return launch_status("desco_shmp_trunk_graphs_fwd_f32");
 }
@@ -549,8 +566,9 @@ extern "C" int desco_shmp_trunk_graphs_fwd_f32(const float* x0, const int32_t* v
 extern "C" int desco_shmp_trunk_graphs_bwd_f32(const float* x0, const float* xall, const int32_t* vrowptr,
                                                const int32_t* vcol, const int32_t* t_rowptr, const int32_t* t_col,
                                                const int32_t* seg_ptr, int num_seg, int64_t num_rows, int num_layers,
-                                               const float* wt, const float* dpooled, int64_t ldp, float* dwt,
-                                               float* dbias, float* dx0, float* workspace, desco_stream_t stream) {
+                                               const float* wt, const float* dpooled, int64_t ldp, float mask_scale,
+                                               float* dwt, float* dbias, float* dx0, float* workspace,
+                                               desco_stream_t stream) {
   using namespace desco;
   using namespace desco::small;
   if (num_rows == 0 || num_seg == 0) return 0;
@@ -559,7 +577,7 @@ extern "C" int desco_shmp_trunk_graphs_bwd_f32(const float* x0, const float* xal
       !workspace || num_rows < 0 || num_seg < 0 || num_layers < 1 || ldp < 64 * (num_layers + 1) || ldp % 4 ||
       mis16(x0) || mis16(xall) || mis16(wt) || mis16(dpooled) || mis16(dwt) || mis16(dx0) || mis16(workspace))
     return fail(DESCO_EINVAL, "desco_shmp_trunk_graphs_bwd_f32: bad argument (16-byte alignment, ldp >= 64 (L + 1))");
-  GBwdArgs g{xall, t_rowptr, t_col, seg_ptr, num_layers, num_rows, wt, dpooled, ldp, workspace, dx0};
+  GBwdArgs g{xall, t_rowptr, t_col, seg_ptr, num_layers, num_rows, wt, dpooled, ldp, workspace, dx0, mask_scale};
   hipLaunchKernelGGL(shmp_graphs_bwd_kernel, dim3((unsigned)num_seg), dim3(GT), 0, (hipStream_t)stream, g);
   int rc = launch_status("desco_shmp_trunk_graphs_bwd_f32");
   if (rc) return rc;

@@ -344,7 +344,7 @@ class BaseGNN(nn.Module):
             self._pack_cache = (ver, pk)
         return self._pack_cache[1]
 
-    def forward(self, data, query_emb=None):
+    def forward(self, data, query_emb=None, drop_key=None):
         if self.conv_type == "GOSSIP":
             if not isinstance(data, GossipBatch):
                 raise TypeError("gossip BaseGNN.forward expects a desco_amd.batch.GossipBatch")
@@ -358,7 +358,7 @@ class BaseGNN(nn.Module):
                 "homogeneous SAGE (ablation, hetero_graph=False) is out of the hot path; call "
                 "to_hetero_old()/to_hetero() first (main.py:221-224)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return shmp_forward_train(self, data)
+            return shmp_forward_train(self, data, drop_key)
         return shmp_forward(self, data)
 
 
@@ -683,17 +683,25 @@ def fold_shmp_native(gnn: BaseGNN, t: str):
     return AG.FoldShmp.apply(sp, *sp.params)
 
 
-def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
+POST_DROP_SITE = 200      # dropout site of post_mp.1 (the layers use 2 l + row type)
+
+
+def shmp_forward_train(gnn: BaseGNN, batch, drop_key: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Differentiable twin of ``shmp_forward`` (same math, un-fused kernels, autograd Functions from
-    desco_amd.autograd; every forward and backward op is a C-ABI kernel launch)."""
+    desco_amd.autograd; every forward and backward op is a C-ABI kernel launch).  ``drop_key``: the (seed, step) key of
+    this pass's dropout (ops.rng_next), drawn here when None -- callers that run two models on two streams draw both
+    keys first, on one stream (NeighborhoodCountingModel.train_forward)."""
     from . import autograd as AG
     core = gnn.gnn_core
     dev = batch.vrowptr.device
     N, S = batch.num_rows, batch.slots
     import torch.nn.functional as F
-    # --neigh_dropout > 0 (default 0.0, config.py:251): F.dropout after every layer's relu and the
-    # nn.Dropout of post_mp.1, as the reference applies them in training mode
-    drop = gnn.training and float(core.dropout or 0.0) > 0.0
+    # --neigh_dropout > 0 (default 0.0, config.py:251): F.dropout after every layer's relu (gnn_model.py:274) and the
+    # nn.Dropout of post_mp.1 (:46), in training mode: counter-based factors inside the fused nodes' epilogues
+    # (autograd.ShmpTrunk / ShmpTrunkSmall / Mlp), as in the gossip model
+    p_layer = float(core.dropout or 0.0) if gnn.training else 0.0
+    p_post = float(gnn.post_mp[1].p or 0.0) if gnn.training else 0.0
+    drop = p_layer > 0.0 or p_post > 0.0
     if isinstance(batch, NeighborhoodBatch):
         Nc = batch.num_count
         groups = [("count", 0, Nc, 4), ("canonical", Nc, N, 2)]
@@ -707,7 +715,14 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
         feat = batch.__dict__.get("_zero_feat")          # ZeroNodeFeat: a constant of the batch, made once
         if feat is None or feat.shape[1] != core.input_dim:
             feat = batch.__dict__["_zero_feat"] = torch.zeros((N, core.input_dim), device=dev)
-    if FUSED_TRAIN_TRUNK and not drop and all(len(core.slot_keys(t)) == su for t, _, _, su in groups):
+    small = (SMALL_TRUNK_KERNEL and not isinstance(batch, NeighborhoodBatch) and S == 2 and core.layer_num >= 1
+             and 0 < N <= ops.shmp_trunk_small_max_rows())
+    if small and drop and not AG.ShmpTrunkSmall.per_graph(batch):
+        small = False                                   # (only the per-graph kernels carry the dropout factors)
+    if FUSED_TRAIN_TRUNK and all(len(core.slot_keys(t)) == su for t, _, _, su in groups):
+        if drop and drop_key is None:
+            drop_key = ops.rng_next(dev)
+        ldrop = (drop_key, p_layer) if p_layer > 0.0 else None
         # The whole layer loop + anchor + pooling as one autograd node (autograd.ShmpTrunk) on weights folded in
         # stacked form.  Everything between the parameters and that node is this library's kernels too (round 5): the
         # folding reads the parameters through an address table (autograd.FoldShmp), the K-major copies of pre_mp /
@@ -724,15 +739,15 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
         flat = [wts[ng], gnn.anchor_mlp[0].bias] if has_anchor else []
         for t, *_ in groups:
             flat += list(fold_shmp_native(gnn, t))
-        if (SMALL_TRUNK_KERNEL and not has_anchor and S == 2 and len(groups) == 1 and core.layer_num >= 1
-                and 0 < N <= ops.shmp_trunk_small_max_rows()):
-            # the query graphs (135 rows): the whole trunk in one workgroup, one launch per direction
-            pooled = AG.ShmpTrunkSmall.apply(x, batch, *flat)
+        if small and len(groups) == 1:
+            # the query graphs (135 rows): the whole trunk in one launch per direction (one workgroup per graph)
+            pooled = AG.ShmpTrunkSmall.apply(x, batch, ldrop, *flat)
         else:
-            pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, *flat)
+            pooled = AG.ShmpTrunk.apply(x, batch, groups, has_anchor, ldrop, *flat)
         pw = wts[ng + (1 if has_anchor else 0):]
         post = {"post": [(pw[j], gnn.post_mp[i].bias) for j, i in enumerate((0, 3, 5, 7))]}
-        return _post_mp_train(AG, post, gnn, pooled, drop)
+        pdrop = ops.DropSite(drop_key, POST_DROP_SITE, p_post) if p_post > 0.0 else None
+        return _post_mp_train(AG, post, gnn, pooled, pdrop)
     pk = pack_shmp(gnn, bf16_planes=False)   # differentiable folding: grads reach the raw parameters
     ti = batch.train_index()
     x = torch.cat([AG.SmallKLinear.apply(feat[r0:r1], *pk["pre"][t]) for t, r0, r1, _ in groups], 0)
@@ -762,13 +777,16 @@ def shmp_forward_train(gnn: BaseGNN, batch) -> torch.Tensor:
 
 
 def _post_mp_train(AG, pk, gnn, pooled, drop):
+    """post_mp of a training pass.  ``drop``: None / False (no dropout), an ops.DropSite (post_mp.1 as the counter-based
+    factor inside the fused node), or True (the per-op cross-check path: torch's F.dropout)."""
     import torch.nn.functional as F
     (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post"]
-    if not drop:
+    if not drop or isinstance(drop, ops.DropSite):
         # the four Linears and their backward as one autograd node (activation derivatives in the GEMM epilogues, one
         # launch pair for all weight gradients)
         return AG.Mlp.apply(pooled, ((ops.ACT_LEAKY, 0.1), (ops.ACT_RELU, 0.0), (ops.ACT_RELU, 0.0), (ops.ACT_NONE, 0.0)),
-                            tuple(gnn.post_mp[i].weight for i in (0, 3, 5, 7)), w0, b0, w3, b3, w5, b5, w7, b7)
+                            tuple(gnn.post_mp[i].weight for i in (0, 3, 5, 7)), drop if drop else None,
+                            w0, b0, w3, b3, w5, b5, w7, b7)
     if drop:                                                               # post_mp.1 (gnn_model.py:46)
         h = AG.Linear.apply(pooled, None, w0, b0, ops.ACT_NONE, 0.0)
         h = F.leaky_relu(F.dropout(h, p=gnn.post_mp[1].p, training=True), 0.1)

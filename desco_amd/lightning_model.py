@@ -272,6 +272,11 @@ class NeighborhoodCountingModel(_LightningLike):
         # (single process only: under DDP the gradient buckets are all-reduced from autograd hooks, which would run
         #  on the side stream for the query model's parameters while other gradients of the same bucket are still
         #  being written on the main stream)
+        # --neigh_dropout > 0: both models' dropout keys are drawn HERE, on one stream, before the query model's pass
+        # forks onto its own (two streams advancing one (seed, step) counter would race for their keys)
+        kq = kt = None
+        if self.training and self.device.type == "cuda" and float(self.emb_model.gnn_core.dropout or 0.0) > 0.0:
+            kq, kt = ops.rng_next(self.device), ops.rng_next(self.device)
         if OVERLAP_QUERY_TRUNK and self.device.type == "cuda" and D.world_size() == 1:
             # the query model's trunk is ~100 launches on 135 rows: forward (and, through autograd, backward) on a
             # second stream, beside the target batch's launches instead of in front of them (also inside a hipGraph
@@ -282,13 +287,13 @@ class NeighborhoodCountingModel(_LightningLike):
                 side = self.__dict__["_query_stream"] = torch.cuda.Stream(self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                emb_q = self.emb_model_query(self._queries())
-            emb_t = self.emb_model(batch)
+                emb_q = self.emb_model_query(self._queries(), drop_key=kq)
+            emb_t = self.emb_model(batch, drop_key=kt)
             cur.wait_stream(side)
             emb_q.record_stream(cur)
         else:
-            emb_q = self.emb_model_query(self._queries())
-            emb_t = self.emb_model(batch)
+            emb_q = self.emb_model_query(self._queries(), drop_key=kq)
+            emb_t = self.emb_model(batch, drop_key=kt)
         W1, b1 = self.count_model[0].weight, self.count_model[0].bias
         wt_t, wt_q = AG.SplitT.apply(W1, H)                # K-major halves of count_model.0; one gradient for W1
         T = AG.Linear.apply(emb_t, None, wt_t, None, ops.ACT_NONE, 0.0)

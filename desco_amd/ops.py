@@ -162,9 +162,10 @@ def csr_gather_sum_add(x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor,
 
 def shmp_bwd_dx(d: torch.Tensor, t_rowptr: torch.Tensor, t_col: torch.Tensor, num_count: int, off_count: int,
                 off_canon: int, dpool: torch.Tensor, seg_id: torch.Tensor, dcanon: Optional[torch.Tensor],
-                relu_src: Optional[torch.Tensor]) -> torch.Tensor:
+                relu_src: Optional[torch.Tensor], mask_scale: float = 1.0) -> torch.Tensor:
     """Input-row gradient of one SHMP layer of the training trunk (desco_shmp_bwd_dx_f32): seed (pooling
-    broadcast / anchor operand) + self block + transposed gather of the slot blocks, masked by relu'."""
+    broadcast / anchor operand) + self block + transposed gather of the slot blocks, masked by relu' (times
+    ``mask_scale``: the factor 1 / (1 - p) of a dropout behind the relu, whose kept elements are the positive ones)."""
     n = d.shape[0]
     out = torch.empty((n, 64), device=d.device, dtype=torch.float32)
     dp, ldd = _rows(d, "d")
@@ -178,7 +179,8 @@ def shmp_bwd_dx(d: torch.Tensor, t_rowptr: torch.Tensor, t_col: torch.Tensor, nu
         _lib.check(_lib.lib().desco_shmp_bwd_dx_f32(dp, ldd, _dev(t_rowptr, "t_rowptr", torch.int32),
                                                    _dev(tc, "t_col", torch.int32), n, int(num_count), int(off_count),
                                                    int(off_canon), pp, ldp, _dev(seg_id, "seg_id", torch.int32),
-                                                   cp_, ldc, rs, _dev(out, "out"), _stream()), "shmp_bwd_dx")
+                                                   cp_, ldc, rs, float(mask_scale), _dev(out, "out"), _stream()),
+                   "shmp_bwd_dx")
     return out
 
 
@@ -908,9 +910,10 @@ def shmp_trunk_graphs_max_rows() -> int:
     return int(_lib.lib().desco_shmp_trunk_graphs_max_rows())
 
 
-def shmp_trunk_graphs_fwd(x0, vrowptr, vcol, wt, bias, seg_ptr, num_seg):
+def shmp_trunk_graphs_fwd(x0, vrowptr, vcol, wt, bias, seg_ptr, num_seg, drop: "Optional[DropSite]" = None):
     """The SHMP trunk with one workgroup per graph (desco_shmp_trunk_graphs_fwd_f32; graphs of at most
-    shmp_trunk_graphs_max_rows() rows): returns (xall [L, n, 64], pooled [num_seg, 64 (L + 1)])."""
+    shmp_trunk_graphs_max_rows() rows): returns (xall [L, n, 64], pooled [num_seg, 64 (L + 1)]).  ``drop``: F.dropout
+    behind every layer's relu, layer l at site drop.site + 2 l."""
     n, L = x0.shape[0], wt.shape[0]
     assert x0.is_contiguous() and wt.is_contiguous() and bias.is_contiguous() and tuple(wt.shape) == (L, 192, 64)
     xall = torch.empty((L, n, 64), device=x0.device, dtype=torch.float32)
@@ -918,12 +921,13 @@ def shmp_trunk_graphs_fwd(x0, vrowptr, vcol, wt, bias, seg_ptr, num_seg):
     with _Timed("shmp_graphs_fwd_kernel", 2.0 * n * 192 * 64 * L, 4.0 * (num_seg * L * 192 * 64 + (L + 1) * n * 64)):
         _lib.check(_lib.lib().desco_shmp_trunk_graphs_fwd_f32(
             _dev(x0, "x0"), _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), n, L, _dev(wt, "wt"),
-            _dev(bias, "bias"), _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, _dev(xall, "xall"),
+            _dev(bias, "bias"), _dev(seg_ptr, "seg_ptr", torch.int32), num_seg,
+            None if drop is None else ctypes.byref(drop.desc()), _dev(xall, "xall"),
             _dev(pooled, "pooled"), pooled.shape[1], _stream()), "shmp_trunk_graphs_fwd")
     return xall, pooled
 
 
-def shmp_trunk_graphs_bwd(x0, xall, vrowptr, vcol, t_rowptr, t_col_s1, seg_ptr, num_seg, wt, dpooled):
+def shmp_trunk_graphs_bwd(x0, xall, vrowptr, vcol, t_rowptr, t_col_s1, seg_ptr, num_seg, wt, dpooled, mask_scale=1.0):
     """Backward of shmp_trunk_graphs_fwd: (dwt [L, 192, 64], dbias [L, 64], dx0 [n, 64]); two launches."""
     L, n = xall.shape[0], xall.shape[1]
     assert wt.is_contiguous() and tuple(wt.shape) == (L, 192, 64)
@@ -938,7 +942,7 @@ def shmp_trunk_graphs_bwd(x0, xall, vrowptr, vcol, t_rowptr, t_col_s1, seg_ptr, 
         _lib.check(_lib.lib().desco_shmp_trunk_graphs_bwd_f32(
             _dev(x0, "x0"), _dev(xall, "xall"), _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32),
             _dev(t_rowptr, "t_rowptr", torch.int32), _dev(t_col_s1, "t_col", torch.int32),
-            _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, n, L, _dev(wt, "wt"), dp, ldp, _dev(dwt, "dwt"),
+            _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, n, L, _dev(wt, "wt"), dp, ldp, float(mask_scale), _dev(dwt, "dwt"),
             _dev(dbias, "dbias"), _dev(dx0, "dx0"), _dev(ws, "workspace"), _stream()), "shmp_trunk_graphs_bwd")
     return dwt, dbias, dx0
 
@@ -1323,6 +1327,11 @@ class DropSite:
     def __init__(self, key: torch.Tensor, site: int, p: float):
         assert key.dtype == torch.int64 and key.numel() == 2 and key.is_contiguous() and 0 <= site < 256 and 0.0 <= p <= 1.0
         self.key, self.site, self.p = key, site, float(p)
+
+    @property
+    def scale(self) -> float:
+        """the factor of the kept elements, as the kernels apply it (fp32)"""
+        return 0.0 if self.p >= 1.0 else float(torch.tensor(1.0 / (1.0 - self.p), dtype=torch.float32))
 
     def desc(self) -> "_lib.Dropout":
         d = _lib.Dropout()

@@ -498,12 +498,15 @@ int desco_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, i
  * < num_count, self_off_canon for the others), dv = d viewed as rows of 64 floats (t_col indexes them: the
  * transposed index over (row, slot) virtual rows with ldd / 64 blocks per row); seed_i = dpool[seg_id[i]] (the
  * pooling's broadcast gradient, rows ld_pool apart) for i < num_count, dcanon[i - num_count] (NULL: 0) otherwise;
- * mask = (relu_src[i] > 0) elementwise, or 1 when relu_src is NULL.  Replaces a seed build, two adds, the
- * transposed gather and the activation gradient (five launches) of the per-op wiring. */
+ * mask = (relu_src[i] > 0) * mask_scale elementwise, or 1 when relu_src is NULL (mask_scale: 1, or the factor
+ * 1 / (1 - p) of an F.dropout behind the relu, gnn_model.py:273-274: relu_src = dropout(relu(z)) is positive exactly
+ * where the element was kept).  Replaces a seed build, two adds, the transposed gather and the activation gradient
+ * (five launches) of the per-op wiring. */
 int desco_shmp_bwd_dx_f32(const float* d, int64_t ldd, const int32_t* t_rowptr, const int32_t* t_col,
                           int64_t num_rows, int64_t num_count, int self_off_count, int self_off_canon,
                           const float* dpool, int64_t ld_pool, const int32_t* seg_id, const float* dcanon,
-                          int64_t ld_canon, const float* relu_src, float* out, desco_stream_t stream);
+                          int64_t ld_canon, const float* relu_src, float mask_scale, float* out,
+                          desco_stream_t stream);
 
 /* bytes of workspace desco_gemm_tn_f32 needs for this shape (and the number of M slabs it uses) */
 size_t desco_gemm_tn_workspace(int64_t m, int k, int n, int* splits_out);
@@ -575,15 +578,19 @@ int desco_shmp_trunk_small_bwd_f32(const float* x0, const float* xall, const int
  * graphs are independent of each other, so 29 workgroups stream the layers' weights side by side instead of one
  * workgroup walking 135 rows behind one weight stream.  Arguments as the _small_ entry points; rows of a segment beyond
  * the limit are ignored (the caller checks its segment sizes); the backward takes wt itself ([L][192][64], no transposed
- * copy), seg_ptr instead of seg_id, and a workspace of num_layers * num_rows * 64 floats; no limit on num_rows. */
+ * copy), seg_ptr instead of seg_id, and a workspace of num_layers * num_rows * 64 floats; no limit on num_rows.
+ * drop (NULL: none): F.dropout behind every layer's relu (gnn_model.py:274) -- layer l's rows are multiplied by the
+ * factor of (row, col) of site drop->site + 2 l; the backward then takes mask_scale = drop->scale (1 without). */
 int desco_shmp_trunk_graphs_max_rows(void);
 int desco_shmp_trunk_graphs_fwd_f32(const float* x0, const int32_t* vrowptr, const int32_t* vcol, int64_t num_rows,
                                     int num_layers, const float* wt, const float* bias, const int32_t* seg_ptr,
-                                    int num_seg, float* xall, float* pooled, int64_t ldp, desco_stream_t stream);
+                                    int num_seg, const desco_dropout* drop, float* xall, float* pooled, int64_t ldp,
+                                    desco_stream_t stream);
 int desco_shmp_trunk_graphs_bwd_f32(const float* x0, const float* xall, const int32_t* vrowptr, const int32_t* vcol,
                                     const int32_t* t_rowptr, const int32_t* t_col, const int32_t* seg_ptr, int num_seg,
                                     int64_t num_rows, int num_layers, const float* wt, const float* dpooled, int64_t ldp,
-                                    float* dwt, float* dbias, float* dx0, float* workspace, desco_stream_t stream);
+                                    float mask_scale, float* dwt, float* dbias, float* dx0, float* workspace,
+                                    desco_stream_t stream);
 
 /* Backward of desco_linear_smallk_f32 with n = 64 (pre_mp, gnn_model.py:131; feat carries no gradient):
  * dwb[k][0:64] = sum_m feat[m, k] dout[m, :] for k < K, dwb[K][0:64] = sum_m dout[m, :] (the bias gradient), in one

@@ -51,11 +51,12 @@ def sage_conv(sd, key, x_src, n_dst, ei, emulate_quirk, bipartite):
 
 
 def gnn_core_hetero(sd, prefix, feats: Dict[str, torch.Tensor], edge_index: Dict, node_types,
-                    edge_types, layer_num, emulate_quirk=True):
+                    edge_types, layer_num, emulate_quirk=True, layer_masks=None):
     """BaseGNNCore.forward (SAGE branch) after pyg.nn.to_hetero(aggr="sum").
 
     gnn_model.py:230-277; per-type module copies and the pairwise-queue sum over edge types with
-    a common destination type are [EXT].
+    a common destination type are [EXT].  ``layer_masks[l][t]`` [n_t, H]: the factor tensor
+    (0 or 1 / (1 - p)) of F.dropout behind layer l's relu (:274) in training mode, given by the caller (see ``post_mp``).
     """
     x = {t: _lin(sd, f"{prefix}.pre_mp.0.{t}", feats[t]) for t in node_types}      # :231
     emb = dict(x)                                                                   # :253
@@ -74,6 +75,8 @@ def gnn_core_hetero(sd, prefix, feats: Dict[str, torch.Tensor], edge_index: Dict
             x_neigh = q[0]
             h = _lin(sd, f"{prefix}.updates.{l}.{t}", torch.cat((x_neigh, x[t]), dim=1))  # :264
             new_x[t] = F.relu(h)                     # :273 ; dropout p=0 (:274) is the identity
+            if layer_masks is not None:
+                new_x[t] = new_x[t] * layer_masks[l][t]                                 # :274 (training, p > 0)
         x = new_x
         emb = {t: torch.cat((emb[t], x[t]), dim=1) for t in node_types}             # :275
     return emb
@@ -93,26 +96,28 @@ def post_mp(sd, prefix, emb, mask=None):
 
 
 def base_gnn_hetero(sd, prefix, batch: Dict, node_types, edge_types, layer_num, input_dim=1,
-                    feats=None, emulate_quirk=True):
-    """BaseGNN.forward, hetero path, gnn_model.py:58-109.  ``batch`` = oracle.partition.collate()."""
+                    feats=None, emulate_quirk=True, masks=None):
+    """BaseGNN.forward, hetero path, gnn_model.py:58-109.  ``batch`` = oracle.partition.collate().
+    ``masks`` = (layer_masks, post_mask): the dropout factors of a training pass (gnn_core_hetero, post_mp)."""
     if feats is None:       # ZeroNodeFeat / NetworkxToHetero zeros (transforms.py:380-384)
         feats = {t: torch.zeros(batch["num_nodes"][t], input_dim) for t in node_types}
     emb = gnn_core_hetero(sd, f"{prefix}.gnn_core", feats, batch["edge_index"], node_types,
-                          edge_types, layer_num, emulate_quirk)                     # :66
+                          edge_types, layer_num, emulate_quirk,
+                          None if masks is None else masks[0])                       # :66
     if "canonical" in emb:                                                          # :69-73
         emb["canonical"] = F.leaky_relu(_lin(sd, f"{prefix}.anchor_mlp.0", emb["canonical"]), 0.1)
     allemb = torch.cat([emb[t] for t in node_types], dim=0)                          # :88-89
     bvec = torch.cat([_t(batch["batch"][t]).long() for t in node_types])
     pooled = torch.zeros(batch["num_graphs"], allemb.shape[1], dtype=allemb.dtype)
     pooled.index_add_(0, bvec, allemb)                                              # :107 global_add_pool
-    return post_mp(sd, prefix, pooled)                                              # :108
+    return post_mp(sd, prefix, pooled, None if masks is None else masks[1])         # :108
 
 
-def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1, qfeats=None):
+def neighborhood_embed_queries(sd, qbatch, layer_num, input_dim=1, qfeats=None, masks=None):
     """emb_model_query on the query batch (lightning_model.py:204-207).  ``qfeats``
     {"union_node": [sum n, input_dim]}: labelled queries (--use_node_feature); None = zeros."""
     return base_gnn_hetero(sd, "emb_model_query", qbatch, ("union_node",), P.QUERY_EDGE_TYPES,
-                           layer_num, input_dim, qfeats)
+                           layer_num, input_dim, qfeats, masks=masks)
 
 
 def head_logits(sd, emb_t, emb_q):
@@ -148,14 +153,15 @@ def eval_loss_from_logits(logits, y):
 
 
 def neighborhood_logits(sd, batch, qbatch, layer_num=8, input_dim=1, feats=None,
-                        emulate_quirk=True, qfeats=None):
+                        emulate_quirk=True, qfeats=None, masks_t=None, masks_q=None):
     """The [B,Q] pre-exponent outputs of graph_to_count / train_forward.
 
     lightning_model.py:198-219: the queries are re-embedded on every call, then the head loop.
+    ``masks_t`` / ``masks_q``: dropout factors of the target / query model's training pass (base_gnn_hetero).
     """
-    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim, qfeats)
+    emb_q = neighborhood_embed_queries(sd, qbatch, layer_num, input_dim, qfeats, masks_q)
     emb_t = base_gnn_hetero(sd, "emb_model", batch, P.NODE_TYPES, P.EDGE_TYPES, layer_num,
-                            input_dim, feats, emulate_quirk)
+                            input_dim, feats, emulate_quirk, masks_t)
     return head_logits(sd, emb_t, emb_q), emb_q
 
 

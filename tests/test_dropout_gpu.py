@@ -197,3 +197,72 @@ def test_trainer_replays_the_gossip_step_with_dropout(tmp_path, setup):
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
     assert ha == hb
+
+
+@pytest.mark.parametrize("p", [0.2])
+def test_neighborhood_training_with_dropout_vs_oracle_with_the_same_masks(p):
+    """--neigh_dropout p (default 0.0, config.py:251): F.dropout behind every SAGE layer's relu of BOTH models (target
+    and query, gnn_model.py:274) and post_mp.1 (:46) inside the fused training nodes (autograd.ShmpTrunk: the layer
+    products' epilogues; ShmpTrunkSmall: the per-graph kernels; Mlp).  One training step's loss and gradients against
+    torch autograd through the CPU oracle fed with the factor tensors of the step's two keys (query model: the first
+    key drawn, target model: the second)."""
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.lightning_model import NeighborhoodCountingModel
+    from desco_amd.partition import build_partition
+    from desco_amd import gnn_model as GM
+    from oracle import partition as OP
+    from helpers import GRAD_TOL, neigh_args
+    ref0, _ = make_models(seed=0)
+    nm = NeighborhoodCountingModel(1, 64, neigh_args(dropout=p)).to_hetero_old(True, True)
+    nm.load_state_dict(ref0.state_dict())
+    nm = nm.to(DEV)
+    qids, queries = standard_queries()
+    nm.set_queries(qids)
+    graphs = golden_graphs(max_n=41)[:10]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    g = torch.Generator().manual_seed(9)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) ** 3 * 40)
+    batch = NeighborhoodBatch(part, DEV, y=y)
+    seed = 31337
+    ops.manual_seed(seed, step=10)
+    nm.train()
+    nm.zero_grad()
+    loss = nm.train_forward(batch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ops.rng_state(DEV).cpu().tolist() == [seed, 12]             # two keys: query model, target model
+    kq = torch.tensor([seed, 10], dtype=torch.int64, device=DEV)
+    kt = torch.tensor([seed, 11], dtype=torch.int64, device=DEV)
+    Nc, B, nq = batch.num_count, batch.num_graphs, sum(n for n, _ in queries)
+
+    def fac(key, site, pp, rows):
+        return ops.dropout_mask(ops.DropSite(key, site, pp), rows, 64).cpu()
+    masks_t = ([{"count": fac(kt, 2 * l, p, Nc), "canonical": fac(kt, 2 * l + 1, p, B)} for l in range(8)],
+               fac(kt, GM.POST_DROP_SITE, p, B))
+    masks_q = ([{"union_node": fac(kq, 2 * l, p, nq)} for l in range(8)], fac(kq, GM.POST_DROP_SITE, p, len(queries)))
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in nm.state_dict().items()}
+    ref_loss = OM.neighborhood_loss(sd, OP.neighborhood_batch(neighs), OP.query_batch(queries), y, emulate_quirk=False,
+                                    masks_t=masks_t, masks_q=masks_q)
+    ref_loss.backward()
+    assert_loss_close(f"neighborhood train loss, dropout {p}", loss.detach(), ref_loss.detach())
+    plain = OM.neighborhood_loss({k: v.detach() for k, v in sd.items()}, OP.neighborhood_batch(neighs),
+                                 OP.query_batch(queries), y, emulate_quirk=False)
+    assert abs(float(plain) - float(ref_loss.detach())) / abs(float(ref_loss.detach())) > 1e-3     # the masks matter
+    worst, checked = 0.0, 0
+    for name, prm in nm.named_parameters():
+        ref = sd[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        worst = max(worst, assert_grad_close(name, prm.grad, ref, tol=GRAD_TOL))
+        checked += 1
+    print(f"[parity] neighborhood worst relative gradient error at dropout {p} over {checked} tensors: {worst:.3e}")
+    assert checked > 150
+    # eval mode: no dropout, no key drawn
+    nm.eval()
+    before = ops.rng_state(DEV).cpu().tolist()
+    with torch.no_grad():
+        a = nm.graph_to_count(batch)
+        b = nm.graph_to_count(batch)
+    assert torch.equal(a, b) and ops.rng_state(DEV).cpu().tolist() == before

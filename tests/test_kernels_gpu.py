@@ -665,9 +665,9 @@ def test_small_trunk_matches_the_layerwise_trunk(layers):
         a, w, b = (t.clone().to(DEV).requires_grad_() for t in (x0, wt, bias))
         if small:
             qb.__dict__["_small_per_graph"] = False          # (the per-graph form has its own test below)
-            pooled = AG.ShmpTrunkSmall.apply(a, qb, w, b)
+            pooled = AG.ShmpTrunkSmall.apply(a, qb, None, w, b)
         else:
-            pooled = AG.ShmpTrunk.apply(a, qb, [("union_node", 0, n, 2)], False, w, b)
+            pooled = AG.ShmpTrunk.apply(a, qb, [("union_node", 0, n, 2)], False, None, w, b)
         (pooled * seed.to(DEV)).sum().backward()
         res.append((pooled.detach(), a.grad, w.grad, b.grad))
     worst = 0.0
@@ -700,7 +700,7 @@ def test_per_graph_trunk_matches_the_one_workgroup_trunk(layers):
         for per_graph in (True, False):
             qb.__dict__["_small_per_graph"] = per_graph
             a, w, b = (t.clone().to(DEV).requires_grad_() for t in (x0, wt, bias))
-            pooled = AG.ShmpTrunkSmall.apply(a, qb, w, b)
+            pooled = AG.ShmpTrunkSmall.apply(a, qb, None, w, b)
             (pooled * seed.to(DEV)).sum().backward()
             res.append((pooled.detach(), a.grad, w.grad, b.grad))
         worst = 0.0

@@ -947,6 +947,43 @@ def test_gossip_kernel_200_launches_bit_identical(setup):
     assert bad == 0
 
 
+@pytest.mark.parametrize("shape", ["syn_1827", "msrc_imdb", "hubs_ragged"])
+def test_gossip_kernel_repeats_bit_identically_on_dense_hub_and_ragged_shapes(setup, shape):
+    """the weight-fragment ring of gossip_f16.hip issues its LDS reads and counted waits as inline asm, which
+    LLVM's hazard recogniser does not look into; the evidence that no ring slot collides with a dying MFMA result was the
+    200-launch run on ONE (molecule-like) shape.  The same bit-identity check on the other shapes the bench launches the
+    kernel with -- Syn_1827-shaped graphs (dense, hubs of degree 100+: the beyond-four-neighbours loop and its on-demand
+    column loads), MSRC-21 + IMDB-shaped clique unions -- and on a set built to hit the ragged cases: a node count that is
+    not a multiple of the 16-node groups or the 128-node degree tiles, isolated nodes, stars of degree 15, 16, 17 (the
+    staged-column limit WCOLS = 15 sits between them) and 300."""
+    from desco_amd import synthetic
+    nm, gm, qids, queries = setup
+    Q = len(queries)
+    if shape == "hubs_ragged":
+        graphs, n0 = [], 0
+        for deg in (15, 16, 17, 300, 1, 0, 0, 33):
+            graphs.append((deg + 1, [(0, v) for v in range(1, deg + 1)]))
+        graphs += [(7, [(i, i + 1) for i in range(6)]), (1, []), (130, [(i, (i * 7 + 3) % 130) for i in range(130) if i != (i * 7 + 3) % 130])]
+        graphs = [(n, sorted({(min(a, b), max(a, b)) for a, b in es})) for n, es in graphs]
+        gs = GraphSet.from_edge_lists(graphs * 37 + [(5, [(0, 1), (1, 2)])])      # 19 541 nodes: 5 beyond the last 16-node group
+        assert gs.num_nodes % 16 != 0
+    else:
+        gs = synthetic.WORKLOADS[shape]()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(gs.num_nodes, Q, generator=g) * 30
+    gm.set_query_emb(nm.get_query_emb())
+    gb = GossipBatch(gs, DEV, x=x)
+    with torch.no_grad():
+        ref = gm.graph_to_count(gb).clone()
+        assert torch.isfinite(ref).all()
+        bad = 0
+        for _ in range(100):
+            bad += int((gm.graph_to_count(gb).view(torch.int32) != ref.view(torch.int32)).sum())
+    print(f"[stress] {shape}: 100 launches x {gs.num_nodes * Q} results (max degree "
+          f"{int(np.diff(gs.rowptr).max())}): {bad} differ from the first launch")
+    assert bad == 0
+
+
 def test_logit_error_split_by_arithmetic_form(setup):
     """where the 1.5e-5 logit error against the oracle comes from.  The same batch through the three
     arithmetic forms of the matrix products -- f16x3 (default), bf16x6, and the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32:
