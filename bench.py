@@ -539,7 +539,7 @@ def ddp_world1_leg(stride=4):
     env.pop("DESCO_SHARE_GPU", None)
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--ddp-child", "--train-stride", str(stride)],
-                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                           capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"ddp_world1_nccl"')]
         if p.returncode != 0 or not lines:
             return {"status": "error", "returncode": p.returncode, "stderr_tail": p.stderr[-600:]}
