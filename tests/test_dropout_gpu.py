@@ -266,3 +266,48 @@ def test_neighborhood_training_with_dropout_vs_oracle_with_the_same_masks(p):
         a = nm.graph_to_count(batch)
         b = nm.graph_to_count(batch)
     assert torch.equal(a, b) and ops.rng_state(DEV).cpu().tolist() == before
+
+
+def test_trainer_replays_the_neighborhood_step_with_dropout(tmp_path):
+    """Trainer(graph_capture=True) on the neighborhood model at --neigh_dropout 0.1: both models' keys are drawn inside
+    the captured step (two rng_next launches on the capturing stream, the query pass forked after them), so every replay
+    draws fresh masks, and the replayed run equals the eager run bit for bit."""
+    from desco_amd.batch import NeighborhoodBatch
+    from desco_amd.lightning_model import NeighborhoodCountingModel
+    from desco_amd.partition import build_partition
+    from desco_amd.trainer import Trainer
+    from helpers import neigh_args
+    qids, queries = standard_queries()
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=41)[:12]), 4)
+    g = torch.Generator().manual_seed(9)
+    y = torch.floor(torch.rand(part.num_neigh, len(queries), generator=g) ** 3 * 40)
+    cuts = [0, part.num_neigh // 2, part.num_neigh]
+
+    class DM:
+        def _mk(self):
+            return [NeighborhoodBatch(part.slice(a, b), DEV, y=y[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+
+        def train_dataloader(self):
+            return self._mk()
+
+        def val_dataloader(self):
+            return self._mk()[:1]
+
+    outs = []
+    for capture in (False, True):
+        ref0, _ = make_models(seed=2)
+        nm = NeighborhoodCountingModel(1, 64, neigh_args(dropout=0.1)).to_hetero_old(True, True)
+        nm.load_state_dict(ref0.state_dict())
+        nm = nm.to(DEV)
+        nm.set_queries(qids)
+        ops.manual_seed(5)
+        tr = Trainer(max_epochs=3, default_root_dir=str(tmp_path / f"n{int(capture)}"), graph_capture=capture)
+        tr.fit(nm, DM())
+        torch.cuda.synchronize()
+        outs.append(({k: v.detach().clone() for k, v in nm.state_dict().items()}, ops.rng_state(DEV).cpu().tolist(),
+                     [h["neighborhood_counting_val_loss"] for h in tr.history]))
+    (sa, ra, ha), (sb, rb, hb) = outs
+    assert ra == rb == [5, 12]                    # 6 training steps x 2 keys (query model, target model)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert ha == hb
