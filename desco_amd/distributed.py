@@ -445,6 +445,17 @@ def mean_loss_weight(batch_sizes: Sequence[int], group: Sequence[Optional[int]],
     return 0.0 if i is None or tot == 0 else batch_sizes[i] / tot
 
 
+_HOOKED_STEPS = 0      # GradBuckets between zero() and finish(): their hooks issue all-reduces from inside backward
+
+
+def hooks_active() -> bool:
+    """A hook-driven data-parallel step is in progress (GradBuckets.zero() ... finish()): autograd hooks issue bucket
+    all-reduces on whatever stream a gradient is accumulated on, so a forward that forks part of the model onto a second
+    stream must not do so now (NeighborhoodCountingModel.train_forward).  The replayed form (trainer.DDPReplay) packs
+    and reduces after the backward has joined its streams: there the fork is safe."""
+    return _HOOKED_STEPS > 0
+
+
 class GradBuckets:
     """Gradients of a model in ``num_buckets`` flat fp32 buffers; ``p.grad`` are views.
 
@@ -528,6 +539,9 @@ class GradBuckets:
         self._pending = [len(m) for m in self._members]
         self._next = 0                      # buckets are issued strictly in index order on every
         self._handles = []                  # rank (collectives are matched by order)
+        if not self.active:
+            global _HOOKED_STEPS
+            _HOOKED_STEPS += 1
         self.active = True
 
     # -- the replayable form of a step (Trainer's DDPReplay): gradients land in fresh tensors (p.grad = None before the
@@ -617,6 +631,9 @@ class GradBuckets:
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self.active:
+            global _HOOKED_STEPS
+            _HOOKED_STEPS -= 1
         self.active = False
         if self._steps == 0:
             self._demote_unused()

@@ -269,15 +269,16 @@ class NeighborhoodCountingModel(_LightningLike):
         if batch.y is None:
             raise ValueError("train_forward needs batch.y (apply_truth_from_dataset first)")
         from . import distributed as D
-        # (single process only: under DDP the gradient buckets are all-reduced from autograd hooks, which would run
-        #  on the side stream for the query model's parameters while other gradients of the same bucket are still
-        #  being written on the main stream)
+        # (not inside a hook-driven data-parallel step: there the gradient buckets are all-reduced from autograd hooks,
+        #  which would run on the side stream for the query model's parameters while other gradients of the same bucket
+        #  are still being written on the main stream; the replayed data-parallel step reduces after the backward has
+        #  joined its streams and keeps the fork)
         # --neigh_dropout > 0: both models' dropout keys are drawn HERE, on one stream, before the query model's pass
         # forks onto its own (two streams advancing one (seed, step) counter would race for their keys)
         kq = kt = None
         if self.training and self.device.type == "cuda" and float(self.emb_model.gnn_core.dropout or 0.0) > 0.0:
             kq, kt = ops.rng_next(self.device), ops.rng_next(self.device)
-        if OVERLAP_QUERY_TRUNK and self.device.type == "cuda" and D.world_size() == 1:
+        if OVERLAP_QUERY_TRUNK and self.device.type == "cuda" and not D.hooks_active():
             # the query model's trunk is ~100 launches on 135 rows: forward (and, through autograd, backward) on a
             # second stream, beside the target batch's launches instead of in front of them (also inside a hipGraph
             # capture: the side stream forks from and joins the capturing stream)
