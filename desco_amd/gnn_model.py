@@ -50,6 +50,8 @@ SMALL_TRUNK_KERNEL = True
 # True: global_add_pool of the count rows fused into the layer kernel's epilogue (partials per
 # (32-row tile, neighborhood) + a small reduce) instead of one segment_sum pass over X_l per layer
 FUSED_POOLING = True
+# ... and the layers' partials reduced by ONE launch at the end of the layer loop (False: one launch per layer)
+POOL_REDUCE_MULTI = os.environ.get("DESCO_POOL_REDUCE_MULTI", "1") != "0"
 # Training: the SHMP layer loop + anchor + pooling as ONE autograd node whose forward and backward are C-ABI
 # launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
 # --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
@@ -629,11 +631,18 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     else:
         anch = None                                  # query graphs: no canonical node, no anchor
         seg_ptr = batch.graph_ptr
+    if pool_parts and POOL_REDUCE_MULTI:
+        # the layers' partial sums, reduced together: one launch for (up to eight of) them instead of one per layer
+        ls = sorted(pool_parts)
+        ops.pool_reduce_multi([pool_parts[l] for l in ls], pbits, pslot, seg_ptr, B,
+                              [None if anch is None else anch[:, l * H:(l + 1) * H] for l in ls],
+                              [pooled[:, l * H:(l + 1) * H] for l in ls])
     for l, xl in enumerate(X):                                             # :88-89, :107
         extra = None if anch is None else anch[:, l * H:(l + 1) * H]
         out_l = pooled[:, l * H:(l + 1) * H]
         if l in pool_parts:
-            ops.pool_reduce(pool_parts[l], pbits, pslot, seg_ptr, B, extra=extra, out=out_l)
+            if not POOL_REDUCE_MULTI:
+                ops.pool_reduce(pool_parts[l], pbits, pslot, seg_ptr, B, extra=extra, out=out_l)
         elif xl is None:     # constant X_0: the segment sum is (rows in segment) * x0
             t0 = groups[0][0]
             ck = ("pool0_coef", t0)

@@ -398,6 +398,36 @@ def pool_reduce(part: torch.Tensor, bits: torch.Tensor, slot: torch.Tensor, seg_
     return out
 
 
+def pool_reduce_multi(parts, bits: torch.Tensor, slot: torch.Tensor, seg_ptr: torch.Tensor, num_seg: int, extras, outs,
+                      tile_rows: Optional[int] = None) -> None:
+    """``pool_reduce`` for several layers in one launch (desco_pool_reduce_multi_f32, groups of 8): parts[i] -> outs[i]
+    (+ extras[i], or None); the layers share the tile index and the segments.  Bit-identical to the single calls."""
+    L = _lib.lib()
+    tr = pool_tile_rows() if tile_rows is None else tile_rows
+    for i0 in range(0, len(parts), 8):
+        ps, es, os_ = parts[i0:i0 + 8], extras[i0:i0 + 8], outs[i0:i0 + 8]
+        n = len(ps)
+        pa, ea, oa = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        lde = ldo = None
+        for i, (p_, e_, o_) in enumerate(zip(ps, es, os_)):
+            pa[i] = _dev(p_, "pool_part")
+            op, lo = _rows(o_, "out")
+            oa[i] = op
+            assert ldo in (None, lo)
+            ldo = lo
+            if e_ is not None:
+                ep, le = _rows(e_, "extra")
+                ea[i] = ep
+                assert lde in (None, le)
+                lde = le
+        with _Timed("pool_reduce_kernel", float(sum(p_.shape[0] for p_ in ps)) * 64,
+                    sum(256.0 * p_.shape[0] + 4.0 * (2 * bits.numel() + num_seg) + 512.0 * num_seg for p_ in ps)):
+            _lib.check(L.desco_pool_reduce_multi_f32(n, pa, _dev(bits, "pool_bits", torch.int32),
+                                                     _dev(slot, "pool_slot", torch.int32),
+                                                     _dev(seg_ptr, "seg_ptr", torch.int32), num_seg, ea, lde or 0, oa, ldo,
+                                                     tr, _stream()), "pool_reduce_multi")
+
+
 def shmp_kernel_name(kb: int, st: int, x6: bool, f16: bool = False) -> str:
     """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
     the bf16x6 form unless DESCO_SHMP_ROWS=32; always for the fp16 three-product form) and its

@@ -327,6 +327,13 @@ int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, con
                           const int32_t* seg_ptr, int64_t num_seg, const float* extra,
                           int64_t ld_extra, float* out, int64_t ldo, int tile_rows,
                           desco_stream_t stream);
+/* The same reduce for 1..8 layers' partial arrays in one launch (they share the tile index and the segments): HOST arrays
+ * of DEVICE pointers pool_parts[num], extras[num] (or NULL; entries may be NULL), outs[num]; common ld_extra / ldo.
+ * Bit-identical to num calls of desco_pool_reduce_f32. */
+int desco_pool_reduce_multi_f32(int num, const float* const* pool_parts, const uint32_t* pool_bits,
+                                const int32_t* pool_slot, const int32_t* seg_ptr, int64_t num_seg,
+                                const float* const* extras, int64_t ld_extra, float* const* outs, int64_t ldo,
+                                int tile_rows, desco_stream_t stream);
 
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);

@@ -1056,3 +1056,21 @@ def test_empty_loss_and_replaced_parameters(setup):
         nm.emb_model.gnn_core.updates[3]["count"].weight.mul_(0.5)
     g2 = grads()
     assert not torch.equal(g2["emb_model.gnn_core.updates.3.count.weight"], g1["emb_model.gnn_core.updates.3.count.weight"])
+
+
+def test_pool_reduce_in_one_launch_changes_no_bit(setup):
+    """gnn_model.POOL_REDUCE_MULTI: the seven pooled layers' partial sums reduced by one launch
+    (desco_pool_reduce_multi_f32) instead of one launch per layer -- same arithmetic per layer, identical logits."""
+    import desco_amd.gnn_model as GM
+    nm, *_ = setup
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=60) + random_family_graphs(3, 40)), 4)
+    batch = NeighborhoodBatch(part, DEV)
+    outs = []
+    for multi in (True, False):
+        GM.POOL_REDUCE_MULTI = multi
+        try:
+            with torch.no_grad():
+                outs.append(nm._logits(batch, exp2=False).clone())
+        finally:
+            GM.POOL_REDUCE_MULTI = True
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
