@@ -35,8 +35,19 @@ constexpr int AH = 36;        // half-K fp32 table image row stride (floats): co
 constexpr int APS = 32;       // half-K bf16 plane row stride (shorts, 64 B), chunks XOR-swizzled
 constexpr int MAXS = 4;       // relation slots stored per row
 constexpr int RPN = WR * MAXS + 2;
-constexpr int EXTRA_STEPS = 9; // batched 2-source steps after the prefetched one (<= 20 sources per row)
-constexpr int WCAP = 200;     // source ids staged per wave and buffer (longer slices fall back to global)
+// (round 6 sweep on the f16 form with 12 waves, same-box A/B, count-row launch: 5 steps +2.5 %; 14 / 20 / 32 steps -0.9 %
+//  on Syn_1827 shapes and -1.4 % on MSRC-21 + IMDB shapes, COX2 shapes unchanged -- NOT taken: a row of 21..42 sources
+//  is then summed two at a time instead of by the cooperative path's eight partial sums, and which rows of a tile lie
+//  beyond the WCAP staged ids depends on the tile, so the 2-rank-vs-1-rank deviation of the un-chunked pipeline rose
+//  from 5e-5 to 1.05e-4 of 1 + |count|, past its 1e-4 gate (tests/test_multirank_gpu.py))
+#ifndef SHMP16_EXTRA_STEPS
+#define SHMP16_EXTRA_STEPS 9
+#endif
+#ifndef SHMP16_WCAP
+#define SHMP16_WCAP 200
+#endif
+constexpr int EXTRA_STEPS = SHMP16_EXTRA_STEPS; // batched 2-source steps after the prefetched one (<= 20 sources per row)
+constexpr int WCAP = SHMP16_WCAP;     // source ids staged per wave and buffer (longer slices fall back to global)
 constexpr int A_FLOATS = 3 * WR * APS / 2;               // A region per wave: max(16*36, 3*16*32/2) floats (bf16x6 form)
 constexpr int WAVE_LDS = A_FLOATS + 2 * RPN + 2 * WCAP;  // floats per wave
 static_assert(A_FLOATS >= WR * AH, "the fp32 image must fit in the plane region");
@@ -657,10 +668,9 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
         if (lane + 64 < nslot) DESCO_DMA4(src + (lane + 64 < nptr ? lane + 64 : nptr - 1), rpn + 64);
         const int32_t* ids = (g.vcol + ebn_cur) + (unsigned)lane;    // uniform base + 32-bit lane offset
         const int ne = (een_cur - ebn_cur) < WCAP ? (een_cur - ebn_cur) : WCAP;
-        if (lane < ne) DESCO_DMA4(ids, ecn);
-        if (lane + 64 < ne) DESCO_DMA4(ids + 64, ecn + 64);
-        if (lane + 128 < ne) DESCO_DMA4(ids + 128, ecn + 128);
-        if (lane + 192 < ne) DESCO_DMA4(ids + 192, ecn + 192);
+#pragma unroll
+        for (int k_ = 0; k_ < (WCAP + 63) / 64; ++k_)
+          if (lane + 64 * k_ < ne) DESCO_DMA4(ids + 64 * k_, ecn + 64 * k_);
       }
       // ---- the two 32-column halves of block b; the first gather step of block b+1 goes out
       //      under this block's MFMAs (after the low halves have left their registers)
