@@ -143,6 +143,17 @@ __device__ __forceinline__ float absmax16(const f32x4 a, const f32x4 b, const f3
 // so the MFMAs that use them come after it.  The counted wait is safe whatever else the compiler puts in between: LDS
 // operations of a wave return in order, a fragment read is complete once at most as many LGKM operations are outstanding
 // as were issued after it, and lgkmcnt(4) -- the four reads of the one younger pair step -- is at most that number.
+// Hazards the compiler does not see (its hazard recogniser and waitcnt insertion do not look inside the asm):
+//   * RAW on a fragment: covered by GF16_WAIT's counted wait (above).
+//   * WAW against an MFMA result: excluded by construction -- the only MFMA destinations are the accumulators acc0..acc3,
+//     which are live across every REQ / WAIT of a block, and a ring slot is a live asm OUTPUT from its REQ to its last
+//     MFMA: two simultaneously live values never share a register.
+//   * WAR against an MFMA that still reads the slot (a slot re-requested while the MFMAs of its previous contents are in
+//     flight): slot d % 3 is re-requested by REQ(d + 3), which is issued in front of the MFMAs of pair step d + 1 -- the
+//     six MFMAs of pair step d have all been ISSUED by then, an MFMA reads its A / B operands in its first passes, and
+//     the read's data returns an LDS round trip (> 64 cycles, > the 16 cycles of one 16x16x32 MFMA) later.
+//   tests/test_model_gpu.py holds this to bit-identical repeats on molecule, Syn_1827, MSRC-21 + IMDB and hub / ragged
+//   shapes (200 / 100 launches each).
 struct WFrag { f16x8 h0, l0, h1, l1; };          // tiles 2 p (0) and 2 p + 1 (1)
 #define GF16_RD_(dst_, base_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(base_), "n"(off_));
 #define GF16_REQ(d_)                                                                                    \
