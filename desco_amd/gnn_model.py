@@ -52,6 +52,9 @@ SMALL_TRUNK_KERNEL = True
 FUSED_POOLING = True
 # ... and the layers' partials reduced by ONE launch at the end of the layer loop (False: one launch per layer)
 POOL_REDUCE_MULTI = os.environ.get("DESCO_POOL_REDUCE_MULTI", "1") != "0"
+# ... and the closed-form first layer's count launch leaves its partial sums too (desco_degree_affine_pool_f32) instead
+# of a segment-sum pass over the rows it has just written
+POOL_FIRST_LAYER = os.environ.get("DESCO_POOL_FIRST_LAYER", "1") != "0"
 # Training: the SHMP layer loop + anchor + pooling as ONE autograd node whose forward and backward are C-ABI
 # launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
 # --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
@@ -527,11 +530,21 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
         src_of_slot = (lambda t, s: ("count" if s < 2 else "canonical")) if len(groups) == 2 else \
             (lambda t, s: t)
         xn = torch.empty((N, H), device=dev)
+        # the count rows' launch leaves their pooled partial sums like the fused layers' launches do (round 6: saves the
+        # one read of X_1 that its segment sum cost)
+        pool1 = None
+        if (POOL_FIRST_LAYER and FUSED_POOLING and SHMP_BF16X6 and GEMM_BF16X6 and isinstance(batch, NeighborhoodBatch)
+                and Nc > 0 and ops.pool_tile_rows() == 16):
+            pbits1, pslot1, nslots1 = batch.pool_index()
+            pool1 = (pbits1, pslot1, torch.empty((nslots1, H), device=dev))
         for t, r0, r1, su in groups:
             if r1 <= r0:
                 continue
-            ops.degree_affine(batch.vrowptr, r0, r1 - r0, S,
-                              _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev), ops.ACT_RELU, 0.0, xn)
+            coef = _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev)
+            if pool1 is not None and t == "count" and r0 == 0:
+                ops.degree_affine_pool(batch.vrowptr, r1, S, coef, ops.ACT_RELU, 0.0, xn, pool1)
+            else:
+                ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, coef, ops.ACT_RELU, 0.0, xn)
         X = [None, xn]
         first = 1
     else:
@@ -567,6 +580,8 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     pool_parts = {}
     if fpool:
         pbits, pslot, nslots = batch.pool_index()
+        if const_input and first == 1 and pool1 is not None:
+            pool_parts[1] = pool1[2]
     for l in range(first, core.layer_num):
         last = l == core.layer_num - 1
         # the last layer's count rows feed nothing but the pooling: with fused pooling they are
@@ -603,7 +618,7 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
                     ops.gemm(agg[r0:r1, :su * H], e["wt"], e["b"], a2=X[-1][r0:r1],
                              act=ops.ACT_RELU, out=xn[r0:r1])
         X.append(xn)
-        if fpool and direct_canon and l >= 2 and l in pool_parts:
+        if fpool and direct_canon and l >= 1 and l in pool_parts:
             # layer l's rows have been consumed (their pooled sums sit in pool_parts[l], their canonical
             # rows in `canon`): release them -- a block then holds three [N, 64] tensors instead of nine,
             # which is what lets InferencePipeline run blocks of tens of millions of rows

@@ -496,6 +496,20 @@ def degree_affine(vrowptr: torch.Tensor, row0: int, num_rows: int, slots: int, c
     return out
 
 
+def degree_affine_pool(vrowptr: torch.Tensor, num_rows: int, slots: int, coef: torch.Tensor, act: int, slope: float,
+                       out: Optional[torch.Tensor], pool: tuple) -> None:
+    """``degree_affine`` for rows [0, num_rows) with the rows' segment sums fused in (desco_degree_affine_pool_f32):
+    ``pool`` = (pool_bits, pool_slot, pool_part) as for ``shmp_layer(pool=...)`` with 16-row tiles; ``out`` may be None."""
+    assert coef.is_contiguous() and coef.shape == (slots + 1, 64) and pool_tile_rows() == 16
+    bits, slot, part = pool
+    op, ldo = (None, 64) if out is None else _rows(out, "out")
+    with _Timed("degree_affine_kernel", 2.0 * num_rows * slots * 64, 256.0 * num_rows + 4.0 * num_rows * (slots + 1)):
+        _lib.check(_lib.lib().desco_degree_affine_pool_f32(
+            _dev(vrowptr, "vrowptr", torch.int32), num_rows, slots, _dev(coef, "coef"), act, slope, op, ldo,
+            _dev(bits, "pool_bits", torch.int32), _dev(slot, "pool_slot", torch.int32), _dev(part, "pool_part"),
+            _stream()), "degree_affine_pool")
+
+
 def gemm_split(a1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
                a2: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -354,6 +354,14 @@ int desco_degree_affine_f32(const int32_t* vrowptr, int64_t row0, int64_t num_ro
                             const float* coef, int act, float slope, const float* extra,
                             int64_t ld_extra, float* out, int64_t ldo, float* row_absmax,
                             desco_stream_t stream);
+/* The same rows for a launch that starts at row 0 (the count rows), with their global_add_pool (gnn_model.py:88-89, 107)
+ * fused in as in desco_shmp_layer_pool_*: besides storing the rows (out may be NULL) every 16-row tile leaves one partial
+ * row per segment that has a row in it at pool_part[pool_slot[t] + k] (pool_bits / pool_slot: the index of
+ * desco_shmp_layer_pool_bf16x6_f32 for 16-row tiles); desco_pool_reduce(_multi)_f32 finishes the sums.  Saves the one
+ * read of the produced rows that the segment sum of this layer cost. */
+int desco_degree_affine_pool_f32(const int32_t* vrowptr, int64_t num_rows, int slots, const float* coef, int act,
+                                 float slope, float* out, int64_t ldo, const uint32_t* pool_bits,
+                                 const int32_t* pool_slot, float* pool_part, desco_stream_t stream);
 /* row_absmax (optional, [num_rows]): row_absmax[i - row0] = max_c |out[i, c]| is WRITTEN -- the start of the per-row
  * bound desco_gemm_f16x3_f32 takes when these rows are the first column block of its operand. */
 

@@ -1074,3 +1074,41 @@ def test_pool_reduce_in_one_launch_changes_no_bit(setup):
         finally:
             GM.POOL_REDUCE_MULTI = True
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_first_layer_pooling_fused_into_its_launch(setup):
+    """gnn_model.POOL_FIRST_LAYER: the closed-form first layer's count launch leaves per-tile partial sums
+    (desco_degree_affine_pool_f32) instead of a segment-sum pass over the rows it has just written.  Same rows bit for
+    bit; the pooled block is summed in tile order instead of segment_sum's order, so the logits agree to rounding (7e-6
+    measured, through the post MLP) -- and
+    both agree with the oracle within the one gate."""
+    import desco_amd.gnn_model as GM
+    nm, _, qids, queries = setup
+    graphs = golden_graphs(max_n=60) + random_family_graphs(5, 30)
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    batch = NeighborhoodBatch(part, DEV)
+    outs = []
+    for fused in (True, False):
+        GM.POOL_FIRST_LAYER = fused
+        try:
+            with torch.no_grad():
+                outs.append(nm._logits(batch, exp2=False).clone())
+        finally:
+            GM.POOL_FIRST_LAYER = True
+    assert torch.isfinite(outs[0]).all()
+    assert_logits_close("first-layer pooling fused vs segment-sum pass", outs[0], outs[1])
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs), OP.query_batch(queries), emulate_quirk=False)
+    assert_logits_close("fused first-layer pooling vs oracle", outs[0], ref)
+    # kernel level: the partial sums reduce to the segment sums of the rows the launch wrote
+    from desco_amd import ops
+    pbits, pslot, nslots = batch.pool_index()
+    coef = torch.randn(5, 64, device=DEV)
+    xa, xb = torch.empty((batch.num_count, 64), device=DEV), torch.empty((batch.num_count, 64), device=DEV)
+    partials = torch.empty((nslots, 64), device=DEV)
+    ops.degree_affine_pool(batch.vrowptr, batch.num_count, 4, coef, ops.ACT_RELU, 0.0, xa, (pbits, pslot, partials))
+    ops.degree_affine(batch.vrowptr, 0, batch.num_count, 4, coef, ops.ACT_RELU, 0.0, xb)
+    assert torch.equal(xa, xb)
+    got = ops.pool_reduce(partials, pbits, pslot, batch.count_ptr, batch.num_graphs)
+    want = ops.segment_sum(xb, batch.count_ptr, batch.num_graphs)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
