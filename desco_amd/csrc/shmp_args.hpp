@@ -32,6 +32,12 @@ struct ShmpArgs {
   const int32_t* pool_slot;    // [ceil(rows / TR)] first partial slot of TR-row tile t
   float* pool_part;            // [num slots][64] partial segment sums
   int pool_rows;               // TR = 32 (shmp_layer.hip) or 16 (shmp_layer16.hip)
+  // round 6 (16-row form only): the launch's OWN rows (the self block's operand) read from another tensor than the gather
+  // sources: row i of the launch at xself + i * ldxs (i = the same global row index that addresses x).  The canonical
+  // launches use it to read their rows from the anchor operand's column block (row stride 576) -- the only place the
+  // canonical rows are stored since -- and pass out = NULL (rows go to out2 alone).  NULL: the rows come from x.
+  const float* xself;
+  int64_t ldxs;
 };
 
 // 16-row-tile form (shmp_layer16.hip); returns false when the shape is not one it is built for

@@ -803,7 +803,8 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        const float* ytab, int64_t ldy, int64_t ytab_row0, float* out, int64_t ldo,
                        float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream,
                        const uint32_t* pool_bits = nullptr, const int32_t* pool_slot = nullptr,
-                       float* pool_part = nullptr, const float* wscale = nullptr, float* row_absmax = nullptr) {
+                       float* pool_part = nullptr, const float* wscale = nullptr, float* row_absmax = nullptr,
+                       const float* xself = nullptr, int64_t ldxs = 0) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
@@ -813,7 +814,9 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                slots_table != 2))
     return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % tile rows, no out2, "
                               "slots_mfma == 2, slots_table == 2)");
-  if (!x || (!vrowptr && slots_stored > 0) || !weights || (!out && !pool) || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
+  if (xself && (!(x6 && (wscale || shmp_tile_rows() == 16)) || ldxs % 4 || mis16(xself) || pool))
+    return fail(DESCO_EINVAL, "desco_shmp_layer_*: xself is implemented by the 16-row form only (16-byte rows, no pooling)");
+  if (!x || (!vrowptr && slots_stored > 0) || !weights || (!out && !pool && !out2) || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
       slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
       ldx % 4 || (slots_table > 0 && ldy % 4) || mis16(x) || mis16(weights) ||
@@ -856,7 +859,11 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              pool_bits,
              pool_slot,
              pool_part,
-             tile_rows};
+             tile_rows,
+             xself,
+             ldxs};
+  if (!out && !pool && !(x6 && tile_rows == 16))
+    return fail(DESCO_EINVAL, "desco_shmp_layer_*: out == NULL (rows to out2 alone) is implemented by the 16-row form only");
   hipStream_t st = (hipStream_t)stream;
   if (x6 && tile_rows == 16) {
     if (!shmp16_launch(g, cus, stream)) return fail(DESCO_EINVAL, "desco_shmp_layer_bf16x6_f32: shape not built");
@@ -928,12 +935,13 @@ extern "C" int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int
                                           const int16_t* wt_planes, const float* w_scale, const float* bias,
                                           const float* ytab, int64_t ldy, int64_t ytab_row0,
                                           float* out, int64_t ldo, float* out2, int64_t ldo2,
-                                          float* row_absmax, desco_stream_t stream) {
+                                          float* row_absmax, const float* xself, int64_t ldxs,
+                                          desco_stream_t stream) {
   if (!w_scale) return desco::fail(DESCO_EINVAL, "desco_shmp_layer_f16x3_f32: w_scale is null");
   return desco::shmp_launch("desco_shmp_layer_f16x3_f32", true, x, ldx, vrowptr, vcol, row0,
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
                             ldy, ytab_row0, out, ldo, out2, ldo2, DESCO_ACT_RELU, 0.f, stream, nullptr, nullptr,
-                            nullptr, w_scale, row_absmax);
+                            nullptr, w_scale, row_absmax, xself, ldxs);
 }
 
 extern "C" int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr,

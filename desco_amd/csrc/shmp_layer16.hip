@@ -118,7 +118,7 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
-    const float* p_ = xb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDX;                          \
+    const float* p_ = xsb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDXS;                        \
     DESCO_SELF_REG(it_, 0) = *reinterpret_cast<const float4*>(p_);                             \
     DESCO_SELF_REG(it_, 1) = *reinterpret_cast<const float4*>(p_ + 32);                        \
   }
@@ -510,6 +510,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   const int64_t LDX = LD64 ? 64 : g.ldx, LDY = LD64 ? 64 * (ST > 0 ? ST : 1) : g.ldy;
   const int64_t LDO = LD64 ? 64 : g.ldo;
   const float* xb = g.x + 4 * l8;
+  const float* xsb = g.xself ? g.xself + 4 * l8 : xb;      // the launch's own rows (self block): x, or another tensor
+  const int64_t LDXS = g.xself ? g.ldxs : LDX;
   const float* yb = ST > 0 ? g.ytab + 4 * l8 - g.ytab_row0 * LDY : nullptr;
   const float* zrow = shmp16_zero_row + 4 * l8;
   (void)yb;
@@ -820,14 +822,16 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     const int nru = __builtin_amdgcn_readfirstlane(nr_out);
 #define DESCO_ROW(r_) ((r_) < 4 ? q0[(r_) & 3] : (r_) < 8 ? q1[(r_) & 3] : (r_) < 12 ? q2[(r_) & 3] : q3[(r_) & 3])
     if (!POOL || g.out) {
-      float* ob = g.out + grow_out * LDO + lane;               // LD64: row r at the immediate offset 256 r
-      if (nru == 16) {
+      if (g.out) {
+        float* ob = g.out + grow_out * LDO + lane;               // LD64: row r at the immediate offset 256 r
+        if (nru == 16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
-      } else {
+          for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (r < nru) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
+          for (int r = 0; r < 16; ++r)
+            if (r < nru) __builtin_nontemporal_store(DESCO_ROW(r), ob + r * LDO);
+        }
       }
       if (g.out2) {
         float* o2 = g.out2 + (grow_out - g.row0) * g.ldo2 + lane;
@@ -913,7 +917,7 @@ static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) 
 
 template <int NW, int KB, bool F16>
 static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
-  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st) && (!g.out || g.ldo == 64);
+  const bool ld64 = g.ldx == 64 && (g.st == 0 || g.ldy == 64 * g.st) && (!g.out || g.ldo == 64);      // (xself has its own stride)
   if (g.pool_part) {
     if constexpr (KB == 3) {
       if (g.st != 2) return false;

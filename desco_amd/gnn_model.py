@@ -55,6 +55,10 @@ POOL_REDUCE_MULTI = os.environ.get("DESCO_POOL_REDUCE_MULTI", "1") != "0"
 # ... and the closed-form first layer's count launch leaves its partial sums too (desco_degree_affine_pool_f32) instead
 # of a segment-sum pass over the rows it has just written
 POOL_FIRST_LAYER = os.environ.get("DESCO_POOL_FIRST_LAYER", "1") != "0"
+# the canonical rows of every layer are stored ONCE, in their column block of the anchor operand [B, 64 (L + 1)]: the
+# canonical launches read their own rows from there (desco_shmp_layer_f16x3_f32: xself) and the table products too,
+# instead of from a second copy behind the count rows of X_l (False: both copies, rounds 2-5)
+CANON_ROWS_ONCE = os.environ.get("DESCO_CANON_ROWS_ONCE", "1") != "0"
 # Training: the SHMP layer loop + anchor + pooling as ONE autograd node whose forward and backward are C-ABI
 # launches on its own buffers (autograd.ShmpTrunk); False: one autograd Function per op (round 2; kept for
 # --neigh_dropout > 0 and as the cross-check of the fused node's gradients)
@@ -530,6 +534,9 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
         src_of_slot = (lambda t, s: ("count" if s < 2 else "canonical")) if len(groups) == 2 else \
             (lambda t, s: t)
         xn = torch.empty((N, H), device=dev)
+        # (canonical rows only in the anchor operand: the f16x3 fused path with its direct column-block writes)
+        canon_once = (CANON_ROWS_ONCE and isinstance(batch, NeighborhoodBatch) and GEMM_BF16X6 and GEMM_F16X3
+                      and SHMP_BF16X6 and SHMP_F16X3 and N > Nc > 0)
         # the count rows' launch leaves their pooled partial sums like the fused layers' launches do (round 6: saves the
         # one read of X_1 that its segment sum cost)
         pool1 = None
@@ -543,6 +550,8 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
             coef = _first_layer_coef(pk, t, su, S, x0, src_of_slot, dev)
             if pool1 is not None and t == "count" and r0 == 0:
                 ops.degree_affine_pool(batch.vrowptr, r1, S, coef, ops.ACT_RELU, 0.0, xn, pool1)
+            elif t == "canonical" and canon_once:
+                pass                                   # (written below, straight into the anchor operand's block 1)
             else:
                 ops.degree_affine(batch.vrowptr, r0, r1 - r0, S, coef, ops.ACT_RELU, 0.0, xn)
         X = [None, xn]
@@ -556,6 +565,7 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
             ops.linear_smallk(feat[r0:r1], wt, b, out=x[r0:r1])               # :231
         X = [x]
         first = 0
+        canon_once = False
     B = batch.num_graphs
     P = H * (core.layer_num + 1)
     # emb["canonical"] [B, P] (operand of the anchor MLP): the fused canonical launches write their
@@ -593,8 +603,9 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
                     continue
                 e = pk["layers"][l][t]
                 if "wt_tab" in e:
-                    ytab = (ops.linear64(X[-1][Nc:], e["wt_tab_l64"]) if GEMM_BF16X6 else
-                            ops.gemm(X[-1][Nc:], e["wt_tab"]))            # canonical rows x [W2|W3]
+                    crows = canon[:, l * H:(l + 1) * H] if canon_once else X[-1][Nc:]     # canonical rows of X_l
+                    ytab = (ops.linear64(crows, e["wt_tab_l64"]) if GEMM_BF16X6 else
+                            ops.gemm(crows, e["wt_tab"]))                 # canonical rows x [W2|W3]
                     pool = None
                     if fpool and "wt_mfma_x6" in e:
                         pool_parts[l + 1] = torch.empty((nslots, H), device=dev)
@@ -604,12 +615,14 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
                                    e["b"], None if (pool is not None and last) else xn, ytab=ytab,
                                    ytab_row0=Nc, pool=pool)
                 else:
+                    once = canon_once and t == "canonical" and isinstance(e.get("wt_x6"), ops.F16Planes)
                     ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
-                                   e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], xn,
+                                   e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], None if once else xn,
                                    out2=(canon[:, (l + 1) * H:(l + 2) * H]
                                          if direct_canon and t == "canonical" else None),
                                    row_absmax=canon_max if (direct_canon and t == "canonical" and
-                                                            isinstance(e.get("wt_x6"), ops.F16Planes)) else None)
+                                                            isinstance(e.get("wt_x6"), ops.F16Planes)) else None,
+                                   xself=canon[:, l * H:(l + 1) * H] if once else None)
         else:
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)   # [N, S*64]
             for t, r0, r1, su in groups:

@@ -302,8 +302,11 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                num_rows: int, slots_stored: int, slots_mfma: int, wt: torch.Tensor,
                bias: torch.Tensor, out: Optional[torch.Tensor], ytab: Optional[torch.Tensor] = None,
                ytab_row0: int = 0, out2: Optional[torch.Tensor] = None,
-               pool: Optional[tuple] = None, row_absmax: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+               pool: Optional[tuple] = None, row_absmax: Optional[torch.Tensor] = None,
+               xself: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
+    ``xself`` [num_rows, >= 64] (f16x3 form): the launch's own rows (self block) read from this view -- row i of the launch
+    at xself[i - row0] -- instead of from ``x``; ``out`` may then be None when ``out2`` is given.
     ``ytab`` [n_src, 64*st]: pre-transformed sources of the table slots sm .. sm+st-1.
     ``out2`` [num_rows, >=64] (optional): second copy of the produced rows (see desco_hip.h).
     ``wt``: fp32 [(sm+1)*64, 64] (f32 MFMA) or int16 planes [3, 64, (sm+1)*64] =
@@ -323,7 +326,14 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     else:
         assert wt.is_contiguous() and wt.shape == ((slots_mfma + 1) * 64, 64)
     xp, ldx = _rows(x, "x")
-    op, ldo = _rows(out, "out")
+    op, ldo = (None, 64) if out is None else _rows(out, "out")
+    xsp, ldxs = None, 0
+    if xself is not None:
+        if not f16:
+            raise ValueError("shmp_layer: xself is implemented by the f16x3 form only")
+        assert xself.shape[0] == num_rows
+        xsp, ldxs = _rows(xself, "xself")
+        xsp -= 4 * ldxs * row0                       # the entry point indexes it by the global row id
     st, yp, ldy = 0, None, 0
     if ytab is not None:
         st = ytab.shape[1] // 64
@@ -342,7 +352,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
             raise ValueError("shmp_layer: row_absmax is an output of the f16x3 form only")
         if f16:
             rc = L.desco_shmp_layer_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16), _dev(wt.scale, "w_scale"),
-                                              *tail[:-1], _opt(row_absmax, "row_absmax"), tail[-1])
+                                              *tail[:-1], _opt(row_absmax, "row_absmax"), xsp, ldxs, tail[-1])
         else:
             fn = L.desco_shmp_layer_bf16x6_f32 if x6 else L.desco_shmp_layer_f32
             rc = fn(*head, _dev(wt, "wt", wt.dtype), *tail)

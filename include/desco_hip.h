@@ -313,8 +313,11 @@ int desco_shmp_layer_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowp
                                int slots_table, const int16_t* wt_planes, const float* w_scale,
                                const float* bias, const float* ytab, int64_t ldy, int64_t ytab_row0,
                                float* out, int64_t ldo, float* out2, int64_t ldo2, float* row_absmax,
-                               desco_stream_t stream);
-/* row_absmax (optional, [num_rows]): row_absmax[i - row0] = max(row_absmax[i - row0], max_c |out[i, c]|) is ACCUMULATED
+                               const float* xself, int64_t ldxs, desco_stream_t stream);
+/* xself (optional): the launch's OWN rows -- the self block's operand -- are read at xself + i * ldxs (i = the global row
+ * index that addresses x) instead of from x; out may then be NULL when out2 is given (the rows are stored once, in out2's
+ * tensor).  The canonical launches use both: their rows live only in the anchor operand's column blocks.
+ * row_absmax (optional, [num_rows]): row_absmax[i - row0] = max(row_absmax[i - row0], max_c |out[i, c]|) is ACCUMULATED
  * over the launches that fill the column blocks of one operand (out2): its per-row bound for desco_gemm_f16x3_f32. */
 int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
                                     int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,

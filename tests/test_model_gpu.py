@@ -1112,3 +1112,22 @@ def test_first_layer_pooling_fused_into_its_launch(setup):
     got = ops.pool_reduce(partials, pbits, pslot, batch.count_ptr, batch.num_graphs)
     want = ops.segment_sum(xb, batch.count_ptr, batch.num_graphs)
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_canonical_rows_stored_once_changes_no_bit(setup):
+    """gnn_model.CANON_ROWS_ONCE: the canonical rows of every layer live only in their column block of the anchor operand
+    (the canonical launches read their own rows from there -- desco_shmp_layer_f16x3_f32's xself -- and store to out2
+    alone).  Same arithmetic on the same values: identical logits."""
+    import desco_amd.gnn_model as GM
+    nm, *_ = setup
+    part = build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=60) + random_family_graphs(7, 30)), 4)
+    batch = NeighborhoodBatch(part, DEV)
+    outs = []
+    for once in (True, False):
+        GM.CANON_ROWS_ONCE = once
+        try:
+            with torch.no_grad():
+                outs.append(nm._logits(batch, exp2=False).clone())
+        finally:
+            GM.CANON_ROWS_ONCE = True
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
