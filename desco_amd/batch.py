@@ -101,6 +101,14 @@ class NeighborhoodBatch(_TrainIndexMixin):
     def _seg_ptr_device(self):
         return self.count_ptr
 
+    def max_count_rows(self) -> int:
+        """the largest number of count rows of a neighborhood of this batch (host data, cached)"""
+        m = self.__dict__.get("_max_count_rows")
+        if m is None:
+            d = np.diff(self.part.count_ptr)
+            m = self.__dict__["_max_count_rows"] = int(d.max()) if len(d) else 0
+        return m
+
     def pool_index(self, tile_rows: Optional[int] = None):
         """(pool_bits, pool_slot, num_slots) of the fused pooling (desco_shmp_layer_pool_bf16x6_f32):
         per wave tile (``tile_rows`` = 16 or 32 count rows; default: what the library's layer kernel

@@ -38,7 +38,17 @@ struct GemmSplitArgs {
   float* c;
   int64_t ldc;
   int64_t m;
+  // POOLA instantiation (desco_pool_post_bf16x6_f32): the A operand is never materialised -- row b, column 64 l + c is
+  //   a1[b, 64 l + c]  +  (l == 0 ? rows(b) * x0[c] : sum over the <= 3 tiles of segment b of part[l][slot][c])
+  // i.e. the anchor rows plus the fused pooling's partial sums (desco_pool_reduce_f32's arithmetic, same order)
+  const int32_t* seg_ptr;
+  const uint32_t* pool_bits;
+  const int32_t* pool_slot;
+  const float* part[9];     // [1..8]: the layers' partial arrays [slots][64]
+  const float* x0;          // [64]: the constant first block's row
 };
+
+__device__ __attribute__((aligned(16))) float gs_zero_row[64] = {};
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
@@ -56,7 +66,7 @@ __device__ __forceinline__ int gs_chunk(const int row, const int c) { return ((c
 // BM = rows per block tile (128: 4 waves, two blocks per CU).  The A chunk AFTER the next one is kept
 // in flight too: one chunk of MFMAs (2 304 cycles) does not cover an HBM round trip under load, two do
 // (144 -> 156 TF/s fp32-equivalent on the 576^2 anchor GEMM).
-template <int WN, int NP, int BM>
+template <int WN, int NP, int BM, bool POOLA = false>
 __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
   constexpr int NT = 2 * BM;                   // threads
   constexpr int BN = 64 * WN, BPLANE = BN * SST, APLANE = BM * SST;
@@ -109,6 +119,30 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
 
   float4 ra0, ra1, ra2, ra3;                   // A chunk about to be stored
   float4 rn0, rn1, rn2, rn3;                   // A chunk after it (two chunks of latency cover)
+  // POOLA: the segment's partial rows of the chunk's layer, three per row (absent ones read a row of zeros), for both
+  // chunks in flight; per row the offsets of its (at most three) slots and its row count
+  float4 qa00, qa01, qa02, qa10, qa11, qa12, qa20, qa21, qa22, qa30, qa31, qa32;
+  float4 qn00, qn01, qn02, qn10, qn11, qn12, qn20, qn21, qn22, qn30, qn31, qn32;
+  int so00 = 0, so01 = -1, so02 = -1, so10 = 0, so11 = -1, so12 = -1, so20 = 0, so21 = -1, so22 = -1, so30 = 0,
+      so31 = -1, so32 = -1;                    // (float offsets slot * 64: the entry point checks they fit 31 bits)
+  float nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f;
+  float4 x0a = make_float4(0.f, 0.f, 0.f, 0.f), x0b = x0a;
+  if constexpr (POOLA) {
+#define DESCO_POOL_ROW(j_, r_)                                                                                  \
+  {                                                                                                             \
+    const int a_ = g.seg_ptr[r_], e_ = g.seg_ptr[(r_) + 1];                                                     \
+    const int t0_ = a_ >> 4, t1_ = (e_ - 1) >> 4, f_ = a_ - (t0_ << 4);                                         \
+    so##j_##0 = (g.pool_slot[t0_] + __popc(g.pool_bits[t0_] & ((1u << f_) - 1u))) * 64;                         \
+    so##j_##1 = t1_ > t0_ ? g.pool_slot[t0_ + 1] * 64 : -1;                                                     \
+    so##j_##2 = t1_ > t0_ + 1 ? g.pool_slot[t0_ + 2] * 64 : -1;                                                 \
+    nb##j_ = (float)(e_ - a_);                                                                                  \
+  }
+    DESCO_POOL_ROW(0, r0) DESCO_POOL_ROW(1, r1) DESCO_POOL_ROW(2, r2) DESCO_POOL_ROW(3, r3)
+#undef DESCO_POOL_ROW
+    x0a = *reinterpret_cast<const float4*>(g.x0 + 4 * ac4);
+    x0b = *reinterpret_cast<const float4*>(g.x0 + 32 + 4 * ac4);
+  }
+  (void)qa00; (void)qn00; (void)nb0; (void)x0a; (void)x0b;
   uint4 rb00, rb01, rb02, rb10, rb11, rb12, rb20, rb21, rb22;   // W planes of the next chunk
   rb00 = rb01 = rb02 = rb10 = rb11 = rb12 = rb20 = rb21 = rb22 = make_uint4(0, 0, 0, 0);
 #define DESCO_LOAD_A(d_, kk_)                                                                 \
@@ -119,6 +153,35 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
     d_##1 = *reinterpret_cast<const float4*>((s1_ ? p11 : p21) + k_);                         \
     d_##2 = *reinterpret_cast<const float4*>((s1_ ? p12 : p22) + k_);                         \
     d_##3 = *reinterpret_cast<const float4*>((s1_ ? p13 : p23) + k_);                         \
+  }
+// POOLA: the partial rows of chunk kk_ (layer l = kk_ / 64; block 0 has none: its term is rows(b) * x0)
+#define DESCO_LOAD_Q1(d_, j_, P_)                                                             \
+  {                                                                                           \
+    d_##j_##0 = *reinterpret_cast<const float4*>((P_) ? (P_) + so##j_##0 : zr_);              \
+    d_##j_##1 = *reinterpret_cast<const float4*>((P_) && so##j_##1 >= 0 ? (P_) + so##j_##1 : zr_);  \
+    d_##j_##2 = *reinterpret_cast<const float4*>((P_) && so##j_##2 >= 0 ? (P_) + so##j_##2 : zr_);  \
+  }
+#define DESCO_LOAD_Q(d_, kk_)                                                                 \
+  if constexpr (POOLA) {                                                                      \
+    const int kq_ = (kk_);                                                                    \
+    const int lq_ = kq_ >> 6;                                                                 \
+    const float* zr_ = gs_zero_row + 4 * ac4;                                                 \
+    const float* pq_ = lq_ > 0 ? g.part[lq_] + (kq_ & 63) + 4 * ac4 : nullptr;                \
+    DESCO_LOAD_Q1(d_, 0, pq_) DESCO_LOAD_Q1(d_, 1, pq_) DESCO_LOAD_Q1(d_, 2, pq_) DESCO_LOAD_Q1(d_, 3, pq_)  \
+  }
+// pooled row = ((p0 + p1) + p2) + anchor row (desco_pool_reduce_f32's order); block 0: rows(b) * x0 + anchor row, the
+// product rounded on its own (as desco_degree_affine_f32 forms it)
+#define DESCO_POOL_SUM(v_, j_, xq_)                                                           \
+  {                                                                                           \
+    float4 t_;                                                                                \
+    t_.x = (((qa##j_##0).x + (qa##j_##1).x) + (qa##j_##2).x) + __fmul_rn(nb##j_, (xq_).x);          \
+    t_.y = (((qa##j_##0).y + (qa##j_##1).y) + (qa##j_##2).y) + __fmul_rn(nb##j_, (xq_).y);          \
+    t_.z = (((qa##j_##0).z + (qa##j_##1).z) + (qa##j_##2).z) + __fmul_rn(nb##j_, (xq_).z);          \
+    t_.w = (((qa##j_##0).w + (qa##j_##1).w) + (qa##j_##2).w) + __fmul_rn(nb##j_, (xq_).w);          \
+    v_.x = t_.x + v_.x;                                                                       \
+    v_.y = t_.y + v_.y;                                                                       \
+    v_.z = t_.z + v_.z;                                                                       \
+    v_.w = t_.w + v_.w;                                                                       \
   }
 #define DESCO_LOAD_WJ(j_, v_)                                                                 \
   if (BJ > (j_) && (v_)) {                                                                    \
@@ -175,17 +238,29 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   DESCO_LOAD_A(ra, 0)
+  DESCO_LOAD_Q(qa, 0)
   DESCO_LOAD_W(0)
   DESCO_LOAD_A(rn, (nchunks > 1 ? 1 : 0) * SBK)
+  DESCO_LOAD_Q(qn, (nchunks > 1 ? 1 : 0) * SBK)
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch > 0) __syncthreads();          // previous chunk's fragments have been read
+    if constexpr (POOLA) {
+      const float4 zq_ = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 xq_ = ch == 0 ? x0a : ch == 1 ? x0b : zq_;
+      DESCO_POOL_SUM(ra0, 0, xq_) DESCO_POOL_SUM(ra1, 1, xq_) DESCO_POOL_SUM(ra2, 2, xq_) DESCO_POOL_SUM(ra3, 3, xq_)
+    }
     DESCO_STORE_CHUNK()
     __syncthreads();
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
     const int chnn = ch + 2 < nchunks ? ch + 2 : chn;
     ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;
+    if constexpr (POOLA) {
+      qa00 = qn00; qa01 = qn01; qa02 = qn02; qa10 = qn10; qa11 = qn11; qa12 = qn12;
+      qa20 = qn20; qa21 = qn21; qa22 = qn22; qa30 = qn30; qa31 = qn31; qa32 = qn32;
+    }
     DESCO_LOAD_W(chn * SBK)                // in flight under the MFMAs
     DESCO_LOAD_A(rn, chnn * SBK)           // two chunks ahead (HBM latency)
+    DESCO_LOAD_Q(qn, chnn * SBK)
     // lane (r = lane&31, h = lane>>5): A[row r][k = 16 s + 8 h + j], B[k = 16 s + 8 h + j][col r]
     // (row + 32 i / 32 j keeps (row >> 3) & 3, so one swizzle per lane serves every tile)
     const int fsw = (lane >> 3) & 3, fh = lane >> 5;
@@ -230,6 +305,9 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
     }
   }
 #undef DESCO_LOAD_A
+#undef DESCO_LOAD_Q
+#undef DESCO_LOAD_Q1
+#undef DESCO_POOL_SUM
 #undef DESCO_LOAD_W
 #undef DESCO_LOAD_WJ
 #undef DESCO_PUT
@@ -363,7 +441,7 @@ static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, i
       (k2 > 0 && mis16(a2)) || mis16(w))
     return fail(DESCO_EINVAL, who);
   GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w), n, bias,
-                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m};
+                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m, nullptr, nullptr, nullptr, {}, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (np == 3) {
     if (n % 192 == 0) return launch_gemm_split<3, 3>(g, st);
@@ -383,6 +461,48 @@ extern "C" int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, cons
   return gemm_planes("desco_gemm_bf16x6_f32: bad argument (k%32, n%64, 16-byte alignment)", 3, a1, lda1,
                      k1, a2, lda2, k2, w_planes, n, bias, bias_rows, s, ns, ws, act, slope, c, ldc, m,
                      stream);
+}
+
+// post_mp.0 on the pooled embeddings WITHOUT materialising them (round 6): pooled[b] = anchor row + the fused pooling's
+// partial sums was written by desco_pool_reduce_f32 and read straight back by this product -- 5.5 GB per COX2 x64 pass.
+// The POOLA instantiation forms the operand's chunks in its load phase: per row the (at most three) slots of its
+// segment are looked up once, a chunk of layer l is the anchor chunk + the segment's partial rows of that layer.
+extern "C" int desco_pool_post_bf16x6_f32(const float* anch, int64_t lda, int num_layers, const int16_t* w_planes, int n,
+                                          const float* bias, int act, float slope, float* c, int64_t ldc, int64_t m,
+                                          const int32_t* seg_ptr, const uint32_t* pool_bits, const int32_t* pool_slot,
+                                          const float* const* parts, const float* x0, int tile_rows,
+                                          desco_stream_t stream) {
+  using namespace desco;
+  if (m == 0) return 0;
+  if (m > (int64_t)(1 << 24)) return fail(DESCO_EINVAL, "desco_pool_post_bf16x6_f32: more than 2^24 segments (slot offsets are 31 bits)");
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (m < 0 || !anch || !w_planes || !c || num_layers < 1 || num_layers > 8 || n != 64 || !seg_ptr || !pool_bits ||
+      !pool_slot || !parts || !x0 || tile_rows != 16 || lda % 4 || lda < 64 * (num_layers + 1) || mis16(anch) ||
+      mis16(w_planes) || mis16(x0))
+    return fail(DESCO_EINVAL, "desco_pool_post_bf16x6_f32: bad argument (n == 64, 1..8 pooled layers, 16-row tiles)");
+  GemmSplitArgs g{anch, lda, 64 * (num_layers + 1), nullptr, 0, 0, reinterpret_cast<const short*>(w_planes), n, bias, 1,
+                  nullptr, 0, nullptr, act, slope, c, ldc, m, seg_ptr, pool_bits, pool_slot, {}, x0};
+  for (int l = 1; l <= num_layers; ++l) {
+    if (!parts[l - 1] || mis16(parts[l - 1])) return fail(DESCO_EINVAL, "desco_pool_post_bf16x6_f32: NULL / misaligned partial array");
+    g.part[l] = parts[l - 1];
+  }
+  constexpr int BM = 128;
+  constexpr size_t stage_bytes = (size_t)(3 * BM * SST + 3 * 64 * SST) * sizeof(short);
+  constexpr size_t epi_bytes = (size_t)(BM / 32) * 32 * 32 * sizeof(float);
+  constexpr size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+  static DeviceOnce attr_once;
+  if (!attr_once.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<1, 3, BM, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "desco_pool_post_bf16x6_f32: cannot size LDS");
+    attr_once.mark();
+  }
+  const int64_t gm = (m + BM - 1) / BM;
+  const int64_t blocks = ((gm + 7) / 8) * 8;
+  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_pool_post_bf16x6_f32: m too large");
+  hipLaunchKernelGGL((gemm_split_kernel<1, 3, BM, true>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
+                     (hipStream_t)stream, g, gm, 1);
+  return launch_status("desco_pool_post_bf16x6_f32");
 }
 
 // Plain bf16 MFMA GEMM with fp32 accumulation and fp32 output (bf16 training mode): A is rounded

@@ -458,13 +458,21 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     return pk
 
 
+class _PostMp0(object):
+    """post_mp.0's output computed by _shmp_pooled itself (the pooled operand never materialised)"""
+    __slots__ = ("h0",)
+
+    def __init__(self, h0):
+        self.h0 = h0
+
+
 def _post_mp(pk, pooled):
     if GEMM_BF16X6 and "post_nk" in pk:
         def lin(a, w, b, act=ops.ACT_NONE, slope=0.0):
             f = ops.linear64 if w.dim() == 4 else ops.gemm_split
             return f(a, w, b, act=act, slope=slope)
         (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post_nk"]
-        h = lin(pooled, w0, b0, ops.ACT_LEAKY, 0.1)
+        h = pooled.h0 if isinstance(pooled, _PostMp0) else lin(pooled, w0, b0, ops.ACT_LEAKY, 0.1)
         h = lin(h, w3, b3, ops.ACT_RELU)
         h = lin(h, w5, b5, ops.ACT_RELU)
         return lin(h, w7, b7)
@@ -508,12 +516,17 @@ def _anchor_const_input(pk, gnn, canon, row_bound=None):
     return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1, **kw)
 
 
+# the pooled embeddings [B, 64 (L + 1)] are never written: post_mp.0 forms its operand's chunks from the anchor rows and
+# the fused pooling's partial sums in its load phase (desco_pool_post_bf16x6_f32; neighborhoods of at most 33 count rows)
+POOL_POST_FUSED = os.environ.get("DESCO_POOL_POST_FUSED", "1") != "0"
+
+
 def shmp_forward(gnn: BaseGNN, batch) -> torch.Tensor:
     """BaseGNN.forward, hetero path (gnn_model.py:58-109) -> graph embeddings [B, 64]."""
-    return _post_mp(gnn.packed(), _shmp_pooled(gnn, batch))                 # :108
+    return _post_mp(gnn.packed(), _shmp_pooled(gnn, batch, fuse_post0=True))                 # :108
 
 
-def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
+def _shmp_pooled(gnn: BaseGNN, batch, fuse_post0: bool = False):
     """The pooled embeddings [B, 64 (L+1)] of BaseGNN.forward before post_mp (gnn_model.py:58-107)."""
     pk = gnn.packed()
     core = gnn.gnn_core
@@ -659,6 +672,12 @@ def _shmp_pooled(gnn: BaseGNN, batch) -> torch.Tensor:
     else:
         anch = None                                  # query graphs: no canonical node, no anchor
         seg_ptr = batch.graph_ptr
+    if (fuse_post0 and POOL_POST_FUSED and anch is not None and const_input and first == 1 and GEMM_BF16X6
+            and "post_nk" in pk and sorted(pool_parts) == list(range(1, core.layer_num + 1)) and core.layer_num <= 8
+            and ops.pool_tile_rows() == 16 and batch.max_count_rows() <= 33):
+        w0, b0 = pk["post_nk"][0]
+        return _PostMp0(ops.pool_post(anch, [pool_parts[l] for l in range(1, core.layer_num + 1)], pbits, pslot, seg_ptr,
+                                      x0[groups[0][0]], w0, b0, ops.ACT_LEAKY, 0.1))
     if pool_parts and POOL_REDUCE_MULTI:
         # the layers' partial sums, reduced together: one launch for (up to eight of) them instead of one per layer
         ls = sorted(pool_parts)

@@ -438,6 +438,26 @@ def pool_reduce_multi(parts, bits: torch.Tensor, slot: torch.Tensor, seg_ptr: to
                                                      tr, _stream()), "pool_reduce_multi")
 
 
+def pool_post(anch: torch.Tensor, parts, bits: torch.Tensor, slot: torch.Tensor, seg_ptr: torch.Tensor, x0: torch.Tensor,
+              w_planes: torch.Tensor, bias: torch.Tensor, act: int, slope: float) -> torch.Tensor:
+    """act(pooled @ W^T + bias) [B, 64] with pooled = [anch block 0 + rows * x0 | anch block l + segment sums of parts[l-1]]
+    formed inside the product (desco_pool_post_bf16x6_f32): ``parts`` = the pooled layers' partial arrays (layers 1..L),
+    ``w_planes`` = split_bf16_planes(W) [3, 64, 64 (L + 1)].  Every segment must span at most three 16-row tiles."""
+    B, L = anch.shape[0], len(parts)
+    assert tuple(w_planes.shape) == (3, 64, 64 * (L + 1)) and w_planes.is_contiguous() and anch.shape[1] >= 64 * (L + 1)
+    assert x0.is_contiguous() and x0.numel() == 64 and pool_tile_rows() == 16
+    out = torch.empty((B, 64), device=anch.device, dtype=torch.float32)
+    ap, lda = _rows(anch, "anch")
+    pa = (ctypes.c_void_p * L)(*[_dev(p_, "pool_part") for p_ in parts])
+    with _Timed("gemm_split_kernel", 2.0 * B * 64 * 64 * (L + 1),
+                4.0 * B * 64 * (L + 2) + sum(256.0 * p_.shape[0] for p_ in parts)):
+        _lib.check(_lib.lib().desco_pool_post_bf16x6_f32(
+            ap, lda, L, _dev(w_planes, "w_planes", torch.int16), 64, _dev(bias.contiguous(), "bias"), act, slope,
+            _dev(out, "out"), 64, B, _dev(seg_ptr, "seg_ptr", torch.int32), _dev(bits, "pool_bits", torch.int32),
+            _dev(slot, "pool_slot", torch.int32), pa, _dev(x0, "x0"), 16, _stream()), "pool_post")
+    return out
+
+
 def shmp_kernel_name(kb: int, st: int, x6: bool, f16: bool = False) -> str:
     """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
     the bf16x6 form unless DESCO_SHMP_ROWS=32; always for the fp16 three-product form) and its

@@ -338,6 +338,18 @@ int desco_pool_reduce_multi_f32(int num, const float* const* pool_parts, const u
                                 const float* const* extras, int64_t ld_extra, float* const* outs, int64_t ldo,
                                 int tile_rows, desco_stream_t stream);
 
+/* post_mp.0 (gnn_model.py:44-53, first Linear) on the pooled embeddings WITHOUT materialising them: row b of the operand is
+ *   [ anch[b, 0:64] + rows(b) * x0 | anch[b, 64 l : 64 (l + 1)] + sum of segment b's partial rows of layer l, l = 1..L ]
+ * (what desco_pool_reduce_f32 would have written, same summation order), formed in the product's load phase:
+ *   c[b, 0:64] = act( operand[b, :] * W^T + bias ),  W as desco_split_bf16x3_f32 planes [3][64][64 (L + 1)].
+ * anch: [m, >= 64 (L + 1)]; parts: HOST array of the L layers' DEVICE partial arrays; seg_ptr / pool_bits / pool_slot: the
+ * fused pooling's index for 16-row tiles.  EVERY SEGMENT MUST LIE IN AT MOST THREE TILES (<= 33 rows; the caller checks:
+ * further tiles are ignored).  Saves the write and the read of the pooled [m, 64 (L + 1)] tensor. */
+int desco_pool_post_bf16x6_f32(const float* anch, int64_t lda, int num_layers, const int16_t* w_planes, int n,
+                               const float* bias, int act, float slope, float* c, int64_t ldc, int64_t m,
+                               const int32_t* seg_ptr, const uint32_t* pool_bits, const int32_t* pool_slot,
+                               const float* const* parts, const float* x0, int tile_rows, desco_stream_t stream);
+
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);
  * w_planes[num_blocks][3][64 n][64 k] = desco_split_bf16x3_f32 of every 64-row block of the

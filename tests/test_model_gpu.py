@@ -1131,3 +1131,47 @@ def test_canonical_rows_stored_once_changes_no_bit(setup):
         finally:
             GM.CANON_ROWS_ONCE = True
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_pooled_embeddings_never_materialised_changes_no_bit(setup):
+    """gnn_model.POOL_POST_FUSED: post_mp.0 forms its operand -- anchor rows + the fused pooling's partial sums, block 0 =
+    rows(b) * x0 -- in its load phase (desco_pool_post_bf16x6_f32) instead of reading a pooled tensor that
+    desco_pool_reduce_f32 wrote.  Same values in the same summation order into the same product: identical logits.
+    Neighborhoods of 1..33 count rows (one to three 16-row tiles per segment, every alignment); above that the unfused
+    path runs."""
+    import desco_amd.gnn_model as GM
+    nm, *_ = setup
+    stars = [(k + 1, [(0, v) for v in range(1, k + 1)]) for k in (1, 2, 15, 16, 17, 31, 32, 33)]     # count rows up to 33
+    graphs = golden_graphs(max_n=60) + random_family_graphs(11, 30) + stars
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    keep = np.flatnonzero(np.diff(part.count_ptr) <= 33)
+    assert len(keep) > 100 and int(np.diff(part.count_ptr)[keep].max()) >= 30
+    # a batch of the eligible neighborhoods only (contiguous runs of them)
+    runs, a = [], None
+    for i in range(part.num_neigh + 1):
+        ok = i < part.num_neigh and np.diff(part.count_ptr)[i] <= 33
+        if ok and a is None:
+            a = i
+        if not ok and a is not None:
+            runs.append((a, i))
+            a = None
+    a, b = max(runs, key=lambda r: r[1] - r[0])
+    batch = NeighborhoodBatch(part.slice(a, b), DEV)
+    assert batch.max_count_rows() <= 33
+    outs = []
+    for fused in (True, False):
+        GM.POOL_POST_FUSED = fused
+        try:
+            with torch.no_grad():
+                outs.append(nm._logits(batch, exp2=False).clone())
+        finally:
+            GM.POOL_POST_FUSED = True
+    assert torch.isfinite(outs[0]).all()
+    print(f"[fused post_mp.0] {batch.num_graphs} neighborhoods, max |d| = {float((outs[0] - outs[1]).abs().max()):.3e}")
+    assert torch.equal(outs[0], outs[1])
+    # a batch with a larger neighborhood takes the unfused path (and still agrees with itself)
+    big = NeighborhoodBatch(part, DEV)
+    if big.max_count_rows() > 33:
+        with torch.no_grad():
+            x = nm._logits(big, exp2=False)
+        assert torch.isfinite(x).all()
