@@ -1,0 +1,314 @@
+// post_mp.3 -> .5 -> .7 of BaseGNN (reference gnn_model.py:44-53: Linear(64, 64), ReLU, Linear(64, 256), ReLU,
+// Linear(256, 64)) in ONE launch: a row of the [m, 64] input is read once and a row of the [m, 64] result written once;
+// the [m, 64] and [m, 256] intermediates of the three separate launches (3.1 GB of HBM traffic per 1.2 M rows) stay in
+// registers.
+//
+// Arithmetic: the f16x3 form of gemm_f16x3.hip (fp32 operands scaled by a power of two and split into two fp16 terms,
+// hi*hi + lo*hi + hi*lo accumulated in fp32 on v_mfma_f32_32x32x16_f16).
+//
+// The products are formed TRANSPOSED, D^T = W X^T: the weight fragment is the MFMA's A operand (row = output feature),
+// the activations its B operand (column = data row).  In the C/D layout a lane then holds, for ITS data row (column
+// lane & 31), features (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of a 32-feature block -- and registers 8t .. 8t+7 are
+// exactly the eight k values a lane supplies to K step t of the next product's B operand, in the order
+//     k = 16 t + 4 (lane >> 5) + (j & 3) + 8 (j >> 2),   j = 0..7,
+// a permutation of the MFMA's own k order (8 (lane >> 5) + j) that the next layer's weight image in LDS carries (bits 2
+// and 3 of k swapped when the image is filled).  So a layer's output becomes the next layer's operand by converting
+// registers in place: no LDS round trip, no shuffles.  The per-row power-of-two scale of an activation row is a per-LANE
+// constant in this form.
+//
+// The 256 hidden features never exist at once: each block of 32 is produced (12 MFMAs), scaled / split, and consumed
+// by the last layer's 12 MFMAs straight away.  Its row scale is a RUNNING one: when a block raises the row's maximum,
+// the last layer's accumulators are multiplied by the (exact, power-of-two) ratio of the scales, so every block is split
+// against a bound between its own and the row's final maximum -- the guarantee of a whole-row scale.
+//
+// One workgroup per CU (the three weight images fill the LDS: 156 KB), 8 waves of 32 rows, the next tile's rows in
+// flight under the current tile's 216 MFMAs.
+#include "common_device.hpp"
+
+namespace desco {
+namespace tail {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int D1 = 64, D2 = 256, D3 = 64;     // output widths of the three layers (input 64)
+constexpr int ST64 = 72, ST256 = 264;         // LDS row strides in halves: 16-byte reads of 32 rows conflict-free
+constexpr int W1_H = 2 * D1 * ST64, W2_H = 2 * D2 * ST64, W3_H = 2 * D3 * ST256;
+constexpr int NWT = 8;
+constexpr size_t TAIL_LDS = (size_t)(W1_H + W2_H + W3_H) * 2 + (size_t)(D1 + D2 + D3) * 4;
+static_assert(TAIL_LDS <= 160 * 1024, "post_mp tail: LDS budget exceeded");
+
+struct TailArgs {
+  const float* x;
+  int64_t ldx, m;
+  const short *w1, *w2, *w3;        // planes [2][64][64], [2][256][64], [2][64][256] (hi, lo) of scale * W
+  const float *s1, *s2, *s3;        // device {scale, 1 / scale} of each matrix
+  const float *b1, *b2, *b3;        // biases or null
+  float* out;
+  int64_t ldo;
+};
+
+// row maximum over both lane halves (lanes n and n + 32 hold the two halves of data row n's features)
+__device__ __forceinline__ float both_halves_max(const float v) {
+  const u32x2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
+__device__ __forceinline__ f16x8 frag_of(const uint32_t a, const uint32_t b, const uint32_t c, const uint32_t d) {
+  const u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// fill one weight image: [2 planes][rows][K] halves -> LDS rows of `stride` halves; `swap` = the 4-half chunks of each
+// 16-k group stored in the order 0, 2, 1, 3 (bits 2 and 3 of k exchanged)
+template <int K, bool SWAP>
+__device__ __forceinline__ void fill_image(short* dst, const short* __restrict__ src, const int rows2, const int stride,
+                                           const int tid) {
+  constexpr int CH = K / 4;
+  for (int i = tid; i < rows2 * CH; i += NWT * 64) {
+    const int row = i / CH, c = i % CH;
+    const int cd = SWAP ? ((c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1)) : c;
+    *reinterpret_cast<uint2*>(dst + row * stride + 4 * cd) = *reinterpret_cast<const uint2*>(src + (int64_t)row * K + 4 * c);
+  }
+}
+
+#define DESCO_MFMA3(acc_, wh_, wl_, bh_, bl_)                                       \
+  acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_, bh_, acc_, 0, 0, 0);          \
+  acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_, bl_, acc_, 0, 0, 0);          \
+  acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_, bh_, acc_, 0, 0, 0);
+
+__global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
+  extern __shared__ __attribute__((aligned(16))) short lds_h[];
+  short* W1 = lds_h;
+  short* W2 = W1 + W1_H;
+  short* W3 = W2 + W2_H;
+  float* B1 = reinterpret_cast<float*>(W3 + W3_H);
+  float* B2 = B1 + D1;
+  float* B3 = B2 + D2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  fill_image<64, false>(W1, g.w1, 2 * D1, ST64, tid);
+  fill_image<64, true>(W2, g.w2, 2 * D2, ST64, tid);
+  fill_image<256, true>(W3, g.w3, 2 * D3, ST256, tid);
+  for (int i = tid; i < D1 + D2 + D3; i += NWT * 64) {
+    const float* b = i < D1 ? g.b1 : (i < D1 + D2 ? g.b2 : g.b3);
+    const int j = i < D1 ? i : (i < D1 + D2 ? i - D1 : i - D1 - D2);
+    B1[i] = b ? b[j] : 0.f;
+  }
+  const float iw1 = g.s1[1], iw2 = g.s2[1], iw3 = g.s3[1];
+  __syncthreads();
+  const int n = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (g.m + 31) / 32;
+  int64_t tile = (int64_t)blockIdx.x * NWT + wave;
+  if (tile >= ntiles) return;
+  const int64_t tstep = (int64_t)gridDim.x * NWT;
+  // K step s of the first product: the lane supplies k = 16 s + 8 h + 0..7 of its row (the MFMA's own order)
+  float4 xv[8];
+#define DESCO_TAIL_LOAD(t_)                                                     \
+  {                                                                             \
+    const int64_t r_ = (t_) * 32 + n;                                           \
+    const float* p_ = g.x + (r_ < g.m ? r_ : g.m - 1) * g.ldx + 8 * h;          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                          \
+      xv[2 * s_] = *reinterpret_cast<const float4*>(p_ + 16 * s_);              \
+      xv[2 * s_ + 1] = *reinterpret_cast<const float4*>(p_ + 16 * s_ + 4);      \
+    }                                                                           \
+  }
+  DESCO_TAIL_LOAD(tile)
+  // fragment addresses of this lane (in halves): row (lane & 31) of a 32-row block, 8 halves at 8 h of a 16-k group
+  const short* w1p = W1 + n * ST64 + 8 * h;
+  const short* w2p = W2 + n * ST64 + 8 * h;
+  const short* w3p = W3 + n * ST256 + 8 * h;
+  for (;;) {
+    const int64_t row = tile * 32 + n;
+    // ---- input rows -> scaled fp16 (hi, lo) B fragments ----
+    uint32_t xh[16], xl[16];
+    float inv_sx;
+    {
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xv[q].x), fabsf(xv[q].y))), fmaxf(fabsf(xv[q].z), fabsf(xv[q].w)));
+      mx = both_halves_max(mx);
+      const float sx = f16_scale_for(mx);
+      inv_sx = pow2_inverse(sx);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        split2_f16x2(xv[q].x * sx, xv[q].y * sx, xh[2 * q], xl[2 * q]);
+        split2_f16x2(xv[q].z * sx, xv[q].w * sx, xh[2 * q + 1], xl[2 * q + 1]);
+      }
+    }
+    const int64_t tn = tile + tstep;
+    const bool has_next = tn < ntiles;
+    if (has_next) DESCO_TAIL_LOAD(tn)
+    // ---- layer 1: 64 -> 64, relu ----
+    uint32_t h1h[16], h1l[16];
+    float inv_s1;
+    {
+      f32x16 a0, a1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        a0[i] = 0.f;
+        a1[i] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16x8 bh = frag_of(xh[4 * s], xh[4 * s + 1], xh[4 * s + 2], xh[4 * s + 3]);
+        const f16x8 bl = frag_of(xl[4 * s], xl[4 * s + 1], xl[4 * s + 2], xl[4 * s + 3]);
+        const f16x8 wh0 = *reinterpret_cast<const f16x8*>(w1p + 16 * s);
+        const f16x8 wl0 = *reinterpret_cast<const f16x8*>(w1p + D1 * ST64 + 16 * s);
+        const f16x8 wh1 = *reinterpret_cast<const f16x8*>(w1p + 32 * ST64 + 16 * s);
+        const f16x8 wl1 = *reinterpret_cast<const f16x8*>(w1p + (D1 + 32) * ST64 + 16 * s);
+        DESCO_MFMA3(a0, wh0, wl0, bh, bl)
+        DESCO_MFMA3(a1, wh1, wl1, bh, bl)
+      }
+      const float u = iw1 * inv_sx;
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 c0 = *reinterpret_cast<const float4*>(B1 + 8 * q + 4 * h);
+        const float4 c1 = *reinterpret_cast<const float4*>(B1 + 32 + 8 * q + 4 * h);
+        a0[4 * q] = fmaxf(fmaf(a0[4 * q], u, c0.x), 0.f);
+        a0[4 * q + 1] = fmaxf(fmaf(a0[4 * q + 1], u, c0.y), 0.f);
+        a0[4 * q + 2] = fmaxf(fmaf(a0[4 * q + 2], u, c0.z), 0.f);
+        a0[4 * q + 3] = fmaxf(fmaf(a0[4 * q + 3], u, c0.w), 0.f);
+        a1[4 * q] = fmaxf(fmaf(a1[4 * q], u, c1.x), 0.f);
+        a1[4 * q + 1] = fmaxf(fmaf(a1[4 * q + 1], u, c1.y), 0.f);
+        a1[4 * q + 2] = fmaxf(fmaf(a1[4 * q + 2], u, c1.z), 0.f);
+        a1[4 * q + 3] = fmaxf(fmaf(a1[4 * q + 3], u, c1.w), 0.f);
+        mx = fmaxf(fmaxf(mx, fmaxf(a0[4 * q], a0[4 * q + 1])), fmaxf(a0[4 * q + 2], a0[4 * q + 3]));
+        mx = fmaxf(fmaxf(mx, fmaxf(a1[4 * q], a1[4 * q + 1])), fmaxf(a1[4 * q + 2], a1[4 * q + 3]));
+      }
+      mx = both_halves_max(mx);
+      const float s1 = f16_scale_for(mx);
+      inv_s1 = pow2_inverse(s1);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {          // pair p = registers 2p, 2p+1: K step p >> 2 of the block
+        split2_f16x2(a0[2 * p] * s1, a0[2 * p + 1] * s1, h1h[p], h1l[p]);
+        split2_f16x2(a1[2 * p] * s1, a1[2 * p + 1] * s1, h1h[8 + p], h1l[8 + p]);
+      }
+    }
+    // ---- layers 2 (64 -> 256, relu) and 3 (256 -> 64), one 32-feature hidden block at a time ----
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o0[i] = 0.f;
+      o1[i] = 0.f;
+    }
+    float M = 0.f, S = 1.f;
+    const float u2 = iw2 * inv_s1;
+#pragma unroll 2
+    for (int c = 0; c < D2 / 32; ++c) {
+      f32x16 a;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = 0.f;
+      const short* wr = w2p + c * 32 * ST64;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16x8 bh = frag_of(h1h[4 * s], h1h[4 * s + 1], h1h[4 * s + 2], h1h[4 * s + 3]);
+        const f16x8 bl = frag_of(h1l[4 * s], h1l[4 * s + 1], h1l[4 * s + 2], h1l[4 * s + 3]);
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(wr + 16 * s);
+        const f16x8 wl = *reinterpret_cast<const f16x8*>(wr + D2 * ST64 + 16 * s);
+        DESCO_MFMA3(a, wh, wl, bh, bl)
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 cb = *reinterpret_cast<const float4*>(B2 + 32 * c + 8 * q + 4 * h);
+        a[4 * q] = fmaxf(fmaf(a[4 * q], u2, cb.x), 0.f);
+        a[4 * q + 1] = fmaxf(fmaf(a[4 * q + 1], u2, cb.y), 0.f);
+        a[4 * q + 2] = fmaxf(fmaf(a[4 * q + 2], u2, cb.z), 0.f);
+        a[4 * q + 3] = fmaxf(fmaf(a[4 * q + 3], u2, cb.w), 0.f);
+        mx = fmaxf(fmaxf(mx, fmaxf(a[4 * q], a[4 * q + 1])), fmaxf(a[4 * q + 2], a[4 * q + 3]));
+      }
+      mx = fmaxf(both_halves_max(mx), M);
+      const float Sn = f16_scale_for(mx);
+      M = mx;
+      if (__builtin_amdgcn_ballot_w64(Sn != S) != 0) {        // a row's scale fell: rescale its accumulators (exact)
+        const float ratio = Sn * pow2_inverse(S);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          o0[i] *= ratio;
+          o1[i] *= ratio;
+        }
+      }
+      S = Sn;
+      uint32_t ph[8], pl[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) split2_f16x2(a[2 * p] * S, a[2 * p + 1] * S, ph[p], pl[p]);
+      const short* w3r = w3p + 32 * c;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f16x8 bh = frag_of(ph[4 * t], ph[4 * t + 1], ph[4 * t + 2], ph[4 * t + 3]);
+        const f16x8 bl = frag_of(pl[4 * t], pl[4 * t + 1], pl[4 * t + 2], pl[4 * t + 3]);
+        const f16x8 wh0 = *reinterpret_cast<const f16x8*>(w3r + 16 * t);
+        const f16x8 wl0 = *reinterpret_cast<const f16x8*>(w3r + D3 * ST256 + 16 * t);
+        const f16x8 wh1 = *reinterpret_cast<const f16x8*>(w3r + 32 * ST256 + 16 * t);
+        const f16x8 wl1 = *reinterpret_cast<const f16x8*>(w3r + (D3 + 32) * ST256 + 16 * t);
+        DESCO_MFMA3(o0, wh0, wl0, bh, bl)
+        DESCO_MFMA3(o1, wh1, wl1, bh, bl)
+      }
+    }
+    // ---- output: row `row`, features 32 ob + 8 q + 4 h + 0..3 ----
+    if (row < g.m) {
+      const float u3 = iw3 * pow2_inverse(S);
+      float* o = g.out + row * g.ldo + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 c0 = *reinterpret_cast<const float4*>(B3 + 8 * q + 4 * h);
+        const float4 c1 = *reinterpret_cast<const float4*>(B3 + 32 + 8 * q + 4 * h);
+        float4 v0, v1;
+        v0.x = fmaf(o0[4 * q], u3, c0.x);
+        v0.y = fmaf(o0[4 * q + 1], u3, c0.y);
+        v0.z = fmaf(o0[4 * q + 2], u3, c0.z);
+        v0.w = fmaf(o0[4 * q + 3], u3, c0.w);
+        v1.x = fmaf(o1[4 * q], u3, c1.x);
+        v1.y = fmaf(o1[4 * q + 1], u3, c1.y);
+        v1.z = fmaf(o1[4 * q + 2], u3, c1.z);
+        v1.w = fmaf(o1[4 * q + 3], u3, c1.w);
+        *reinterpret_cast<float4*>(o + 8 * q) = v0;
+        *reinterpret_cast<float4*>(o + 32 + 8 * q) = v1;
+      }
+    }
+    if (!has_next) break;
+    tile = tn;
+  }
+#undef DESCO_TAIL_LOAD
+}
+
+#undef DESCO_MFMA3
+
+}  // namespace tail
+}  // namespace desco
+
+using namespace desco;
+
+extern "C" int desco_post_mp_tail_f16x3_f32(const float* x, int64_t ldx, int64_t m, const int16_t* w1_planes,
+                                            const float* w1_scale, const float* b1, const int16_t* w2_planes,
+                                            const float* w2_scale, const float* b2, const int16_t* w3_planes,
+                                            const float* w3_scale, const float* b3, float* out, int64_t ldo,
+                                            desco_stream_t stream) {
+  if (m < 0 || !x || !w1_planes || !w1_scale || !w2_planes || !w2_scale || !w3_planes || !w3_scale || !out ||
+      ldx < 64 || ldx % 4 || ldo < 64 || ldo % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)w1_planes & 7) || ((uintptr_t)w2_planes & 7) || ((uintptr_t)w3_planes & 7))
+    return fail(DESCO_EINVAL, "desco_post_mp_tail_f16x3_f32: bad argument");
+  if (m == 0) return 0;
+  tail::TailArgs g{x, ldx, m, reinterpret_cast<const short*>(w1_planes), reinterpret_cast<const short*>(w2_planes),
+                   reinterpret_cast<const short*>(w3_planes), w1_scale, w2_scale, w3_scale, b1, b2, b3, out, ldo};
+  static DeviceOnce attr_once;
+  if (!attr_once.done()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail::post_tail_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_once.mark();
+  }
+  const int64_t tiles = (m + 31) / 32;
+  const int64_t want = (tiles + tail::NWT - 1) / tail::NWT;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const unsigned grid = (unsigned)(want < cus ? want : cus);
+  hipLaunchKernelGGL(tail::post_tail_kernel, dim3(grid), dim3(tail::NWT * 64), tail::TAIL_LDS, (hipStream_t)stream, g);
+  return launch_status("desco_post_mp_tail_f16x3_f32");
+}

@@ -455,7 +455,16 @@ def pack_shmp(gnn: BaseGNN, bf16_planes: bool = True) -> dict:
     pk["post_nk"] = [((ops.linear64_planes(gnn.post_mp[i].weight) if gnn.post_mp[i].in_features == 64
                        else ops.split_bf16_planes(gnn.post_mp[i].weight)),
                       gnn.post_mp[i].bias.contiguous()) for i in (0, 3, 5, 7)]
+    # post_mp.3 -> .5 -> .7 in one launch (ops.post_mp_tail): the three matrices as fp16 (hi, lo) planes
+    dims = [tuple(gnn.post_mp[i].weight.shape) for i in (3, 5, 7)]
+    if POST_TAIL_FUSED and GEMM_F16X3 and dims == [(64, 64), (256, 64), (64, 256)]:
+        pk["post_tail"] = [v for i in (3, 5, 7)
+                           for v in (ops.split_f16_planes(gnn.post_mp[i].weight), gnn.post_mp[i].bias.contiguous())]
     return pk
+
+
+# post_mp.3 -> .5 -> .7 in one launch (desco_post_mp_tail_f16x3_f32): the [B, 64] and [B, 256] intermediates never reach HBM
+POST_TAIL_FUSED = os.environ.get("DESCO_POST_TAIL_FUSED", "1") != "0"
 
 
 class _PostMp0(object):
@@ -473,6 +482,8 @@ def _post_mp(pk, pooled):
             return f(a, w, b, act=act, slope=slope)
         (w0, b0), (w3, b3), (w5, b5), (w7, b7) = pk["post_nk"]
         h = pooled.h0 if isinstance(pooled, _PostMp0) else lin(pooled, w0, b0, ops.ACT_LEAKY, 0.1)
+        if POST_TAIL_FUSED and "post_tail" in pk:
+            return ops.post_mp_tail(h, *pk["post_tail"])
         h = lin(h, w3, b3, ops.ACT_RELU)
         h = lin(h, w5, b5, ops.ACT_RELU)
         return lin(h, w7, b7)

@@ -458,6 +458,27 @@ def pool_post(anch: torch.Tensor, parts, bits: torch.Tensor, slot: torch.Tensor,
     return out
 
 
+def post_mp_tail(x: torch.Tensor, w1, b1, w2, b2, w3, b3, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W3 relu(W2 relu(W1 x + b1) + b2) + b3 for the [64 -> 64 -> 256 -> 64] tail of post_mp in one launch
+    (desco_post_mp_tail_f16x3_f32); the weights as ``split_f16_planes`` of the [out, in] matrices."""
+    m = x.shape[0]
+    assert x.shape[1] == 64 and all(isinstance(w, F16Planes) for w in (w1, w2, w3))
+    assert tuple(w1.shape) == (2, 64, 64) and tuple(w2.shape) == (2, 256, 64) and tuple(w3.shape) == (2, 64, 256)
+    if out is None:
+        out = torch.empty((m, 64), device=x.device, dtype=torch.float32)
+    if m == 0:
+        return out
+    xp, ldx = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    bp = [None if b is None else _dev(b.contiguous(), "bias") for b in (b1, b2, b3)]
+    with _Timed("post_tail_kernel", 2.0 * m * (64 * 64 + 64 * 256 + 256 * 64), 4.0 * m * 128):
+        _lib.check(_lib.lib().desco_post_mp_tail_f16x3_f32(
+            xp, ldx, m, _dev(w1.planes, "w1", torch.int16), _dev(w1.scale, "w1_scale"), bp[0],
+            _dev(w2.planes, "w2", torch.int16), _dev(w2.scale, "w2_scale"), bp[1],
+            _dev(w3.planes, "w3", torch.int16), _dev(w3.scale, "w3_scale"), bp[2], op, ldo, _stream()), "post_mp_tail")
+    return out
+
+
 def shmp_kernel_name(kb: int, st: int, x6: bool, f16: bool = False) -> str:
     """Profiler key of a fused-layer launch: the kernel family that runs it (16-row wave tiles for
     the bf16x6 form unless DESCO_SHMP_ROWS=32; always for the fp16 three-product form) and its

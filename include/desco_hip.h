@@ -350,6 +350,18 @@ int desco_pool_post_bf16x6_f32(const float* anch, int64_t lda, int num_layers, c
                                const int32_t* seg_ptr, const uint32_t* pool_bits, const int32_t* pool_slot,
                                const float* const* parts, const float* x0, int tile_rows, desco_stream_t stream);
 
+/* post_mp.3 -> ReLU -> post_mp.5 -> ReLU -> post_mp.7 (gnn_model.py:44-53: Linear(64, 64), Linear(64, 256), Linear(256, 64))
+ * in one launch:  out[i, 0:64] = W3 relu(W2 relu(W1 x[i, 0:64] + b1) + b2) + b3.  A row is read once and written once;
+ * the [m, 64] and [m, 256] intermediates stay in registers (f16x3 arithmetic, fp32-accurate: the products are formed
+ * transposed so that a layer's accumulators ARE the next layer's operand registers; per-row power-of-two scales).
+ * wK_planes / wK_scale = desco_split_f16x2_f32 of the [out, in] weights ([2][64][64], [2][256][64], [2][64][256]);
+ * biases [64], [256], [64] or NULL.  x == out is allowed (a wave reads its 32 rows before it writes them). */
+int desco_post_mp_tail_f16x3_f32(const float* x, int64_t ldx, int64_t m, const int16_t* w1_planes,
+                                 const float* w1_scale, const float* b1, const int16_t* w2_planes,
+                                 const float* w2_scale, const float* b2, const int16_t* w3_planes,
+                                 const float* w3_scale, const float* b3, float* out, int64_t ldo,
+                                 desco_stream_t stream);
+
 /* Row-wise Linear with 64 inputs on the fused layer's streaming machinery (bf16x6 arithmetic,
  * fp32-accurate): out[i, 0:64*num_blocks] = act(x[i, 0:64] * W^T + bias[0:64*num_blocks]);
  * w_planes[num_blocks][3][64 n][64 k] = desco_split_bf16x3_f32 of every 64-row block of the

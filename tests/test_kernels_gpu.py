@@ -601,6 +601,106 @@ def test_fused_shmp_layer_f16x3_is_fp32_accurate_over_the_fp32_range(kind):
 
 
 # ---- the optimizer launch (csrc/adam.hip, desco_amd/optim.py) -----------------------------------------------------------
+def _tail_case(m, seed, row_mag=None, w_gain=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, 64, generator=g)
+    if row_mag is not None:
+        x = x * row_mag(m, g)
+    ws = [torch.randn(o, i, generator=g) * (w_gain / i ** 0.5) for o, i in ((64, 64), (256, 64), (64, 256))]
+    bs = [torch.randn(o, generator=g) * 0.1 for o in (64, 256, 64)]
+    return x, ws, bs
+
+
+def _tail_fp64(x, ws, bs):
+    """(result, per-output error scale): the chain in fp64, and the magnitude sum an fp32 chain's rounding errors live
+    on (|W3| (|W2| (|W1||x| + |b1|) + |b2|) + |b3|)"""
+    h = torch.relu(x.double() @ ws[0].double().t() + bs[0].double())
+    h = torch.relu(h @ ws[1].double().t() + bs[1].double())
+    ref = h @ ws[2].double().t() + bs[2].double()
+    mag = x.double().abs() @ ws[0].double().abs().t() + bs[0].double().abs()
+    mag = mag @ ws[1].double().abs().t() + bs[1].double().abs()
+    mag = mag @ ws[2].double().abs().t() + bs[2].double().abs()
+    return ref, mag
+
+
+def _tail_both(x, ws, bs):
+    """the one-launch tail and the three launches it replaces (linear64, linear64, gemm_split: bf16x6 arithmetic)"""
+    xd = x.to(DEV)
+    planes = [ops.split_f16_planes(w.to(DEV)) for w in ws]
+    bd = [b.to(DEV) for b in bs]
+    fused = ops.post_mp_tail(xd, planes[0], bd[0], planes[1], bd[1], planes[2], bd[2])
+    h = ops.linear64(xd, ops.linear64_planes(ws[0].to(DEV)), bd[0], act=ops.ACT_RELU)
+    h = ops.linear64(h, ops.linear64_planes(ws[1].to(DEV)), bd[1], act=ops.ACT_RELU)
+    chain = ops.gemm_split(h, ops.split_bf16_planes(ws[2].to(DEV)), bd[2])
+    torch.cuda.synchronize()
+    return fused.cpu().double(), chain.cpu().double()
+
+
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 257, 5000, 70001])
+def test_post_mp_tail_in_one_launch_is_fp32_accurate(m):
+    """post_mp.3 -> .5 -> .7 in one launch (reference gnn_model.py:44-53) against fp64, next to the three launches it
+    replaces: the f16x3 chain must be as accurate as the bf16x6 one (error relative to the magnitude sum of the chain),
+    for every ragged tail of the 32-row wave tiles and rows whose magnitudes span 30x."""
+    x, ws, bs = _tail_case(m, 100 + m, lambda m_, g: torch.rand(m_, 1, generator=g) * 30 + 0.01)
+    ref, mag = _tail_fp64(x, ws, bs)
+    fused, chain = _tail_both(x, ws, bs)
+    ef = ((fused - ref).abs() / mag).max().item()
+    ec = ((chain - ref).abs() / mag).max().item()
+    print(f"[tail] m={m}: one launch {ef:.2e}  three launches {ec:.2e} (max err / magnitude sum)")
+    assert ef <= max(2.0 * ec, 2e-7)
+    assert (fused - chain).abs().max().item() <= 5e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["1e5", "1e-5", "rows_2^+-20", "zero_rows", "late_block_dominates", "big_weights"])
+def test_post_mp_tail_range(kind):
+    """The activations' per-row power-of-two scales (a running one over the 256 hidden features) must carry any
+    magnitude: huge and tiny rows, all-zero rows, a hidden row whose largest feature sits in the LAST 32-feature block
+    (every earlier block's accumulators are rescaled), weights far from O(1)."""
+    m = 1000
+    mags = {
+        "1e5": lambda m_, g_: torch.full((m_, 1), 1e5),
+        "1e-5": lambda m_, g_: torch.full((m_, 1), 1e-5),
+        "rows_2^+-20": lambda m_, g_: 2.0 ** torch.randint(-20, 21, (m_, 1), generator=g_).float(),
+        "zero_rows": lambda m_, g_: (torch.rand(m_, 1, generator=g_) > 0.5).float(),
+    }
+    x, ws, bs = _tail_case(m, 7 + len(kind), mags.get(kind), w_gain=300.0 if kind == "big_weights" else 1.0)
+    if kind == "late_block_dominates":
+        ws[1][:224] *= 2.0 ** -12          # hidden features 224..255 are 4096x the others
+        bs[1][:224] *= 2.0 ** -12
+    if kind in ("1e5", "1e-5", "rows_2^+-20", "zero_rows"):
+        bs = [b * 0 for b in bs]           # (a bias would swamp the tiny rows and hide their error)
+    ref, mag = _tail_fp64(x, ws, bs)
+    fused, chain = _tail_both(x, ws, bs)
+    live = mag > 0
+    ef = ((fused - ref).abs()[live] / mag[live]).max().item()
+    ec = ((chain - ref).abs()[live] / mag[live]).max().item()
+    print(f"[tail range] {kind}: one launch {ef:.2e}  three launches {ec:.2e}")
+    assert ef <= max(2.0 * ec, 2e-7)
+    if kind == "zero_rows":
+        zero = x.abs().sum(1) == 0
+        assert zero.any() and torch.all(fused[zero] == 0)
+
+
+def test_post_mp_tail_strided_in_place_and_bad_arguments():
+    x, ws, bs = _tail_case(300, 5)
+    planes = [ops.split_f16_planes(w.to(DEV)) for w in ws]
+    bd = [b.to(DEV) for b in bs]
+    want = ops.post_mp_tail(x.to(DEV), planes[0], bd[0], planes[1], bd[1], planes[2], bd[2])
+    wide = torch.zeros(300, 192, device=DEV)
+    wide[:, 64:128] = x.to(DEV)
+    got = ops.post_mp_tail(wide[:, 64:128], planes[0], bd[0], planes[1], bd[1], planes[2], bd[2], out=wide[:, 128:192])
+    assert torch.equal(got, want) and torch.all(wide[:, :64] == 0)
+    inpl = x.to(DEV).clone()
+    ops.post_mp_tail(inpl, planes[0], bd[0], planes[1], bd[1], planes[2], bd[2], out=inpl)
+    assert torch.equal(inpl, want)
+    nob = ops.post_mp_tail(x.to(DEV), planes[0], None, planes[1], None, planes[2], None)
+    ref = torch.relu(torch.relu(x.double() @ ws[0].double().t()) @ ws[1].double().t()) @ ws[2].double().t()
+    assert (nob.cpu().double() - ref).abs().max().item() < 1e-5
+    assert ops.post_mp_tail(x[:0].to(DEV), planes[0], bd[0], planes[1], bd[1], planes[2], bd[2]).shape == (0, 64)
+    with pytest.raises(Exception):
+        ops.post_mp_tail(wide[:, 1:65], planes[0], bd[0], planes[1], bd[1], planes[2], bd[2])     # misaligned rows
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-2])
 def test_adam_matches_torch_adam(wd):
     """desco_amd.optim.Adam against torch.optim.Adam (the reference's optimizer, lightning_model.py:160-173) on a

@@ -1175,3 +1175,47 @@ def test_pooled_embeddings_never_materialised_changes_no_bit(setup):
         with torch.no_grad():
             x = nm._logits(big, exp2=False)
         assert torch.isfinite(x).all()
+
+
+def test_post_mp_tail_in_one_launch_keeps_the_logits(setup):
+    """gnn_model.POST_TAIL_FUSED: post_mp.3 -> .5 -> .7 in one launch (desco_post_mp_tail_f16x3_f32, f16x3 arithmetic)
+    against the three launches it replaces (bf16x6), both against the oracle on the same batch: the one-launch form is
+    held to the suite's gate and is no further from the oracle than the three launches were (2x margin for noise); the
+    two forms differ from each other by rounding only (the count head amplifies it: printed)."""
+    import desco_amd.gnn_model as GM
+    nm, _, qids, queries = setup
+    graphs = golden_graphs(max_n=41)[:16]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    batch = NeighborhoodBatch(part.slice(0, min(512, part.num_neigh)), DEV)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs[:batch.num_graphs]), OP.query_batch(queries),
+                                    emulate_quirk=False)
+    assert "post_tail" in nm.emb_model.packed()
+    outs = {}
+    for fused in (True, False):
+        GM.POST_TAIL_FUSED = fused
+        try:
+            with torch.no_grad():
+                outs[fused] = nm._logits(batch, exp2=False).cpu().double()
+        finally:
+            GM.POST_TAIL_FUSED = True
+    r = ref.double()
+    err = lambda a, b: float(((a - b).abs() / (1.0 + b.abs())).max())      # noqa: E731   (the suite's metric, helpers.py)
+    e1, e3, d = err(outs[True], r), err(outs[False], r), err(outs[True], outs[False])
+    print(f"[fused post_mp tail] {batch.num_graphs} neighborhoods: one launch vs oracle {e1:.2e}, three launches {e3:.2e}, "
+          f"one vs three {d:.2e}")
+    assert e1 <= LOGIT_TOL and e3 <= LOGIT_TOL
+    assert e1 <= 2.0 * max(e3, 1e-6)
+    # a larger mixed batch (hub neighborhoods, logits up to 1e3): the two forms stay within a fraction of the gate
+    big = NeighborhoodBatch(build_partition(GraphSet.from_edge_lists(golden_graphs(max_n=60) + random_family_graphs(11, 30)),
+                                            4), DEV)
+    for fused in (True, False):
+        GM.POST_TAIL_FUSED = fused
+        try:
+            with torch.no_grad():
+                outs[fused] = nm._logits(big, exp2=False).cpu().double()
+        finally:
+            GM.POST_TAIL_FUSED = True
+    d = err(outs[True], outs[False])
+    print(f"[fused post_mp tail] {big.num_graphs} neighborhoods, one vs three launches {d:.2e}")
+    assert torch.isfinite(outs[True]).all() and d <= 0.5 * LOGIT_TOL
