@@ -8,6 +8,7 @@ by one batched head kernel / a query axis in the gossip kernels.
 from __future__ import annotations
 
 import argparse
+import os
 import warnings
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -129,6 +130,9 @@ class _LightningLike(nn.Module):
 
 # training: run the query model's trunk on a second HIP stream beside the target batch's (train_forward)
 OVERLAP_QUERY_TRUNK = True
+# the count head formed straight from the target embeddings at inference (desco_count_head_emb_f16x3_f32): the [B, 256]
+# target half of count_model.0 never reaches HBM
+HEAD_FROM_EMB = os.environ.get("DESCO_HEAD_FROM_EMB", "1") != "0"
 
 
 class NeighborhoodCountingModel(_LightningLike):
@@ -223,8 +227,10 @@ class NeighborhoodCountingModel(_LightningLike):
         emb_t = self.emb_model(batch)
         hp = self._head_pack()
         from . import gnn_model as GM
+        fused_head = (HEAD_FROM_EMB and GM.GEMM_BF16X6 and GM.GEMM_F16X3 and not torch.is_grad_enabled()
+                      and emb_q.shape[0] == 29 and hp["w2"].numel() == 256 and emb_t.shape[1] == 64)
         if GM.GEMM_BF16X6:
-            T = ops.linear64(emb_t, hp["w_t_l64"])                         # target half
+            T = None if fused_head else ops.linear64(emb_t, hp["w_t_l64"])  # target half
             # query half + bias: a function of (head weights, query embeddings) only -- cached with them at inference
             # (keyed on the tensor OBJECT, which the cache keeps alive: an address could be handed to the next query
             #  set's embeddings by the caching allocator)
@@ -238,6 +244,12 @@ class NeighborhoodCountingModel(_LightningLike):
             T = ops.gemm(emb_t, hp["wt_t"])
             Qh = ops.gemm(emb_q, hp["wt_q"], hp["b1"])
         slope = self.count_model[1].negative_slope
+        if fused_head:
+            # the [B, 256] target half is never written: formed block by block inside the head's launch
+            if "w_t_f16" not in hp:
+                hp["w_t_f16"] = ops.split_f16_planes(self.count_model[0].weight[:, :emb_t.shape[1]].contiguous())
+            return ops.count_head_emb(emb_t, hp["w_t_f16"], Qh, hp["w2"], hp["b2"], slope, exp2,
+                                      out=getattr(batch, "out_buf", None) if exp2 else None)
         if Qh.shape[0] <= 32:
             # (InferencePipeline hands every block a slice of ONE persistent result tensor: no torch.cat per pass)
             return ops.count_head(T, Qh, hp["w2"], hp["b2"], slope, exp2,

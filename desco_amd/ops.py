@@ -787,6 +787,31 @@ def count_head(t: torch.Tensor, qh: torch.Tensor, w2: torch.Tensor, b2, slope: f
     return out
 
 
+def count_head_emb(emb: torch.Tensor, wt: "F16Planes", qh: torch.Tensor, w2: torch.Tensor, b2, slope: float,
+                   exp2_minus_1: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``count_head(emb @ Wt.T, qh, ...)`` without the [B, 256] tensor in between (desco_count_head_emb_f16x3_f32):
+    ``wt`` = split_f16_planes of count_model.0's target half [256, 64]; 29 queries, 256 hidden features."""
+    B, Q, hid = emb.shape[0], qh.shape[0], qh.shape[1]
+    assert emb.shape[1] == 64 and isinstance(wt, F16Planes) and tuple(wt.shape) == (2, hid, 64)
+    if out is None:
+        out = torch.empty((B, Q), device=emb.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, Q) or not out.is_contiguous():
+        raise ValueError("count_head_emb: `out` must be a contiguous [B, Q] tensor")
+    if B == 0:
+        return out
+    ep, lde = _rows(emb, "emb")
+    qp, ldq = _rows(qh, "qh")
+    with _Timed("count_head_emb_kernel", 2.0 * B * 64 * hid + 4.0 * B * Q * hid, 4.0 * (B * 64 + Q * hid + B * Q)):
+        b2_dev = None
+        if isinstance(b2, torch.Tensor):
+            b2_dev, b2 = _dev(b2.detach().reshape(1).contiguous(), "b2"), 0.0
+        _lib.check(_lib.lib().desco_count_head_emb_f16x3_f32(
+            ep, lde, B, _dev(wt.planes, "wt", torch.int16), _dev(wt.scale, "wt_scale"), qp, ldq, hid,
+            _dev(w2.contiguous(), "w2"), b2, b2_dev, slope, int(exp2_minus_1), _dev(out, "out"), Q, Q, _stream()),
+            "count_head_emb")
+    return out
+
+
 def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """dst[rows[b], :] = src[b, :]  (GossipDataset.apply_neighborhood_count, workload.py:107-112)."""
     sp, lds = _rows(src, "src")

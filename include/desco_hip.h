@@ -650,6 +650,16 @@ int desco_rowdot_bwd_f32(const float* y, int64_t ldy, int n, const float* w, con
 int desco_act_grad_f32(const float* dc, const float* c, int act, float slope, float* dz,
                        int64_t count, desco_stream_t stream);
 
+/* The count head straight from the target embeddings (inference): T[b, :] = Wt emb[b, 0:64] (count_model.0's target half,
+ * lightning_model.py:127-131) is formed 32 features at a time on the matrix pipe (f16x3, wt_planes / wt_scale =
+ * desco_split_f16x2_f32 of the [256, 64] weight) and consumed from registers, so the [m, 256] tensor T that
+ * desco_linear64_bf16x6_f32 would write and desco_count_head_f32 read never exists.  Same result as that pair up to
+ * rounding.  hid must be 256 and num_q 29 (the standard query set, data.py:37); other shapes use the two-launch form. */
+int desco_count_head_emb_f16x3_f32(const float* emb, int64_t lde, int64_t m, const int16_t* wt_planes,
+                                   const float* wt_scale, const float* qh, int64_t ldq, int hid, const float* w2,
+                                   float b2, const float* b2_dev, float slope, int exp2_minus_1, float* out,
+                                   int64_t ldo, int num_q, desco_stream_t stream);
+
 /* backward of desco_count_head_f32 (logit mode): given dl[b,q] = dLoss/dlogit,
  * dt[b,c], dqh[q,c] (contiguous [num_q, hid]), dw2[c];  (db2 = sum dl is left to the caller)
  * workspace: desco_count_head_bwd_workspace(num_b, num_q, hid) bytes (ABI 1 documented a constant of

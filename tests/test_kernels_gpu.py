@@ -128,6 +128,40 @@ def test_count_head(B, Q, hid, slope):
     assert_counts_close("count head, exp2 - 1 form", got2[idx.to(DEV)], 2 ** ref - 1)
 
 
+@pytest.mark.parametrize("B", [1, 31, 33, 1000, 70001])
+@pytest.mark.parametrize("slope", [0.01, 0.2])
+def test_count_head_from_the_embeddings(B, slope):
+    """desco_count_head_emb_f16x3_f32: the count head with count_model.0's target half formed inside the launch
+    (lightning_model.py:127-131, 176-193) against fp64 and against the two launches it replaces (linear64 + count_head);
+    ragged 32-row tiles, rows of very different magnitude, both output forms."""
+    g = torch.Generator().manual_seed(B)
+    emb = torch.randn(B, 64, generator=g) * (torch.rand(B, 1, generator=g) * 30 + 0.01)
+    wt = torch.randn(256, 64, generator=g) / 8
+    qh = torch.randn(29, 256, generator=g)
+    w2, b2 = torch.randn(256, generator=g) / 16, 0.3
+    idx = torch.randperm(B, generator=g)[:300]
+    t64 = emb[idx].double() @ wt.double().t()
+    pre = torch.nn.functional.leaky_relu(t64[:, None, :] + qh.double()[None], slope)
+    ref = pre @ w2.double() + b2
+    mag = (emb[idx].double().abs() @ wt.double().abs().t())[:, None, :] + qh.double().abs()[None]
+    mag = mag @ w2.double().abs() + abs(b2)
+    planes = ops.split_f16_planes(wt.to(DEV))
+    got = ops.count_head_emb(emb.to(DEV), planes, qh.to(DEV), w2.to(DEV), b2, slope, False)
+    two = ops.count_head(ops.linear64(emb.to(DEV), ops.linear64_planes(wt.to(DEV))), qh.to(DEV), w2.to(DEV), b2, slope,
+                         False)
+    assert got.shape == (B, 29)
+    e1 = ((got[idx.to(DEV)].cpu().double() - ref).abs() / mag).max().item()
+    e2 = ((two[idx.to(DEV)].cpu().double() - ref).abs() / mag).max().item()
+    print(f"[head from emb] B={B} slope={slope}: one launch {e1:.2e}  two launches {e2:.2e} (max err / magnitude sum)")
+    assert e1 <= max(2.0 * e2, 1.2e-7)          # (one fp32 rounding unit of the magnitude sum: the max(t, -q) + q form)
+    _close(got[idx.to(DEV)], ref)
+    got2 = ops.count_head_emb(emb.to(DEV), planes, qh.to(DEV), w2.to(DEV), torch.tensor(b2, device=DEV), slope, True)
+    small = ref.abs().max(1).values < 20                  # (2^logit - 1 within fp32 range)
+    assert_counts_close("count head from emb, exp2 - 1 form", got2[idx.to(DEV)][small.to(DEV)], 2 ** ref[small] - 1)
+    with pytest.raises(Exception):
+        ops.count_head_emb(emb.to(DEV), planes, qh[:28].to(DEV), w2.to(DEV), b2, slope, False)      # 29 queries only
+
+
 def test_scatter_rows_and_linear_smallk_and_rowdot():
     g = torch.Generator().manual_seed(8)
     src = torch.randn(50, 29, generator=g)

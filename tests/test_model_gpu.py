@@ -1219,3 +1219,30 @@ def test_post_mp_tail_in_one_launch_keeps_the_logits(setup):
     d = err(outs[True], outs[False])
     print(f"[fused post_mp tail] {big.num_graphs} neighborhoods, one vs three launches {d:.2e}")
     assert torch.isfinite(outs[True]).all() and d <= 0.5 * LOGIT_TOL
+
+
+def test_count_head_from_the_embeddings_keeps_the_logits(setup):
+    """lightning_model.HEAD_FROM_EMB: the head's target half formed inside the head's launch (f16x3) against the
+    linear64 + count_head pair (bf16x6), both against the oracle on the same batch."""
+    import desco_amd.lightning_model as LM
+    nm, _, qids, queries = setup
+    graphs = golden_graphs(max_n=41)[:16]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    batch = NeighborhoodBatch(part.slice(0, min(512, part.num_neigh)), DEV)
+    _, _, neighs = OP.neighborhood_dataset(graphs, 4)
+    ref, _ = OM.neighborhood_logits(cpu_sd(nm), OP.neighborhood_batch(neighs[:batch.num_graphs]), OP.query_batch(queries),
+                                    emulate_quirk=False)
+    outs = {}
+    for fused in (True, False):
+        LM.HEAD_FROM_EMB = fused
+        try:
+            with torch.no_grad():
+                outs[fused] = nm._logits(batch, exp2=False).cpu().double()
+        finally:
+            LM.HEAD_FROM_EMB = True
+    r = ref.double()
+    err = lambda a, b: float(((a - b).abs() / (1.0 + b.abs())).max())      # noqa: E731
+    e1, e2, d = err(outs[True], r), err(outs[False], r), err(outs[True], outs[False])
+    print(f"[head from emb] {batch.num_graphs} neighborhoods: one launch vs oracle {e1:.2e}, two launches {e2:.2e}, "
+          f"one vs two {d:.2e}")
+    assert e1 <= LOGIT_TOL and e2 <= LOGIT_TOL and e1 <= 2.0 * max(e2, 1e-6) and d > 0.0
