@@ -64,7 +64,7 @@ def mfma_peak(kernel: str):
     """(peak TFLOP/s in algorithmic fp32 flops, pipe) for an MFMA-bound kernel, else None."""
     if kernel == "gemm_f32_kernel" or kernel.endswith(",f32>"):
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
-    if kernel in ("gemm_f16x3_kernel", "gossip_fused_f16_kernel") or kernel.endswith(",f16x3>"):
+    if kernel in ("gemm_f16x3_kernel", "gossip_fused_f16_kernel", "post_tail_kernel") or kernel.endswith(",f16x3>"):
         return PEAK_X3_TFLOPS, "fp16 MFMA x 3 products (f16x3, fp32-accurate)"
     if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>") or \
             kernel.startswith("shmp_layer16_kernel<"):
@@ -1025,9 +1025,9 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "arithmetic": "fp32 in/out, fp32 accumulation; matrix products of the SHMP layers, the gossip stage and the anchor "
-                      "GEMM as 3 fp16 MFMA products per multiply-add (hi/lo split with power-of-two scales), of the "
-                      "small streaming GEMMs as 6 bf16 products (3-way truncation split): both fp32-accurate, DESIGN.md "
-                      "section 4",
+                      "GEMM, the post_mp tail and the count head's target half as 3 fp16 MFMA products per multiply-add "
+                      "(hi/lo split with power-of-two scales), of the table products and post_mp.0 as 6 bf16 products "
+                      "(3-way truncation split): both fp32-accurate, DESIGN.md section 4",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}-shaped synthetic ({base.num_graphs} graphs) x{args.replicas} "

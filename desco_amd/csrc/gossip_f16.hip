@@ -35,6 +35,7 @@
 //     MFMA triple.  Packed fp32 selection is back on and the end-of-block accumulator drain is gone: the wrong-result
 //     mode of round 4 was one operand selection of the packed instructions (OP_SEL on src1/src2), which this source
 //     does not produce and tools/check_isa.py refuses in the linked library (profiles/r5_a_gossip_f16_hazard.md).
+#include "tu_no_packed_f32_begin.hpp"
 #include "common_device.hpp"
 
 namespace desco {
@@ -70,6 +71,7 @@ struct Args {
   float* out;               // [N,Q]
   const uint8_t* tperm;     // [tiles*128] phase-1 slot -> row of the tile, or null
   unsigned long long* queue;  // {next ticket, finished blocks}: zero before the first launch that uses it, left zero
+  unsigned grid_blocks;     // gridDim.x (set by the launcher)
 };
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t n
   extern __shared__ __attribute__((aligned(16))) uint4 gf_lds[];
   short* WB = reinterpret_cast<short*>(gf_lds);                       // nine resident weight blocks
   float* cst = reinterpret_cast<float*>(WB + 9 * WBLK);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = (int)__builtin_amdgcn_workitem_id_x(), lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int* ecolw = reinterpret_cast<int*>(cst + WCST) + wave * (WCOLS * 16 + 64);   // this wave's staged column ids ...
   float* zpw = reinterpret_cast<float*>(ecolw + WCOLS * 16);                     // ... and zp_q
@@ -228,8 +230,8 @@ __global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t n
 
   const int QC = (Q + WQ - 1) / WQ;
   const int64_t nunits = num_groups * QC;
-  const unsigned long long nwaves = (unsigned long long)gridDim.x * 8;
-  int64_t unit = (int64_t)blockIdx.x * 8 + wave;
+  const unsigned long long nwaves = (unsigned long long)g.grid_blocks * 8;      // (= gridDim.x; passed, not queried)
+  int64_t unit = (int64_t)__builtin_amdgcn_workgroup_id_x() * 8 + wave;
   const int fq = 4 * q4;
   // this lane's 16 features of the standard-order operands (hh, h1): 8 q4 .. +7 and 32 + 8 q4 .. +7
   const int fa = 8 * q4, fb = 32 + 8 * q4;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(GNT) void gossip_fused_f16_kernel(Args g, int64_t n
 __global__ __launch_bounds__(256) void gossip_f16_stream_kernel(const short* __restrict__ w1, const short* __restrict__ wp,
                                                                 const short* __restrict__ w3, const short* __restrict__ w5,
                                                                 short* __restrict__ stream) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;       // [9][64 n][64 k slot]
+  const int idx = (int)(__builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x());       // [9][64 n][64 k slot]
   if (idx >= 9 * 4096) return;
   const int b = idx >> 12, n = (idx >> 6) & 63, ks = idx & 63;
   const short* src;
@@ -507,6 +509,9 @@ extern "C" int desco_gossip_fused_f16x3_f32(const float* scal4, const int32_t* r
   const int64_t units = groups * ((num_q + WQ - 1) / WQ);
   const int64_t blocks = (units + 7) / 8;
   const unsigned grid = (unsigned)(blocks < (int64_t)cus ? blocks : (int64_t)cus);
+  a.grid_blocks = grid;
   hipLaunchKernelGGL(gossip_fused_f16_kernel, dim3(grid), dim3(GNT), LDS_WAVE, (hipStream_t)stream, a, groups);
   return launch_status("desco_gossip_fused_f16x3_f32");
 }
+
+#include "tu_no_packed_f32_end.hpp"

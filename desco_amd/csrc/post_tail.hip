@@ -23,6 +23,7 @@
 //
 // One workgroup per CU (the three weight images fill the LDS: 156 KB), 8 waves of 32 rows, the next tile's rows in
 // flight under the current tile's 216 MFMAs.
+#include "tu_no_packed_f32_begin.hpp"
 #include "common_device.hpp"
 
 namespace desco {
@@ -48,6 +49,7 @@ struct TailArgs {
   const float *b1, *b2, *b3;        // biases or null
   float* out;
   int64_t ldo;
+  unsigned grid;                    // gridDim.x (set by the launcher: see tu_no_packed_f32_begin.hpp)
 };
 
 // row maximum over both lane halves (lanes n and n + 32 hold the two halves of data row n's features)
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
   float* B1 = reinterpret_cast<float*>(W3 + W3_H);
   float* B2 = B1 + D1;
   float* B3 = B2 + D2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (int)__builtin_amdgcn_workitem_id_x(), lane = tid & 63, wave = tid >> 6;
   fill_image<64, false>(W1, g.w1, 2 * D1, ST64, tid);
   fill_image<64, true>(W2, g.w2, 2 * D2, ST64, tid);
   fill_image<256, true>(W3, g.w3, 2 * D3, ST256, tid);
@@ -100,9 +102,9 @@ __global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
   __syncthreads();
   const int n = lane & 31, h = lane >> 5;
   const int64_t ntiles = (g.m + 31) / 32;
-  int64_t tile = (int64_t)blockIdx.x * NWT + wave;
+  int64_t tile = (int64_t)(int)__builtin_amdgcn_workgroup_id_x() * NWT + wave;
   if (tile >= ntiles) return;
-  const int64_t tstep = (int64_t)gridDim.x * NWT;
+  const int64_t tstep = (int64_t)g.grid * NWT;
   // K step s of the first product: the lane supplies k = 16 s + 8 h + 0..7 of its row (the MFMA's own order)
   float4 xv[8];
 #define DESCO_TAIL_LOAD(t_)                                                     \
@@ -306,6 +308,7 @@ struct HeadArgs {
   int exp2m1;
   float* out;              // [m, HQ]
   int64_t ldo;
+  unsigned grid;           // gridDim.x (set by the launcher)
 };
 
 // x + y of a register pair as ONE scalar add: left to itself hipcc pairs these sums into v_pk_add_f32 with OP_SEL on
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(NWT * 64) void count_head_emb_kernel(HeadArgs g) {
   float* QT = reinterpret_cast<float*>(Wt + 2 * HHID * ST64);       // [HQ][256] re-ordered
   float* R = QT + HQ * HHID;                                         // [256] re-ordered (1 - slope) w2
   float* SQ = R + HHID;                                              // [32]: b2 + slope (w2.Qh[q])
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (int)__builtin_amdgcn_workitem_id_x(), lane = tid & 63, wave = tid >> 6;
   fill_image<64, false>(Wt, g.wt, 2 * HHID, ST64, tid);
   for (int i = tid; i < HQ * HHID; i += NWT * 64) {
     const int q = i >> 8, c = i & 255;
@@ -402,9 +405,9 @@ __global__ __launch_bounds__(NWT * 64) void count_head_emb_kernel(HeadArgs g) {
   __syncthreads();
   const int n = lane & 31, h = lane >> 5;
   const int64_t ntiles = (g.m + 31) / 32;
-  int64_t tile = (int64_t)blockIdx.x * NWT + wave;
+  int64_t tile = (int64_t)(int)__builtin_amdgcn_workgroup_id_x() * NWT + wave;
   if (tile >= ntiles) return;
-  const int64_t tstep = (int64_t)gridDim.x * NWT;
+  const int64_t tstep = (int64_t)g.grid * NWT;
   float4 xv[8];
 #define DESCO_HEAD_LOAD(t_)                                                     \
   {                                                                             \
@@ -535,6 +538,7 @@ extern "C" int desco_post_mp_tail_f16x3_f32(const float* x, int64_t ldx, int64_t
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   const unsigned grid = (unsigned)(want < cus ? want : cus);
+  g.grid = grid;
   hipLaunchKernelGGL(tail::post_tail_kernel, dim3(grid), dim3(tail::NWT * 64), tail::TAIL_LDS, (hipStream_t)stream, g);
   return launch_status("desco_post_mp_tail_f16x3_f32");
 }
@@ -565,6 +569,9 @@ extern "C" int desco_count_head_emb_f16x3_f32(const float* emb, int64_t lde, int
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   const unsigned grid = (unsigned)(want < cus ? want : cus);
+  g.grid = grid;
   hipLaunchKernelGGL(tail::count_head_emb_kernel, dim3(grid), dim3(tail::NWT * 64), tail::HEAD_LDS, (hipStream_t)stream, g);
   return launch_status("desco_count_head_emb_f16x3_f32");
 }
+
+#include "tu_no_packed_f32_end.hpp"
