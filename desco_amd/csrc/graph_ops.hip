@@ -864,70 +864,56 @@ extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, cons
 
 // The closed-form first layer with its global_add_pool fused in (round 6): the count rows of X_1 used to be written by
 // degree_affine_kernel and read back once by segment_sum64 for their pooled block -- 9.9 GB of reads per Syn_1827 x2 pass
-// for sums of rows the kernel had in registers.  Here a workgroup walks whole 16-row tiles (the tiles of the fused
+// for sums of rows the kernel had in registers.  Here a wave walks whole 16-row tiles (the tiles of the fused
 // pooling of the SHMP layer kernel: same pool_bits / pool_slot index, same partial-sum format, so the layer joins the
-// others in pool_reduce): the 16 lane groups compute and store the tile's rows, leave them in an LDS image, and wave 0
-// runs the layer kernel's running sum down the rows in row order (wave-uniform control flow, lane = column).
+// others in pool_reduce): a wave computes and stores the tile's rows one column per lane and runs the layer kernel's
+// running sum down the rows in row order (wave-uniform control flow).
 __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* __restrict__ vrowptr, int64_t num_rows,
                                                                  int S, const float* __restrict__ coef, int act,
                                                                  float slope, float* __restrict__ out, int64_t ldo,
                                                                  const uint32_t* __restrict__ pool_bits,
                                                                  const int32_t* __restrict__ pool_slot,
                                                                  float* __restrict__ pool_part) {
-  __shared__ __attribute__((aligned(16))) float T[2][16][64];
-  const int tid = threadIdx.x, g = tid >> 4, c4 = 4 * (tid & 15), lane = tid & 63;
-  float4 cf[DA_MAXS];
+  // One WAVE per 16-row tile, one lane per column, no LDS and no barrier (round 6; the first form staged the tile in
+  // LDS for wave 0's running sum behind a barrier per tile and wrote at 3.2-3.5 TB/s): the tile's 16 S slot degrees are
+  // the differences of 16 S + 1 consecutive row pointers -- lane l holds difference l, a row's S of them reach the
+  // vector unit as wave-uniform operands (v_readlane) -- a row leaves as one 256-byte store, and the lane's running sum
+  // over the rows IS the column's pooled partial (same order as before: bit-identical results).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cf[DA_MAXS];
 #pragma unroll
-  for (int s = 0; s < DA_MAXS; ++s)
-    cf[s] = s < S ? *reinterpret_cast<const float4*>(coef + s * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 c0 = *reinterpret_cast<const float4*>(coef + S * 64 + c4);
+  for (int s = 0; s < DA_MAXS; ++s) cf[s] = s < S ? coef[s * 64 + lane] : 0.f;
+  const float c0 = coef[S * 64 + lane];
   const int64_t ntiles = (num_rows + 15) / 16;
-  int buf = 0;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x, buf ^= 1) {
-    const int64_t row = t * 16 + g;
-    const bool live = row < num_rows;
-    const int32_t* vp = vrowptr + (live ? row : num_rows - 1) * S;
-    int d[DA_MAXS + 1];
+  const int64_t last = num_rows * S;                       // index of the final row pointer
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t e0 = t * 16 * S + lane;
+    const int p0 = vrowptr[e0 < last ? e0 : last], p1 = vrowptr[e0 + 1 < last ? e0 + 1 : last];
+    const int dvi = __float_as_int((float)(p1 - p0));      // degree of (row lane / S, slot lane % S); 0 past the end
+    const uint32_t E = __builtin_amdgcn_readfirstlane(pool_bits[t]);
+    int slot = __builtin_amdgcn_readfirstlane(pool_slot[t]);
+    const int nr = (int)((num_rows - t * 16) < 16 ? (num_rows - t * 16) : 16);
+    float* o = out ? out + t * 16 * ldo + lane : nullptr;
+    float* pp = pool_part + lane;
+    float run = 0.f;
 #pragma unroll
-    for (int s = 0; s <= DA_MAXS; ++s) d[s] = vp[s <= S ? s : S];
-    float4 acc = c0;
+    for (int r = 0; r < 16; ++r) {
+      if (r < nr) {                                        // (wave-uniform)
+        float acc = c0;
 #pragma unroll
-    for (int s = 0; s < DA_MAXS; ++s) {
-      if (s < S) {
-        const float dd = (float)(d[s + 1] - d[s]);
-        acc.x += dd * cf[s].x;
-        acc.y += dd * cf[s].y;
-        acc.z += dd * cf[s].z;
-        acc.w += dd * cf[s].w;
-      }
-    }
-    acc.x = apply_act(acc.x, act, slope);
-    acc.y = apply_act(acc.y, act, slope);
-    acc.z = apply_act(acc.z, act, slope);
-    acc.w = apply_act(acc.w, act, slope);
-    if (live && out) *reinterpret_cast<float4*>(out + row * ldo + c4) = acc;
-    *reinterpret_cast<float4*>(&T[buf][g][c4]) = acc;
-    __syncthreads();          // (one barrier per tile: the image is double-buffered, wave 0 reads buffer `buf` while the
-                              //  others go on to the next tile's buffer)
-    if (tid < 64) {
-      const uint32_t E = pool_bits[t];
-      int slot = pool_slot[t];
-      const int nr = (int)((num_rows - t * 16) < 16 ? (num_rows - t * 16) : 16);
-      float* pp = pool_part + lane;
-      float run = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (r < nr) {
-          run += T[buf][r][lane];
-          if ((E >> r) & 1u) {
-            pp[(int64_t)slot * 64] = run;
-            ++slot;
-            run = 0.f;
-          }
+        for (int s = 0; s < DA_MAXS; ++s)
+          if (s < S) acc += __int_as_float(__builtin_amdgcn_readlane(dvi, r * S + s)) * cf[s];
+        acc = apply_act(acc, act, slope);
+        if (o) o[r * ldo] = acc;
+        run += acc;
+        if ((E >> r) & 1u) {                               // row r ends its segment (wave-uniform)
+          pp[(int64_t)slot * 64] = run;
+          ++slot;
+          run = 0.f;
         }
       }
-      if (nr > 0 && !((E >> (nr - 1)) & 1u)) pp[(int64_t)slot * 64] = run;
     }
+    if (nr > 0 && !((E >> (nr - 1)) & 1u)) pp[(int64_t)slot * 64] = run;
   }
 }
 
@@ -939,8 +925,8 @@ extern "C" int desco_degree_affine_pool_f32(const int32_t* vrowptr, int64_t num_
   if (!vrowptr || !coef || !pool_bits || !pool_slot || !pool_part || num_rows < 0 || slots < 1 || slots > DA_MAXS ||
       (out && (ldo % 4 || mis16(out))) || mis16(coef) || mis16(pool_part))
     return fail(DESCO_EINVAL, "desco_degree_affine_pool_f32: bad argument (slots <= 4, 16-byte rows)");
-  int64_t blocks = (num_rows + 15) / 16;
-  if (blocks > 16 * 256) blocks = 16 * 256;
+  int64_t blocks = ((num_rows + 15) / 16 + 3) / 4;         // four wave tiles per block
+  if (blocks > 8 * 256) blocks = 8 * 256;
   hipLaunchKernelGGL(degree_affine_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vrowptr,
                      num_rows, slots, coef, act, slope, out, ldo, pool_bits, pool_slot, pool_part);
   return launch_status("desco_degree_affine_pool_f32");
