@@ -93,6 +93,7 @@ SIGNATURES = {
     "desco_pool_reduce_multi_f32": (c_int, [i32, POINTER(vp), vp, vp, vp, i64, POINTER(vp), i64, POINTER(vp), i64, i32, vp]),
     "desco_shmp_layer_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, vp, i64, vp]),
     "desco_shmp_layer_pool_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
+    "desco_shmp_layer_pool_table_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp, vp]),
     "desco_shmp_pool_tile_rows": (c_int, []),
     "desco_degree_affine_f32": (c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i64, vp, i64, vp, vp]),
     "desco_degree_affine_pool_f32": (c_int, [vp, i64, i32, vp, i32, f32, vp, i64, vp, vp, vp, vp]),

@@ -143,6 +143,41 @@ class NeighborhoodBatch(_TrainIndexMixin):
                                 torch.from_numpy(slot[:-1].astype(np.int32)).to(dev), int(slot[-1]))
         return cache[tile_rows]
 
+    def degree_table_index(self, max_rows: int = 1 << 16):
+        """The count rows' S slot degrees as an index into their DISTINCT tuples (built once per batch, on the device):
+        ``(uptr, row_id, vcol_t)`` or None.  The closed-form first layer (ZeroNodeFeat: every node of a type has the same
+        input row) makes X_1[i] a function of row i's degree tuple alone, so X_1 = T[row_id] for the table T of the U
+        distinct tuples -- ``uptr`` [U S + 1] int32 is their row-pointer array (what desco_degree_affine_f32 turns into
+        T), ``row_id`` [num_count] int32 each count row's table row, and ``vcol_t`` = vcol with the sources of the
+        relation slots 0 and 1 (count rows) replaced by their table rows, so that the second layer's launches gather
+        from T (desco_shmp_layer_pool_table_f16x3_f32, which recomputes the launch's own rows from their degrees).  None when the batch has more than ``max_rows`` distinct tuples
+        (the table must stay cache-resident to pay)."""
+        if "_degree_table" in self.__dict__:
+            return self.__dict__["_degree_table"]
+        res = None
+        S, nc, n = self.slots, self.num_count, self.num_rows
+        if S == 4 and nc > 0:
+            vr = self.vrowptr.to(torch.int64)
+            deg = (vr[1:] - vr[:-1]).view(n, S)
+            dc = deg[:nc]
+            m = int(dc.max().item()) + 1
+            if m ** S < 2 ** 62:
+                key = ((dc[:, 0] * m + dc[:, 1]) * m + dc[:, 2]) * m + dc[:, 3]
+                uniq, inv = torch.unique(key, return_inverse=True)
+                if uniq.numel() <= max_rows:
+                    ut = torch.stack([uniq // (m ** 3), (uniq // (m ** 2)) % m, (uniq // m) % m, uniq % m], dim=1)
+                    uptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=ut.device), ut.reshape(-1).cumsum(0)])
+                    # slot of every CSR entry: entry e belongs to (row, slot) pair rs(e); sources of slots 0, 1 are count rows
+                    rs = torch.repeat_interleave(torch.arange(n * S, device=vr.device), deg.reshape(-1))
+                    col = self.vcol.to(torch.int64)
+                    low = (rs % S) < 2
+                    if bool((col[low] < nc).all()):
+                        row_id = inv.to(torch.int32)
+                        vcol_t = torch.where(low, inv[col.clamp(max=nc - 1)], col).to(torch.int32)
+                        res = (uptr.to(torch.int32).contiguous(), row_id.contiguous(), vcol_t.contiguous())
+        self.__dict__["_degree_table"] = res
+        return res
+
     # PyG-style views -----------------------------------------------------------------------
     @property
     def node_feature_dict(self) -> Dict[str, torch.Tensor]:

@@ -38,6 +38,11 @@ struct ShmpArgs {
   // canonical rows are stored since -- and pass out = NULL (rows go to out2 alone).  NULL: the rows come from x.
   const float* xself;
   int64_t ldxs;
+  // ... or not read at all: with self_coef [S + 1][64] the launch's own row i is RECOMPUTED from its S slot degrees d_s (the
+  // tile's row pointers are in LDS anyway) as relu(coef[S] + sum_s d_s coef[s]) -- the closed-form first layer
+  // (desco_degree_affine_f32's arithmetic, bit for bit).  With x = a table of the distinct rows of that layer's output and
+  // column ids that address the table, X_1 [N, 64] need not exist (gnn_model.FIRST_LAYER_TABLE).
+  const float* self_coef;
 };
 
 // 16-row-tile form (shmp_layer16.hip); returns false when the shape is not one it is built for

@@ -804,7 +804,7 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                        float* out2, int64_t ldo2, int act, float slope, desco_stream_t stream,
                        const uint32_t* pool_bits = nullptr, const int32_t* pool_slot = nullptr,
                        float* pool_part = nullptr, const float* wscale = nullptr, float* row_absmax = nullptr,
-                       const float* xself = nullptr, int64_t ldxs = 0) {
+                       const float* xself = nullptr, int64_t ldxs = 0, const float* self_coef = nullptr) {
   if (num_rows == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
   const int max_mfma = x6 ? 2 : 3;
@@ -814,8 +814,10 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
                slots_table != 2))
     return fail(DESCO_EINVAL, "desco_shmp_layer_pool_bf16x6_f32: bad pooling argument (row0 % tile rows, no out2, "
                               "slots_mfma == 2, slots_table == 2)");
-  if (xself && (!(x6 && (wscale || shmp_tile_rows() == 16)) || ldxs % 4 || mis16(xself) || pool))
-    return fail(DESCO_EINVAL, "desco_shmp_layer_*: xself is implemented by the 16-row form only (16-byte rows, no pooling)");
+  if (xself && (!(x6 && (wscale || shmp_tile_rows() == 16)) || ldxs % 4 || mis16(xself)))
+    return fail(DESCO_EINVAL, "desco_shmp_layer_*: xself is implemented by the 16-row form only (16-byte rows)");
+  if (self_coef && (xself || !pool || !wscale || mis16(self_coef)))
+    return fail(DESCO_EINVAL, "desco_shmp_layer_*: self_coef is implemented by the pooled f16x3 launch only (no xself)");
   if (!x || (!vrowptr && slots_stored > 0) || !weights || (!out && !pool && !out2) || row0 < 0 || num_rows < 0 || slots_mfma < 0 ||
       slots_mfma > max_mfma || slots_table < 0 || slots_mfma + slots_table > slots_stored ||
       slots_stored < 0 || slots_stored > MAXS || (slots_stored == 0 && (slots_mfma || slots_table)) || slots_table > 2 || (slots_table > 0 && !ytab) ||
@@ -861,7 +863,8 @@ static int shmp_launch(const char* who, bool x6, const float* x, int64_t ldx, co
              pool_part,
              tile_rows,
              xself,
-             ldxs};
+             ldxs,
+             self_coef};
   if (!out && !pool && !(x6 && tile_rows == 16))
     return fail(DESCO_EINVAL, "desco_shmp_layer_*: out == NULL (rows to out2 alone) is implemented by the 16-row form only");
   hipStream_t st = (hipStream_t)stream;
@@ -958,6 +961,22 @@ extern "C" int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, cons
                             num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
                             ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
                             pool_bits, pool_slot, pool_part, w_scale);
+}
+
+extern "C" int desco_shmp_layer_pool_table_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr,
+                                                     const int32_t* vcol, int64_t row0, int64_t num_rows,
+                                                     int slots_stored, int slots_mfma, int slots_table,
+                                                     const int16_t* wt_planes, const float* w_scale, const float* bias,
+                                                     const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                                     float* out, int64_t ldo, const uint32_t* pool_bits,
+                                                     const int32_t* pool_slot, float* pool_part,
+                                                     const float* self_coef, desco_stream_t stream) {
+  if (!pool_part || !w_scale || !self_coef)
+    return desco::fail(DESCO_EINVAL, "desco_shmp_layer_pool_table_f16x3_f32: pool_part / w_scale / self_coef is null");
+  return desco::shmp_launch("desco_shmp_layer_pool_table_f16x3_f32", true, x, ldx, vrowptr, vcol, row0,
+                            num_rows, slots_stored, slots_mfma, slots_table, wt_planes, bias, ytab,
+                            ldy, ytab_row0, out, ldo, nullptr, 0, DESCO_ACT_RELU, 0.f, stream,
+                            pool_bits, pool_slot, pool_part, w_scale, nullptr, nullptr, 0, self_coef);
 }
 
 extern "C" int desco_shmp_pool_tile_rows(void) { return desco::shmp_tile_rows(); }

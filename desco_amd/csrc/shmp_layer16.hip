@@ -118,9 +118,32 @@ __device__ __forceinline__ void f4add(float4& a, const float4 b) {
 #define DESCO_ISSUE_SELF(it_)                                                                  \
   {                                                                                            \
     const int r_ = (it_) * 8 + g8;                                                             \
-    const float* p_ = xsb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDXS;                        \
-    DESCO_SELF_REG(it_, 0) = *reinterpret_cast<const float4*>(p_);                             \
-    DESCO_SELF_REG(it_, 1) = *reinterpret_cast<const float4*>(p_ + 32);                        \
+    if constexpr (SELFDEG) {                                                                   \
+      /* the row from its own slot degrees (row pointers of the tile: LDS), degree_affine's arithmetic */ \
+      const int vb_ = (r_ < nr ? r_ : nr - 1) * S;                                             \
+      const float* cq_ = cself + 4 * l8;                                                       \
+      float4 a0_ = *reinterpret_cast<const float4*>(cq_ + S * 64);                             \
+      float4 a1_ = *reinterpret_cast<const float4*>(cq_ + S * 64 + 32);                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < MAXS; ++s_) {                                    \
+        if (s_ < S) {                                                                          \
+          const float dd_ = (float)(rp[vb_ + s_ + 1] - rp[vb_ + s_]);                          \
+          const float4 q0_ = *reinterpret_cast<const float4*>(cq_ + s_ * 64);                  \
+          const float4 q1_ = *reinterpret_cast<const float4*>(cq_ + s_ * 64 + 32);             \
+          a0_.x = fmaf(dd_, q0_.x, a0_.x); a0_.y = fmaf(dd_, q0_.y, a0_.y);                    \
+          a0_.z = fmaf(dd_, q0_.z, a0_.z); a0_.w = fmaf(dd_, q0_.w, a0_.w);                    \
+          a1_.x = fmaf(dd_, q1_.x, a1_.x); a1_.y = fmaf(dd_, q1_.y, a1_.y);                    \
+          a1_.z = fmaf(dd_, q1_.z, a1_.z); a1_.w = fmaf(dd_, q1_.w, a1_.w);                    \
+        }                                                                                      \
+      }                                                                                        \
+      a0_.x = fmaxf(a0_.x, 0.f); a0_.y = fmaxf(a0_.y, 0.f); a0_.z = fmaxf(a0_.z, 0.f); a0_.w = fmaxf(a0_.w, 0.f); \
+      a1_.x = fmaxf(a1_.x, 0.f); a1_.y = fmaxf(a1_.y, 0.f); a1_.z = fmaxf(a1_.z, 0.f); a1_.w = fmaxf(a1_.w, 0.f); \
+      DESCO_SELF_REG(it_, 0) = a0_;                                                            \
+      DESCO_SELF_REG(it_, 1) = a1_;                                                            \
+    } else {                                                                                   \
+      const float* p_ = xsb + (grow0 + (r_ < nr ? r_ : nr - 1)) * LDXS;                      \
+      DESCO_SELF_REG(it_, 0) = *reinterpret_cast<const float4*>(p_);                           \
+      DESCO_SELF_REG(it_, 1) = *reinterpret_cast<const float4*>(p_ + 32);                      \
+    }                                                                                          \
   }
 // table pseudo block: the first source of table slot 0 (-> u) and of table slot 1 (-> w) of row it_
 #define DESCO_TAB_CUR(it_)                                                                  \
@@ -458,7 +481,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 // source-row addresses then need a shift instead of a 64-bit multiply per gathered row, and the stores
 // of a tile are one address with immediate offsets
 // POOL: fused pooling epilogue (instantiated for the count-row launches only)
-template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16>
+template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16, bool SELFDEG = false>
 __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const int32_t* __restrict__ rowptr_s,
                                                               const uint32_t* __restrict__ pool_bits_s,
                                                               const int32_t* __restrict__ pool_slot_s) {
@@ -484,6 +507,10 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
   (void)rs;
   float* biasL = lds + W_FLOATS + NW * WAVE_LDS_;          // [64] bias (zeros without one), block-shared
   int* next_sub = reinterpret_cast<int*>(biasL + 64);      // the block's tile hand-out counter
+  // SELFDEG (its own instantiation: the launch's own rows recomputed from their slot degrees, see shmp_args.hpp): the
+  // [S + 1][64] coefficients, block-shared
+  float* cself = biasL + 64 + 4;
+  (void)cself;
 
   // ---- resident weights -------------------------------------------------------------------
   {
@@ -496,6 +523,8 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
     }
   }
   if (tid < 64) biasL[tid] = g.bias ? g.bias[tid] : 0.f;
+  if constexpr (SELFDEG)
+    for (int i = tid; i < (g.S + 1) * 64; i += NW * 64) cself[i] = g.self_coef[i];
   if (tid == 0) *next_sub = 0;
   __syncthreads();
 
@@ -899,19 +928,20 @@ __global__ __launch_bounds__(NW * 64) void shmp_layer16_kernel(ShmpArgs g, const
 #undef DESCO_GROUP_MAX
 #undef DESCO_ABSMAX8
 
-template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16>
+template <int NW, int KB, int ST, bool LD64, bool POOL, bool F16, bool SELFDEG = false>
 static void shmp16_launch_one(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   constexpr int WST = KB * 64 + 16;
   constexpr size_t w_floats = (size_t)(F16 ? 2 : 3) * 64 * WST / 2;
-  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * (F16 ? WAVE_LDS_F16 : WAVE_LDS) + 64 + 4);
+  constexpr size_t shmem = sizeof(float) * (w_floats + (size_t)NW * (F16 ? WAVE_LDS_F16 : WAVE_LDS) + 64 + 4 +
+                                           (SELFDEG ? (MAXS + 1) * 64 : 0));
   static_assert(shmem <= 160 * 1024, "SHMP layer (16-row tiles): LDS budget exceeded");
   static DeviceOnce attr_once;        // function attributes are per device
   if (!attr_once.done()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16, SELFDEG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_once.mark();
   }
-  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16>), dim3(grid), dim3(NW * 64), shmem, st, g,
+  hipLaunchKernelGGL((shmp_layer16_kernel<NW, KB, ST, LD64, POOL, F16, SELFDEG>), dim3(grid), dim3(NW * 64), shmem, st, g,
                      g.vrowptr, g.pool_bits, g.pool_slot);
 }
 
@@ -921,6 +951,17 @@ static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
   if (g.pool_part) {
     if constexpr (KB == 3) {
       if (g.st != 2) return false;
+      if (g.self_coef) {                 // the rows themselves recomputed from their slot degrees (fp16 form only)
+        if constexpr (F16) {
+          if (ld64)
+            shmp16_launch_one<NW, 3, 2, true, true, true, true>(g, grid, st);
+          else
+            shmp16_launch_one<NW, 3, 2, false, true, true, true>(g, grid, st);
+          return true;
+        } else {
+          return false;
+        }
+      }
       if (ld64)
         shmp16_launch_one<NW, 3, 2, true, true, F16>(g, grid, st);
       else
@@ -930,6 +971,7 @@ static bool shmp16_launch_st(const ShmpArgs& g, unsigned grid, hipStream_t st) {
       return false;
     }
   }
+  if (g.self_coef) return false;          // (built for the pooled count-row launch only)
 #define DESCO_ONE(ST_)                                \
   if (ld64)                                           \
     shmp16_launch_one<NW, KB, ST_, true, false, F16>(g, grid, st);    \

@@ -527,6 +527,12 @@ def _anchor_const_input(pk, gnn, canon, row_bound=None):
     return _gemm_planes(canon[:, H:], *pk["anchor_nk_const"], act=ops.ACT_LEAKY, slope=0.1, **kw)
 
 
+# X_1's count rows are never written: the closed-form first layer's output is a function of a row's four slot degrees, so
+# the second layer gathers the few thousand DISTINCT rows from a table and recomputes its own rows from their degrees
+# (NeighborhoodBatch.degree_table_index, desco_shmp_layer_pool_table_f16x3_f32); bit-identical to the launch on the
+# materialised tensor
+FIRST_LAYER_TABLE = os.environ.get("DESCO_FIRST_LAYER_TABLE", "1") != "0"
+
 # the pooled embeddings [B, 64 (L + 1)] are never written: post_mp.0 forms its operand's chunks from the anchor rows and
 # the fused pooling's partial sums in its load phase (desco_pool_post_bf16x6_f32; neighborhoods of at most 33 count rows)
 POOL_POST_FUSED = os.environ.get("DESCO_POOL_POST_FUSED", "1") != "0"
@@ -551,6 +557,7 @@ def _shmp_pooled(gnn: BaseGNN, batch, fuse_post0: bool = False):
         groups = [("union_node", 0, N, 2)]
     feat = batch.node_feature
     const_input = feat is None and FUSED_SHMP_LAYER and core.layer_num >= 1
+    tab1 = table1 = None
     if const_input:
         # ZeroNodeFeat (workload.py:431-440): pre_mp(x) is its bias, identical for every node of a
         # type, so X_0 is never materialised and layer 0 is a degree-affine map (desco_hip.h).
@@ -568,6 +575,16 @@ def _shmp_pooled(gnn: BaseGNN, batch, fuse_post0: bool = False):
                 and Nc > 0 and ops.pool_tile_rows() == 16):
             pbits1, pslot1, nslots1 = batch.pool_index()
             pool1 = (pbits1, pslot1, torch.empty((nslots1, H), device=dev))
+        # ... and with the table form of the second layer's launches they are not stored either
+        if (FIRST_LAYER_TABLE and pool1 is not None and canon_once and core.layer_num >= 2 and SHMP_F16X3
+                and "wt_tab" in pk["layers"][1]["count"]
+                and isinstance(pk["layers"][1]["count"].get("wt_mfma_x6"), ops.F16Planes)):
+            tab1 = batch.degree_table_index()
+        if tab1 is not None:
+            coef_c = _first_layer_coef(pk, "count", 4, S, x0, src_of_slot, dev)
+            table1 = torch.empty((tab1[0].numel() // S, H), device=dev)
+            ops.degree_affine(tab1[0], 0, table1.shape[0], S, coef_c, ops.ACT_RELU, 0.0, table1)
+            xn = None
         for t, r0, r1, su in groups:
             if r1 <= r0:
                 continue
@@ -621,6 +638,11 @@ def _shmp_pooled(gnn: BaseGNN, batch, fuse_post0: bool = False):
         # the last layer's count rows feed nothing but the pooling: with fused pooling they are
         # never stored (the canonical rows still are, they sit at the end of the same tensor)
         xn = torch.empty((N, H), device=dev)
+        # layer input, column ids and (count rows) self index of this layer's launches: X_l itself, or -- for the second
+        # layer when X_1's count rows exist as a table of distinct rows only -- that table
+        x_src, vcol_l, coef_l = X[-1], batch.vcol, None
+        if const_input and first == 1 and l == 1 and tab1 is not None:
+            x_src, vcol_l, coef_l = table1, tab1[2], coef_c
         if FUSED_SHMP_LAYER:
             for t, r0, r1, su in groups:                                   # :262-264, :273, :389-395
                 if r1 <= r0:
@@ -634,13 +656,13 @@ def _shmp_pooled(gnn: BaseGNN, batch, fuse_post0: bool = False):
                     if fpool and "wt_mfma_x6" in e:
                         pool_parts[l + 1] = torch.empty((nslots, H), device=dev)
                         pool = (pbits, pslot, pool_parts[l + 1])
-                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, 2,
+                    ops.shmp_layer(x_src, batch.vrowptr, vcol_l, r0, r1 - r0, S, 2,
                                    e.get("wt_mfma_x6", e["wt_mfma"]) if SHMP_BF16X6 else e["wt_mfma"],
                                    e["b"], None if (pool is not None and last) else xn, ytab=ytab,
-                                   ytab_row0=Nc, pool=pool)
+                                   ytab_row0=Nc, pool=pool, self_coef=coef_l)
                 else:
                     once = canon_once and t == "canonical" and isinstance(e.get("wt_x6"), ops.F16Planes)
-                    ops.shmp_layer(X[-1], batch.vrowptr, batch.vcol, r0, r1 - r0, S, su,
+                    ops.shmp_layer(x_src, batch.vrowptr, vcol_l, r0, r1 - r0, S, su,
                                    e.get("wt_x6", e["wt"]) if SHMP_BF16X6 else e["wt"], e["b"], None if once else xn,
                                    out2=(canon[:, (l + 1) * H:(l + 2) * H]
                                          if direct_canon and t == "canonical" else None),

@@ -303,7 +303,7 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
                bias: torch.Tensor, out: Optional[torch.Tensor], ytab: Optional[torch.Tensor] = None,
                ytab_row0: int = 0, out2: Optional[torch.Tensor] = None,
                pool: Optional[tuple] = None, row_absmax: Optional[torch.Tensor] = None,
-               xself: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+               xself: Optional[torch.Tensor] = None, self_coef: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Fused gather + folded Linear + relu for rows [row0, row0+num_rows) (see desco_hip.h).
     ``xself`` [num_rows, >= 64] (f16x3 form): the launch's own rows (self block) read from this view -- row i of the launch
     at xself[i - row0] -- instead of from ``x``; ``out`` may then be None when ``out2`` is given.
@@ -311,6 +311,9 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     ``out2`` [num_rows, >=64] (optional): second copy of the produced rows (see desco_hip.h).
     ``wt``: fp32 [(sm+1)*64, 64] (f32 MFMA) or int16 planes [3, 64, (sm+1)*64] =
     ``split_bf16_planes(wt.t())`` (fp32-accurate bf16x6 arithmetic, sm <= 2).
+    ``self_coef`` [slots_stored + 1, 64] (pooled f16x3 launch): the launch's own rows are recomputed from their slot
+    degrees, relu(coef[S] + sum_s d_s coef[s]), instead of read (desco_shmp_layer_pool_table_f16x3_f32: ``x`` is then a
+    table of the layer input's distinct rows and ``vcol`` addresses its rows).
     ``pool`` = (pool_bits, pool_slot, pool_part): also leave the per-(tile, segment) partial sums of
     the produced rows in ``pool_part`` (fused global_add_pool, finished by ``pool_reduce``); ``out``
     may then be None (rows not stored)."""
@@ -318,7 +321,9 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     x6 = f16 or wt.dtype == torch.int16
     if pool is not None:
         return _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out,
-                                ytab, ytab_row0, pool)
+                                ytab, ytab_row0, pool, xself, self_coef)
+    if self_coef is not None:
+        raise ValueError("shmp_layer: self_coef is implemented by the pooled f16x3 launch only")
     if f16:
         assert wt.planes.is_contiguous() and wt.planes.shape == (2, 64, (slots_mfma + 1) * 64)
     elif x6:
@@ -361,9 +366,11 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
 
 
 def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma, wt, bias, out, ytab,
-                     ytab_row0, pool):
+                     ytab_row0, pool, xself=None, self_coef=None):
     bits, slot, part = pool
     f16 = isinstance(wt, F16Planes)
+    if xself is not None or (self_coef is not None and not f16):
+        raise ValueError("shmp_layer(pool=...): no xself; self_coef with the f16x3 form only")
     assert ytab is not None and (f16 or (wt.dtype == torch.int16 and wt.is_contiguous()))
     xp, ldx = _rows(x, "x")
     op, ldo = (None, 0) if out is None else _rows(out, "out")
@@ -379,7 +386,12 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
                 slots_stored, slots_mfma, st)
         tail = (_dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0, op, ldo, _dev(bits, "pool_bits", torch.int32),
                 _dev(slot, "pool_slot", torch.int32), _dev(part, "pool_part"), _stream())
-        if f16:
+        if self_coef is not None:
+            assert tuple(self_coef.shape) == (slots_stored + 1, 64) and self_coef.is_contiguous()
+            rc = L.desco_shmp_layer_pool_table_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16),
+                                                         _dev(wt.scale, "w_scale"), *tail[:-1],
+                                                         _dev(self_coef, "self_coef"), tail[-1])
+        elif f16:
             rc = L.desco_shmp_layer_pool_f16x3_f32(*head, _dev(wt.planes, "wt", torch.int16),
                                                    _dev(wt.scale, "w_scale"), *tail)
         else:

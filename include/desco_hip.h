@@ -326,6 +326,21 @@ int desco_shmp_layer_pool_f16x3_f32(const float* x, int64_t ldx, const int32_t* 
                                     float* out, int64_t ldo, const uint32_t* pool_bits,
                                     const int32_t* pool_slot, float* pool_part, desco_stream_t stream);
 
+/* desco_shmp_layer_pool_f16x3_f32 for a layer input that exists as a TABLE of its distinct rows only.  The closed-form first
+ * layer's output is a function of a row's S slot degrees, so X_1 has a few thousand distinct rows: x = that table (L2-resident),
+ * vcol = the column ids with the sources of the MFMA slots replaced by their table rows, and the launch's OWN rows (the self
+ * block's operand) are RECOMPUTED from their slot degrees with the first layer's coefficients self_coef [slots_stored + 1][64]:
+ *   own row i = relu(self_coef[S] + sum_s degree_s(i) * self_coef[s])          (desco_degree_affine_f32's arithmetic)
+ * -- X_1 [N, 64] is never written or read (host side: NeighborhoodBatch.degree_table_index, gnn_model.FIRST_LAYER_TABLE).
+ * Results are bit-identical to the launch on the materialised tensor. */
+int desco_shmp_layer_pool_table_f16x3_f32(const float* x, int64_t ldx, const int32_t* vrowptr, const int32_t* vcol,
+                                          int64_t row0, int64_t num_rows, int slots_stored, int slots_mfma,
+                                          int slots_table, const int16_t* wt_planes, const float* w_scale,
+                                          const float* bias, const float* ytab, int64_t ldy, int64_t ytab_row0,
+                                          float* out, int64_t ldo, const uint32_t* pool_bits,
+                                          const int32_t* pool_slot, float* pool_part, const float* self_coef,
+                                          desco_stream_t stream);
+
 int desco_pool_reduce_f32(const float* pool_part, const uint32_t* pool_bits, const int32_t* pool_slot,
                           const int32_t* seg_ptr, int64_t num_seg, const float* extra,
                           int64_t ld_extra, float* out, int64_t ldo, int tile_rows,

@@ -1246,3 +1246,36 @@ def test_count_head_from_the_embeddings_keeps_the_logits(setup):
     print(f"[head from emb] {batch.num_graphs} neighborhoods: one launch vs oracle {e1:.2e}, two launches {e2:.2e}, "
           f"one vs two {d:.2e}")
     assert e1 <= LOGIT_TOL and e2 <= LOGIT_TOL and e1 <= 2.0 * max(e2, 1e-6) and d > 0.0
+
+
+def test_first_layer_rows_as_a_table_changes_no_bit(setup):
+    """gnn_model.FIRST_LAYER_TABLE: X_1's count rows are a function of their four slot degrees, so the second layer's
+    launches gather the DISTINCT rows from a table (x = the table, column ids remapped, the rows themselves recomputed
+    from their degrees: desco_shmp_layer_pool_table_f16x3_f32) and X_1 [N, 64] is never written.  Same values into the same sums in
+    the same order: identical logits.  Also pins the index itself (table[row_id] == the materialised rows' degrees)."""
+    import desco_amd.gnn_model as GM
+    nm, *_ = setup
+    graphs = golden_graphs(max_n=60) + random_family_graphs(11, 30) + [(k + 1, [(0, v) for v in range(1, k + 1)]) for k in (1, 17, 40)]
+    part = build_partition(GraphSet.from_edge_lists(graphs), 4)
+    batch = NeighborhoodBatch(part, DEV)
+    idx = batch.degree_table_index()
+    assert idx is not None
+    uptr, row_id, vcol_t = idx
+    S, nc = batch.slots, batch.num_count
+    vr = batch.vrowptr.long()
+    deg = (vr[1:] - vr[:-1]).view(-1, S)[:nc]
+    ut = (uptr.long()[1:] - uptr.long()[:-1]).view(-1, S)
+    assert torch.equal(ut[row_id.long()], deg) and len(torch.unique(ut, dim=0)) == len(ut) < nc
+    outs = []
+    for tab in (True, False):
+        GM.FIRST_LAYER_TABLE = tab
+        try:
+            with torch.no_grad():
+                outs.append(nm._logits(batch, exp2=False).clone())
+        finally:
+            GM.FIRST_LAYER_TABLE = True
+    print(f"[first layer table] {batch.num_graphs} neighborhoods, {nc} count rows, {len(ut)} distinct degree tuples, "
+          f"max |d| = {float((outs[0] - outs[1]).abs().max()):.3e}")
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    # too many distinct tuples for the cap: the materialised path runs
+    assert NeighborhoodBatch(part, DEV).degree_table_index(max_rows=3) is None
