@@ -553,10 +553,12 @@ __global__ __launch_bounds__(256) void degree_affine_kernel(const int32_t* __res
       for (int s = 0; s < DA_MAXS; ++s) {
         if (s < S) {
           const float d = (float)(dptr[u][s + 1] - dptr[u][s]);
-          acc.x += d * cf[s].x;
-          acc.y += d * cf[s].y;
-          acc.z += d * cf[s].z;
-          acc.w += d * cf[s].w;
+          // (explicit fmas: the same chain as degree_affine_pool_kernel and the layer kernel's SELFDEG rows -- left to
+          //  -ffp-contract hipcc fuses some of these sites and not others)
+          acc.x = fmaf(d, cf[s].x, acc.x);
+          acc.y = fmaf(d, cf[s].y, acc.y);
+          acc.z = fmaf(d, cf[s].z, acc.z);
+          acc.w = fmaf(d, cf[s].w, acc.w);
         }
       }
       acc.x = apply_act(acc.x, act, slope);
@@ -868,8 +870,9 @@ extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, cons
 // pooling of the SHMP layer kernel: same pool_bits / pool_slot index, same partial-sum format, so the layer joins the
 // others in pool_reduce): a wave computes and stores the tile's rows one column per lane and runs the layer kernel's
 // running sum down the rows in row order (wave-uniform control flow).
+template <int CS>      // CS = the slot count as a constant (lane selects of the v_readlane are then immediates), or 0
 __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* __restrict__ vrowptr, int64_t num_rows,
-                                                                 int S, const float* __restrict__ coef, int act,
+                                                                 int S_, const float* __restrict__ coef, int act,
                                                                  float slope, float* __restrict__ out, int64_t ldo,
                                                                  const uint32_t* __restrict__ pool_bits,
                                                                  const int32_t* __restrict__ pool_slot,
@@ -880,6 +883,7 @@ __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* 
   // vector unit as wave-uniform operands (v_readlane) -- a row leaves as one 256-byte store, and the lane's running sum
   // over the rows IS the column's pooled partial (same order as before: bit-identical results).
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = CS ? CS : S_;
   float cf[DA_MAXS];
 #pragma unroll
   for (int s = 0; s < DA_MAXS; ++s) cf[s] = s < S ? coef[s * 64 + lane] : 0.f;
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* 
         float acc = c0;
 #pragma unroll
         for (int s = 0; s < DA_MAXS; ++s)
-          if (s < S) acc += __int_as_float(__builtin_amdgcn_readlane(dvi, r * S + s)) * cf[s];
+          if (s < S) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(dvi, r * S + s)), cf[s], acc);
         acc = apply_act(acc, act, slope);
         if (o) o[r * ldo] = acc;
         run += acc;
@@ -927,8 +931,12 @@ extern "C" int desco_degree_affine_pool_f32(const int32_t* vrowptr, int64_t num_
     return fail(DESCO_EINVAL, "desco_degree_affine_pool_f32: bad argument (slots <= 4, 16-byte rows)");
   int64_t blocks = ((num_rows + 15) / 16 + 3) / 4;         // four wave tiles per block
   if (blocks > 8 * 256) blocks = 8 * 256;
-  hipLaunchKernelGGL(degree_affine_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vrowptr,
-                     num_rows, slots, coef, act, slope, out, ldo, pool_bits, pool_slot, pool_part);
+  if (slots == 4)
+    hipLaunchKernelGGL(degree_affine_pool_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vrowptr,
+                       num_rows, slots, coef, act, slope, out, ldo, pool_bits, pool_slot, pool_part);
+  else
+    hipLaunchKernelGGL(degree_affine_pool_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vrowptr,
+                       num_rows, slots, coef, act, slope, out, ldo, pool_bits, pool_slot, pool_part);
   return launch_status("desco_degree_affine_pool_f32");
 }
 
