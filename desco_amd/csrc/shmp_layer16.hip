@@ -62,10 +62,21 @@ __device__ __attribute__((aligned(16))) float shmp16_zero_row[64] = {};
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 __device__ __forceinline__ void f4add(float4& a, const float4 b) {
+#if !defined(SHMP16_F4ADD_PACKED)
+  // four plain adds: left to itself hipcc pairs them into two v_pk_add_f32, which cost more issue time than the four
+  // (tu_no_packed_f32_begin.hpp; the whole file without packed selection spills).  Same-box A/B
+  // (profiles/r6_aq_ab_f4add_scalar.log): count-row launch 6.45 -> 6.32 ms on Syn_1827 shapes (many gather steps per
+  // tile), 1.206 -> 1.208 on COX2 shapes
+  asm("v_add_f32 %0, %0, %1" : "+v"(a.x) : "v"(b.x));
+  asm("v_add_f32 %0, %0, %1" : "+v"(a.y) : "v"(b.y));
+  asm("v_add_f32 %0, %0, %1" : "+v"(a.z) : "v"(b.z));
+  asm("v_add_f32 %0, %0, %1" : "+v"(a.w) : "v"(b.w));
+#else
   a.x += b.x;
   a.y += b.y;
   a.z += b.z;
   a.w += b.w;
+#endif
 }
 
 // 4 bytes per lane from global straight into LDS: lane i's dword lands at dst_[i] (dst_ wave-uniform).

@@ -347,7 +347,8 @@ def shmp_layer(x: torch.Tensor, vrowptr: torch.Tensor, vcol: torch.Tensor, row0:
     L = _lib.lib()
     # executed MFMA flops; compulsory bytes: x once + out once + this range's share of the indices
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
-    nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored + vcol.numel() * num_rows / max(x.shape[0], 1))
+    nb = 512.0 * num_rows + 4.0 * (num_rows * slots_stored +
+                                   vcol.numel() * num_rows / max((vrowptr.numel() - 1) // max(slots_stored, 1), 1))
     # profiler key = the device kernel's template instance (KB = sm + 1 weight blocks, ST table slots)
     with _Timed(shmp_kernel_name(slots_mfma + 1, st, x6, f16), fl, nb):
         head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
@@ -379,8 +380,9 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
     L = _lib.lib()
     fl = 2.0 * num_rows * (slots_mfma + 1) * 64 * 64
     # x once (+ out once when stored) + indices + the partial rows (about one per 32 rows + one per segment)
-    nb = (256.0 if out is None else 512.0) * num_rows + 4.0 * (num_rows * slots_stored +
-                                                                vcol.numel() * num_rows / max(x.shape[0], 1))
+    # (table form: the input rows are not read from HBM either -- a few thousand table rows stand for all of them)
+    nb = ((0.0 if self_coef is not None else 256.0) + (0.0 if out is None else 256.0)) * num_rows + 4.0 * (
+        num_rows * slots_stored + vcol.numel() * num_rows / max((vrowptr.numel() - 1) // max(slots_stored, 1), 1))
     with _Timed(shmp_kernel_name(slots_mfma + 1, st, True, f16), fl, nb):
         head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
                 slots_stored, slots_mfma, st)
