@@ -64,7 +64,7 @@ def mfma_peak(kernel: str):
     """(peak TFLOP/s in algorithmic fp32 flops, pipe) for an MFMA-bound kernel, else None."""
     if kernel == "gemm_f32_kernel" or kernel.endswith(",f32>"):
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32"
-    if kernel in ("gemm_f16x3_kernel", "gossip_fused_f16_kernel", "post_tail_kernel") or kernel.endswith(",f16x3>"):
+    if kernel in ("gemm_f16x3_kernel", "gossip_fused_f16_kernel", "post_tail_kernel") or ",f16x3" in kernel:
         return PEAK_X3_TFLOPS, "fp16 MFMA x 3 products (f16x3, fp32-accurate)"
     if kernel in ("gemm_split_kernel", "gossip_fused_kernel") or kernel.endswith(",x6>") or \
             kernel.startswith("shmp_layer16_kernel<"):

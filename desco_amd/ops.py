@@ -383,7 +383,10 @@ def _shmp_layer_pool(x, vrowptr, vcol, row0, num_rows, slots_stored, slots_mfma,
     # (table form: the input rows are not read from HBM either -- a few thousand table rows stand for all of them)
     nb = ((0.0 if self_coef is not None else 256.0) + (0.0 if out is None else 256.0)) * num_rows + 4.0 * (
         num_rows * slots_stored + vcol.numel() * num_rows / max((vrowptr.numel() - 1) // max(slots_stored, 1), 1))
-    with _Timed(shmp_kernel_name(slots_mfma + 1, st, True, f16), fl, nb):
+    name = shmp_kernel_name(slots_mfma + 1, st, True, f16)
+    if self_coef is not None:           # (its own instantiation of the device kernel: listed on its own)
+        name = name[:-1] + ",selfdeg>"
+    with _Timed(name, fl, nb):
         head = (xp, ldx, _dev(vrowptr, "vrowptr", torch.int32), _dev(vcol, "vcol", torch.int32), row0, num_rows,
                 slots_stored, slots_mfma, st)
         tail = (_dev(bias.contiguous(), "bias"), yp, ldy, ytab_row0, op, ldo, _dev(bits, "pool_bits", torch.int32),

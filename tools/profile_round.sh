@@ -48,9 +48,9 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(f"{out}/sq_{key}_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("desco::", "").replace("gf16::", "").replace("small::", "").strip()
-        if k.startswith("shmp_layer16_kernel<"):           # <NW, KB, ST, LD64, POOL, F16>
+        if k.startswith("shmp_layer16_kernel<"):           # <NW, KB, ST, LD64, POOL, F16[, SELFDEG]>
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-            k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}>"
+            k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}{',selfdeg' if len(a) > 6 and a[6] == 'true' else ''}>"
         elif k.startswith("shmp_layer_f32_kernel<"):
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
             k = f"shmp_layer_f32_kernel<{a[0]},{a[1]},{'x6' if a[2] == 'true' else 'f32'}>"

@@ -42,7 +42,7 @@ for ds in (1, 0):
             if not k.startswith("shmp_layer16_kernel<"):
                 continue
             a = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-            k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}>"
+            k = f"shmp_layer16_kernel<{a[1]},{a[2]}{',f16x3' if len(a) > 5 and a[5] == 'true' else ''}{',selfdeg' if len(a) > 6 and a[6] == 'true' else ''}>"
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
     for k, c in agg.items():
