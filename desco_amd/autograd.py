@@ -24,6 +24,11 @@ PRECISION = "fp32"
 # ShmpTrunkSmall: one workgroup per graph (csrc/shmp_small.hip, round 6) when the graphs are small enough; False: the
 # one-workgroup kernels (their cross-check)
 GRAPH_TRUNK_KERNEL = True
+# the gossip step's forward and input-gradient products (a million (node, query) rows through 64- to 256-wide weights) on
+# the bf16x6 pipe -- fp32-accurate at the streaming rate -- instead of the exact-fp32 matrix pipe, which runs them at
+# 2-4 x their HBM time (desco_gemm_bf16x6_desc_f32: gate and dropout factor in the epilogue); weight gradients stay fp32
+import os as _os
+TRAIN_GEMM_BF16X6 = _os.environ.get("DESCO_TRAIN_GEMM_BF16X6", "1") != "0"
 
 
 def set_precision(p: str) -> None:
@@ -448,13 +453,21 @@ class GossipTrunk(torch.autograd.Function):
             dp = ops.DropSite(key, GossipTrunk.SITE_POST, drop[1])
         h1 = ops.affine_rows(None, C6, V0, ops.ACT_RELU, 0.0, d1)                   # layer 0 (closed form)
         hh = ops.gossip_gather(h1, rowptr, col, n, q, g1)                           # layer 1 aggregate
-        h2 = ops.affine_rows(ops.gemm(hh, wt1, a2=h1), C3, V1, ops.ACT_RELU, 0.0, d2)
-        y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1, dp)   # post_mp.0 + .1 + .2
-        y3 = ops.gemm(y, w3t, b3, act=ops.ACT_RELU)
-        y5 = ops.gemm(y3, w5t, b5, act=ops.ACT_RELU)
+        x6 = TRAIN_GEMM_BF16X6 and PRECISION == "fp32"
+        if x6:
+            w3, w5 = w3.contiguous(), w5.contiguous()
+            h2 = ops.affine_rows(ops.gemm_split(hh, ops.split_bf16_planes_t(wt1), a2=h1), C3, V1, ops.ACT_RELU, 0.0, d2)
+            y = ops.affine_rows(ops.gemm_split(h1, ops.split_bf16_planes_t(wtp), a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1, dp)
+            y3 = ops.gemm_split(y, ops.split_bf16_planes(w3), b3, act=ops.ACT_RELU)
+            y5 = ops.gemm_split(y3, ops.split_bf16_planes(w5), b5, act=ops.ACT_RELU)
+        else:
+            h2 = ops.affine_rows(ops.gemm(hh, wt1, a2=h1), C3, V1, ops.ACT_RELU, 0.0, d2)
+            y = ops.affine_rows(ops.gemm(h1, wtp, a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1, dp)   # post_mp.0 + .1 + .2
+            y3 = ops.gemm(y, w3t, b3, act=ops.ACT_RELU)
+            y5 = ops.gemm(y3, w5t, b5, act=ops.ACT_RELU)
         pred = ops.affine_scalar(ops.rowdot_add(y5, w7, 0.0, None), add=b7, addv=x)
         ctx.save_for_backward(rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5, key)
-        ctx.n, ctx.q, ctx.drop = n, q, drop
+        ctx.n, ctx.q, ctx.drop, ctx.x6 = n, q, drop, x6
         return pred
 
     @staticmethod
@@ -468,6 +481,8 @@ class GossipTrunk(torch.autograd.Function):
         R = h1.shape[0]
         dev = h1.device
         dz5, dwb7 = ops.rowdot_bwd(y5, w7, dcorr.contiguous())                      # [R,256], (dw7 | db7)
+        if ctx.x6:
+            return GossipTrunk._backward_x6(ctx, dz5, dwb7, d1, d2, dp)
         # dA = dZ W^T wants W itself as the [K = out, N = in] operand: post_mp.3 / .5 as torch keeps them, and the
         # transposed blocks of the two folded weights (one copy2d launch)
         wp = torch.empty((2, 64, 64), device=dev)                                    # [(h1 | h2) block][out][in]
@@ -501,6 +516,45 @@ class GossipTrunk(torch.autograd.Function):
                                 dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
         return (None, None, None, None, None, None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp,
                 dw3t, db3, dw5t, db5, dwb7[:256], dwb7[256:257])
+
+
+def _gossip_trunk_backward_x6(ctx, dz5, dwb7, d1, d2, dp):
+    """GossipTrunk.backward with the input-gradient products on the bf16x6 pipe.  dA = dZ W wants the n-major planes of
+    [n = in][k = out]: the transposing split of torch's [out, in] weights (post_mp.3 / .5) and the folded weights' blocks
+    as they are stored ([in, out]); dh1 = dzp Wp_h1 + dz1 W1_h1 is ONE K = 128 product over [dzp | dz1]."""
+    rowptr, col, C6, C3, C2, g1c, w3, w5, wt1, wtp, w7, h1, hh, h2, y, y3, y5, key = ctx.saved_tensors
+    n, q = ctx.n, ctx.q
+    R, dev = h1.shape[0], h1.device
+    dz3 = torch.empty((R, 64), device=dev)
+    ops.gemm_split_desc(dict(a1=dz5, out=dz3, gate=y3, gate_act=ops.ACT_RELU), ops.split_bf16_planes_t(w5))
+    dzp = torch.empty((R, 64), device=dev)
+    ops.gemm_split_desc(dict(a1=dz3, out=dzp, gate=y, gate_act=ops.ACT_LEAKY, gate_slope=0.1, drop=dp),
+                        ops.split_bf16_planes_t(w3))
+    dVp = ops.affine_rows_bwd(C2, dzp, q)
+    dz1 = torch.empty((R, 64), device=dev)
+    ops.gemm_split_desc(dict(a1=dzp, out=dz1, gate=h2, gate_act=ops.ACT_RELU, drop=d2), ops.split_bf16_planes(wtp[64:]))
+    dV1 = ops.affine_rows_bwd(C3, dz1, q)
+    dhh = torch.empty((R, 64), device=dev)
+    ops.gemm_split_desc(dict(a1=dz1, out=dhh), ops.split_bf16_planes(wt1[:64]))
+    wc = torch.empty((64, 128), device=dev)                     # [in_h1][out of post_mp.0 | out of layer 1]
+    ops.copy2d_multi([(wtp[:64], wc[:, :64]), (wt1[64:], wc[:, 64:])])
+    dh1 = torch.empty((R, 64), device=dev)
+    ops.gemm_split_desc(dict(a1=dzp, a2=dz1, out=dh1), ops.split_bf16_planes(wc))
+    ops.add_rows(dh1, ops.gossip_gather(dhh, rowptr, col, n, q, g1c))
+    dsig = ops.gossip_gather(h1, rowptr, col, n, q, None)                       # d out / d g1
+    dg1 = ops.colsum(ops.rowdot2(dhh, dsig).view(n, q))
+    dz0 = ops.act_grad(dh1, h1, ops.ACT_RELU, 0.0, d1)
+    dV0 = ops.affine_rows_bwd(C6, dz0, q)
+    dw5t, db5 = torch.empty((64, 256), device=dev), torch.empty((256,), device=dev)
+    dw3t, db3 = torch.empty((64, 64), device=dev), torch.empty((64,), device=dev)
+    dwtp, dwt1 = torch.empty_like(wtp), torch.empty_like(wt1)
+    ops.linear_bwd_w_multi([dict(a1=y3, dz=dz5, dwt=dw5t, dbias=db5), dict(a1=y, dz=dz3, dwt=dw3t, dbias=db3),
+                            dict(a1=h1, a2=h2, dz=dzp, dwt=dwtp), dict(a1=hh, a2=h1, dz=dz1, dwt=dwt1)])
+    return (None, None, None, None, None, None, None, None, None, None, None, None, dV0, dg1, dwt1, dV1, dwtp, dVp,
+            dw3t, db3, dw5t, db5, dwb7[:256], dwb7[256:257])
+
+
+GossipTrunk._backward_x6 = staticmethod(_gossip_trunk_backward_x6)
 
 
 class Mlp(torch.autograd.Function):

@@ -46,6 +46,12 @@ struct GemmSplitArgs {
   const int32_t* pool_slot;
   const float* part[9];     // [1..8]: the layers' partial arrays [slots][64]
   const float* x0;          // [64]: the constant first block's row
+  // training backward (desco_gemm_bf16x6_desc_f32; desco_gemm_desc's meaning): c = v * dropout factor * act'(gate)
+  const float* gate;
+  int64_t ldg;
+  int gate_act;
+  float gate_slope;
+  DropArgs drop;
 };
 
 __device__ __attribute__((aligned(16))) float gs_zero_row[64] = {};
@@ -334,6 +340,18 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
       float wsv[4] = {0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
       const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
+      // registers 4q..4q+3 of a lane are four consecutive rows (aligned to 4) of one column: one Philox call per quad
+      float fac[16];
+      if (g.drop.key) {
+        const uint64_t seed = g.drop.key[0], step = g.drop.key[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t r4 = (grow0 + 8 * q + 4 * (lane >> 5)) >> 2;
+          const PhiloxOut o = dropout_bits4(g.drop, seed, step, (uint32_t)r4, (uint32_t)gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fac[4 * q + e] = o.w[e] < g.drop.threshold ? 0.f : g.drop.scale;
+        }
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -346,7 +364,13 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
             v += g.bias[(grow % g.bias_rows) * g.n + gcol];
         }
         for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
-        st[row * EW + 32 * j + col] = apply_act(v, g.act, g.slope);
+        v = apply_act(v, g.act, g.slope);
+        if (g.drop.key) v *= fac[reg];
+        if (g.gate) {
+          const float o_ = g.gate[grow * g.ldg + gcol];
+          v = o_ > 0.f ? v : (g.gate_act == DESCO_ACT_RELU ? 0.f : g.gate_act == DESCO_ACT_LEAKY ? v * g.gate_slope : v);
+        }
+        st[row * EW + 32 * j + col] = v;
       }
     }
     __syncthreads();
@@ -431,7 +455,9 @@ static int launch_gemm_split(const GemmSplitArgs& g, hipStream_t stream) {
 static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, int k1, const float* a2,
                        int64_t lda2, int k2, const int16_t* w, int n, const float* bias,
                        int bias_rows, const float* s, int ns, const float* ws, int act, float slope,
-                       float* c, int64_t ldc, int64_t m, desco_stream_t stream) {
+                       float* c, int64_t ldc, int64_t m, desco_stream_t stream, const float* gate = nullptr,
+                       int64_t ldg = 0, int gate_act = 0, float gate_slope = 0.f,
+                       desco::DropArgs drop = desco::DropArgs{nullptr, 0u, 0u, 1.f}) {
   using namespace desco;
   if (m == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
@@ -441,7 +467,8 @@ static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, i
       (k2 > 0 && mis16(a2)) || mis16(w))
     return fail(DESCO_EINVAL, who);
   GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w), n, bias,
-                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m, nullptr, nullptr, nullptr, {}, nullptr};
+                  bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m, nullptr, nullptr, nullptr, {}, nullptr,
+                  gate, ldg, gate_act, gate_slope, drop};
   hipStream_t st = (hipStream_t)stream;
   if (np == 3) {
     if (n % 192 == 0) return launch_gemm_split<3, 3>(g, st);
@@ -461,6 +488,46 @@ extern "C" int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, cons
   return gemm_planes("desco_gemm_bf16x6_f32: bad argument (k%32, n%64, 16-byte alignment)", 3, a1, lda1,
                      k1, a2, lda2, k2, w_planes, n, bias, bias_rows, s, ns, ws, act, slope, c, ldc, m,
                      stream);
+}
+
+// One descriptor of desco_gemm_f32_multi's form on the bf16x6 pipe (training: the gossip step's forward and input-gradient
+// products, with the activation-derivative gate and the dropout factor in the epilogue)
+extern "C" int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes, desco_stream_t stream) {
+  if (!d || !w_planes) return desco::fail(DESCO_EINVAL, "desco_gemm_bf16x6_desc_f32: null descriptor / planes");
+  if (d->accum || (d->gate && (d->ldg < d->n)))
+    return desco::fail(DESCO_EINVAL, "desco_gemm_bf16x6_desc_f32: accum is not supported; gate rows shorter than n");
+  const desco::DropArgs drop{d->drop.key, d->drop.site, d->drop.threshold, d->drop.scale};
+  return gemm_planes("desco_gemm_bf16x6_desc_f32: bad argument (k%32, n%64, 16-byte alignment)", 3, d->a1, d->lda1,
+                     d->k1, d->a2, d->lda2, d->k2, w_planes, d->n, d->bias, d->bias_rows, d->s, d->ns, d->ws, d->act,
+                     d->slope, d->c, d->ldc, d->m, stream, d->gate, d->ldg, d->gate_act, d->gate_slope, drop);
+}
+
+// planes[3][n][k] of the TRANSPOSE of w [k, n] (row stride ldw): the n-major operand of the bf16x6 products from a weight
+// kept as [in, out] (the training step's folded weights) or, for an input-gradient product, from torch's [out, in]
+__global__ __launch_bounds__(256) void split_bf16x3_t_kernel(const float* __restrict__ w, int k, int n, int64_t ldw,
+                                                             short* __restrict__ planes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // output index: row nn, column kk
+  const int64_t count = (int64_t)k * n;
+  if (i >= count) return;
+  const int nn = (int)(i / k), kk = (int)(i % k);
+  const float f = w[(int64_t)kk * ldw + nn];
+  const uint32_t uh = __float_as_uint(f) & 0xffff0000u;
+  const float r1 = f - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  planes[i] = (short)(uh >> 16);
+  planes[count + i] = (short)(um >> 16);
+  planes[2 * count + i] = (short)(__float_as_uint(r2) >> 16);
+}
+
+extern "C" int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ldw, int16_t* planes,
+                                        desco_stream_t stream) {
+  if (!w || !planes || k <= 0 || n <= 0 || ldw < n)
+    return desco::fail(DESCO_EINVAL, "desco_split_bf16x3_t_f32: bad argument");
+  const int64_t count = (int64_t)k * n;
+  hipLaunchKernelGGL(split_bf16x3_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     k, n, ldw, reinterpret_cast<short*>(planes));
+  return desco::launch_status("desco_split_bf16x3_t_f32");
 }
 
 // post_mp.0 on the pooled embeddings WITHOUT materialising them (round 6): pooled[b] = anchor row + the fused pooling's

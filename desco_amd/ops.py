@@ -270,6 +270,53 @@ def gemm_multi(problems) -> None:
         _lib.check(L.desco_gemm_f32_multi(len(problems), descs, _stream()), "gemm_multi")
 
 
+def split_bf16_planes_t(wt: torch.Tensor) -> torch.Tensor:
+    """[3, n, k] int16 planes of ``wt.t()`` for a [k, n] matrix with unit inner stride (rows may be strided): the n-major
+    operand of ``gemm_split`` / ``gemm_split_desc`` from a weight kept as [in, out] (desco_split_bf16x3_t_f32)."""
+    k, n = wt.shape
+    planes = torch.empty((3, n, k), device=wt.device, dtype=torch.int16)
+    wp, ldw = _rows(wt, "wt")
+    _lib.check(_lib.lib().desco_split_bf16x3_t_f32(wp, k, n, ldw, _dev(planes, "planes", torch.int16), _stream()),
+               "split_bf16x3_t")
+    return planes
+
+
+def gemm_split_desc(pr: dict, planes: torch.Tensor) -> None:
+    """One ``gemm_multi`` problem (dict: a1, a2, bias, act, slope, out, gate / gate_act / gate_slope, drop -- no accum)
+    on the bf16x6 pipe (desco_gemm_bf16x6_desc_f32); ``planes`` [3, n, k1 + k2] = the n-major split weight."""
+    a1, out, a2, bias = pr["a1"], pr["out"], pr.get("a2"), pr.get("bias")
+    m, k1 = a1.shape
+    k2 = 0 if a2 is None else a2.shape[1]
+    n = planes.shape[1]
+    assert tuple(planes.shape) == (3, n, k1 + k2) and planes.is_contiguous() and tuple(out.shape) == (m, n)
+    assert not pr.get("accum", False)
+    if m == 0:
+        return
+    d = _lib.GemmDesc()
+    d.m = m
+    d.a1, d.lda1 = _rows(a1, "a1")
+    d.k1, d.k2 = k1, k2
+    if a2 is not None:
+        d.a2, d.lda2 = _rows(a2, "a2")
+    d.n = n
+    if bias is not None:
+        assert bias.is_contiguous() and bias.dim() == 1
+        d.bias, d.bias_rows = _dev(bias, "bias"), 1
+    d.act, d.slope = pr.get("act", ACT_NONE), pr.get("slope", 0.0)
+    d.c, d.ldc = _rows(out, "out")
+    gate = pr.get("gate")
+    if gate is not None:
+        assert tuple(gate.shape) == (m, n)
+        d.gate, d.ldg = _rows(gate, "gate")
+        d.gate_act, d.gate_slope = pr["gate_act"], pr.get("gate_slope", 0.0)
+    drop = pr.get("drop")
+    if drop is not None:
+        d.drop = drop.desc()
+    with _Timed("gemm_split_kernel", 2.0 * m * (k1 + k2) * n, 4.0 * (m * (k1 + k2) + m * n * (2 if gate is not None else 1))):
+        _lib.check(_lib.lib().desco_gemm_bf16x6_desc_f32(ctypes.byref(d), _dev(planes, "planes", torch.int16), _stream()),
+                   "gemm_split_desc")
+
+
 def linear_bwd_w_multi(problems) -> None:
     """Up to 16 independent ``linear_bwd_w`` problems in two launches (desco_linear_bwd_w_multi_f32).  ``problems``:
     dicts a1, a2 (or None), dz, dwt (contiguous [(k1+k2), n]), dbias ([n] or None)."""
