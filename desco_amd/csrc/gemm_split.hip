@@ -504,6 +504,7 @@ extern "C" int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_
 
 // planes[3][n][k] of the TRANSPOSE of w [k, n] (row stride ldw): the n-major operand of the bf16x6 products from a weight
 // kept as [in, out] (the training step's folded weights) or, for an input-gradient product, from torch's [out, in]
+namespace desco {
 __global__ __launch_bounds__(256) void split_bf16x3_t_kernel(const float* __restrict__ w, int k, int n, int64_t ldw,
                                                              short* __restrict__ planes) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // output index: row nn, column kk
@@ -519,13 +520,14 @@ __global__ __launch_bounds__(256) void split_bf16x3_t_kernel(const float* __rest
   planes[count + i] = (short)(um >> 16);
   planes[2 * count + i] = (short)(__float_as_uint(r2) >> 16);
 }
+}  // namespace desco
 
 extern "C" int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ldw, int16_t* planes,
                                         desco_stream_t stream) {
   if (!w || !planes || k <= 0 || n <= 0 || ldw < n)
     return desco::fail(DESCO_EINVAL, "desco_split_bf16x3_t_f32: bad argument");
   const int64_t count = (int64_t)k * n;
-  hipLaunchKernelGGL(split_bf16x3_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+  hipLaunchKernelGGL(desco::split_bf16x3_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                      k, n, ldw, reinterpret_cast<short*>(planes));
   return desco::launch_status("desco_split_bf16x3_t_f32");
 }

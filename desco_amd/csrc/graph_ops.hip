@@ -870,6 +870,7 @@ extern "C" int desco_rowdot_add_f32(const float* y, int64_t ldy, int ncols, cons
 // pooling of the SHMP layer kernel: same pool_bits / pool_slot index, same partial-sum format, so the layer joins the
 // others in pool_reduce): a wave computes and stores the tile's rows one column per lane and runs the layer kernel's
 // running sum down the rows in row order (wave-uniform control flow).
+namespace desco {
 template <int CS>      // CS = the slot count as a constant (lane selects of the v_readlane are then immediates), or 0
 __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* __restrict__ vrowptr, int64_t num_rows,
                                                                  int S_, const float* __restrict__ coef, int act,
@@ -920,6 +921,7 @@ __global__ __launch_bounds__(256) void degree_affine_pool_kernel(const int32_t* 
     if (nr > 0 && !((E >> (nr - 1)) & 1u)) pp[(int64_t)slot * 64] = run;
   }
 }
+}  // namespace desco
 
 extern "C" int desco_degree_affine_pool_f32(const int32_t* vrowptr, int64_t num_rows, int slots, const float* coef,
                                             int act, float slope, float* out, int64_t ldo, const uint32_t* pool_bits,

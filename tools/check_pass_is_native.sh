@@ -28,8 +28,13 @@ out = sys.argv[1]
 def counts(k):
     f = glob.glob(f"{out}/s{k}/**/*kernel_stats.csv", recursive=True)
     assert f, f"no kernel stats for --steps {k}"
-    return {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(f[0]))}
-a, b = counts(2), counts(6)
+    return [{r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(p))} for p in f]
+# (--train-only also starts the world-of-one nccl child, which runs the same steps whatever --train-epochs says: one trace
+#  per process -- a process with the SAME table in both runs is that child, the bench process is what remains)
+ta, tb = counts(2), counts(6)
+same = [t for t in ta if t in tb]
+ta, tb = [t for t in ta if t not in same] or ta, [t for t in tb if t not in same] or tb
+a, b = max(ta, key=lambda t: sum(t.values())), max(tb, key=lambda t: sum(t.values()))
 ours = lambda n: "desco" in n
 grow = {n: (a.get(n, 0), c) for n, c in b.items() if c != a.get(n, 0)}
 foreign_in_pass = {n: v for n, v in grow.items() if not ours(n)}
