@@ -456,8 +456,13 @@ class GossipTrunk(torch.autograd.Function):
         x6 = TRAIN_GEMM_BF16X6 and PRECISION == "fp32"
         if x6:
             w3, w5 = w3.contiguous(), w5.contiguous()
-            h2 = ops.affine_rows(ops.gemm_split(hh, ops.split_bf16_planes_t(wt1), a2=h1), C3, V1, ops.ACT_RELU, 0.0, d2)
-            y = ops.affine_rows(ops.gemm_split(h1, ops.split_bf16_planes_t(wtp), a2=h2), C2, Vp, ops.ACT_LEAKY, 0.1, dp)
+            # (the per-query affine terms of the layer and of post_mp.0 -- affine_rows -- ride in the products' epilogues)
+            h2 = torch.empty_like(h1)
+            ops.gemm_split_desc(dict(a1=hh, a2=h1, out=h2, act=ops.ACT_RELU, s=C3, ws=V1, drop=d2),
+                                ops.split_bf16_planes_t(wt1))
+            y = torch.empty_like(h1)
+            ops.gemm_split_desc(dict(a1=h1, a2=h2, out=y, act=ops.ACT_LEAKY, slope=0.1, s=C2, ws=Vp, drop=dp),
+                                ops.split_bf16_planes_t(wtp))
             y3 = ops.gemm_split(y, ops.split_bf16_planes(w3), b3, act=ops.ACT_RELU)
             y5 = ops.gemm_split(y3, ops.split_bf16_planes(w5), b5, act=ops.ACT_RELU)
         else:

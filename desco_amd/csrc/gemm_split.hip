@@ -52,6 +52,8 @@ struct GemmSplitArgs {
   int gate_act;
   float gate_slope;
   DropArgs drop;
+  int ws_rows;              // > 1: the scalar tail's matrix is per row class, ws[row % ws_rows][ns][n] (the gossip step's
+                            // per-query tables: desco_affine_rows_f32 fused into the product's epilogue)
 };
 
 __device__ __attribute__((aligned(16))) float gs_zero_row[64] = {};
@@ -334,11 +336,16 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int64_t grow0 = m0 + wr * 64 + 32 * i;
+    // row class of this lane's first row (ws_rows > 1): its other 15 rows are 1..27 rows further on -- one division per
+    // lane and half tile, then add and wrap
+    const uint32_t wsr = g.ws_rows > 1 ? (uint32_t)g.ws_rows : 1u;
+    const uint32_t qbase = g.ws_rows > 1 ? (uint32_t)(grow0 + 4 * (lane >> 5)) % wsr : 0u;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int gcol = n0 + wc * EW + 32 * j + col;
       float wsv[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
+      if (g.ws_rows <= 1)
+        for (int q = 0; q < g.ns; ++q) wsv[q] = g.ws[(int64_t)q * g.n + gcol];
       const float b_single = (g.bias && g.bias_rows == 1) ? g.bias[gcol] : 0.f;
       // registers 4q..4q+3 of a lane are four consecutive rows (aligned to 4) of one column: one Philox call per quad
       float fac[16];
@@ -363,7 +370,14 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
           else
             v += g.bias[(grow % g.bias_rows) * g.n + gcol];
         }
-        for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
+        if (g.ws_rows > 1) {
+          uint32_t qc_ = qbase + (uint32_t)((reg & 3) + 8 * (reg >> 2));
+          while (qc_ >= wsr) qc_ -= wsr;
+          const float* wr_ = g.ws + (int64_t)qc_ * g.ns * g.n + gcol;
+          for (int q = 0; q < g.ns; ++q) v = fmaf(g.s[grow * g.ns + q], wr_[(int64_t)q * g.n], v);
+        } else {
+          for (int q = 0; q < g.ns; ++q) v += g.s[grow * g.ns + q] * wsv[q];
+        }
         v = apply_act(v, g.act, g.slope);
         if (g.drop.key) v *= fac[reg];
         if (g.gate) {
@@ -457,7 +471,7 @@ static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, i
                        int bias_rows, const float* s, int ns, const float* ws, int act, float slope,
                        float* c, int64_t ldc, int64_t m, desco_stream_t stream, const float* gate = nullptr,
                        int64_t ldg = 0, int gate_act = 0, float gate_slope = 0.f,
-                       desco::DropArgs drop = desco::DropArgs{nullptr, 0u, 0u, 1.f}) {
+                       desco::DropArgs drop = desco::DropArgs{nullptr, 0u, 0u, 1.f}, int ws_rows = 1) {
   using namespace desco;
   if (m == 0) return 0;
   auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
@@ -468,7 +482,7 @@ static int gemm_planes(const char* who, int np, const float* a1, int64_t lda1, i
     return fail(DESCO_EINVAL, who);
   GemmSplitArgs g{a1, lda1, k1, a2, lda2, k2, reinterpret_cast<const short*>(w), n, bias,
                   bias ? bias_rows : 1, s, ns, ws, act, slope, c, ldc, m, nullptr, nullptr, nullptr, {}, nullptr,
-                  gate, ldg, gate_act, gate_slope, drop};
+                  gate, ldg, gate_act, gate_slope, drop, ws_rows};
   hipStream_t st = (hipStream_t)stream;
   if (np == 3) {
     if (n % 192 == 0) return launch_gemm_split<3, 3>(g, st);
@@ -492,14 +506,16 @@ extern "C" int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, cons
 
 // One descriptor of desco_gemm_f32_multi's form on the bf16x6 pipe (training: the gossip step's forward and input-gradient
 // products, with the activation-derivative gate and the dropout factor in the epilogue)
-extern "C" int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes, desco_stream_t stream) {
+extern "C" int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes, int ws_rows,
+                                          desco_stream_t stream) {
   if (!d || !w_planes) return desco::fail(DESCO_EINVAL, "desco_gemm_bf16x6_desc_f32: null descriptor / planes");
-  if (d->accum || (d->gate && (d->ldg < d->n)))
-    return desco::fail(DESCO_EINVAL, "desco_gemm_bf16x6_desc_f32: accum is not supported; gate rows shorter than n");
+  if (d->accum || (d->gate && (d->ldg < d->n)) || ws_rows < 1 || d->m >= ((int64_t)1 << 31))
+    return desco::fail(DESCO_EINVAL, "desco_gemm_bf16x6_desc_f32: accum is not supported; gate rows shorter than n; "
+                                     "ws_rows >= 1; m < 2^31");
   const desco::DropArgs drop{d->drop.key, d->drop.site, d->drop.threshold, d->drop.scale};
   return gemm_planes("desco_gemm_bf16x6_desc_f32: bad argument (k%32, n%64, 16-byte alignment)", 3, d->a1, d->lda1,
                      d->k1, d->a2, d->lda2, d->k2, w_planes, d->n, d->bias, d->bias_rows, d->s, d->ns, d->ws, d->act,
-                     d->slope, d->c, d->ldc, d->m, stream, d->gate, d->ldg, d->gate_act, d->gate_slope, drop);
+                     d->slope, d->c, d->ldc, d->m, stream, d->gate, d->ldg, d->gate_act, d->gate_slope, drop, ws_rows);
 }
 
 // planes[3][n][k] of the TRANSPOSE of w [k, n] (row stride ldw): the n-major operand of the bf16x6 products from a weight

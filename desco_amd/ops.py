@@ -283,7 +283,9 @@ def split_bf16_planes_t(wt: torch.Tensor) -> torch.Tensor:
 
 def gemm_split_desc(pr: dict, planes: torch.Tensor) -> None:
     """One ``gemm_multi`` problem (dict: a1, a2, bias, act, slope, out, gate / gate_act / gate_slope, drop -- no accum)
-    on the bf16x6 pipe (desco_gemm_bf16x6_desc_f32); ``planes`` [3, n, k1 + k2] = the n-major split weight."""
+    on the bf16x6 pipe (desco_gemm_bf16x6_desc_f32); ``planes`` [3, n, k1 + k2] = the n-major split weight.
+    ``s`` [m, ns] with ``ws`` [QV, ns, n]: out = act(product + bias + sum_j s[r, j] ws[r % QV, j, :]) -- ``affine_rows`` on
+    the product, in its epilogue."""
     a1, out, a2, bias = pr["a1"], pr["out"], pr.get("a2"), pr.get("bias")
     m, k1 = a1.shape
     k2 = 0 if a2 is None else a2.shape[1]
@@ -312,9 +314,16 @@ def gemm_split_desc(pr: dict, planes: torch.Tensor) -> None:
     drop = pr.get("drop")
     if drop is not None:
         d.drop = drop.desc()
+    ws_rows = 1
+    sc, ws = pr.get("s"), pr.get("ws")
+    if sc is not None:
+        ws_rows, ns = ws.shape[0], ws.shape[1]
+        assert tuple(sc.shape) == (m, ns) and sc.is_contiguous() and tuple(ws.shape) == (ws_rows, ns, n) and ns <= 4
+        ws = ws.contiguous()
+        d.s, d.ns, d.ws = _dev(sc, "s"), ns, _dev(ws, "ws")
     with _Timed("gemm_split_kernel", 2.0 * m * (k1 + k2) * n, 4.0 * (m * (k1 + k2) + m * n * (2 if gate is not None else 1))):
-        _lib.check(_lib.lib().desco_gemm_bf16x6_desc_f32(ctypes.byref(d), _dev(planes, "planes", torch.int16), _stream()),
-                   "gemm_split_desc")
+        _lib.check(_lib.lib().desco_gemm_bf16x6_desc_f32(ctypes.byref(d), _dev(planes, "planes", torch.int16), ws_rows,
+                                                         _stream()), "gemm_split_desc")
 
 
 def linear_bwd_w_multi(problems) -> None:

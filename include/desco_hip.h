@@ -228,9 +228,11 @@ int desco_gemm_bf16x6_f32(const float* a1, int64_t lda1, int k1, const float* a2
 int desco_split_bf16x3_f32(const float* w, int64_t count, int16_t* planes, desco_stream_t stream);
 /* One descriptor of desco_gemm_f32_multi's form on the bf16x6 pipe: d->wt is ignored, the weight is w_planes[3][n][k1+k2]
  * (n-major, as for desco_gemm_bf16x6_f32); bias / act / gate / drop as documented for desco_gemm_desc, accum must be 0.
+ * ws_rows > 1: the scalar tail's matrix is per row class -- v += sum_j s[row, j] * ws[row % ws_rows][j][col] -- which is
+ * desco_affine_rows_f32 (the gossip layers' per-query tables, ws_rows = the query count) fused into the epilogue.
  * For the training step's products that stream a million rows through a 64- to 256-wide weight (the gossip step's
  * forward and input-gradient products): fp32-accurate at the HBM rate instead of the fp32 matrix pipe's. */
-int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes, desco_stream_t stream);
+int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes, int ws_rows, desco_stream_t stream);
 /* planes[3][n][k] of the TRANSPOSE of w [k, n] (row stride ldw >= n): the n-major planes of a weight kept as [in, out], or
  * -- for an input-gradient product dA = dZ W -- of torch's [out, in] weight read as [k = out, n = in]. */
 int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ldw, int16_t* planes, desco_stream_t stream);
