@@ -882,6 +882,41 @@ def test_gemm_multi_with_gate_and_accumulate():
     _close(o2, prev.double() + (a2.double() @ w2.double()) * torch.where(gate_l.double() > 0, 1.0, 0.1), atol=1e-4)
 
 
+def test_gemm_split_desc_gate_dropout_and_row_class_tail():
+    """desco_gemm_bf16x6_desc_f32 (the gossip training step's products): the transposing plane split, the backward
+    epilogue (dropout factor regenerated from the key, activation-derivative gate on the saved output) against the
+    exact-fp32 gemm_multi with the same descriptor, and the per-row-class scalar tail against affine_rows on the product."""
+    g = torch.Generator().manual_seed(21)
+    m, k1, k2, n, Q = 3001, 64, 64, 64, 29
+    a1, a2 = torch.randn(m, k1, generator=g).to(DEV), torch.randn(m, k2, generator=g).to(DEV)
+    wt = (torch.randn(k1 + k2, n, generator=g) / 11).to(DEV)                  # [in, out]
+    assert torch.equal(ops.split_bf16_planes_t(wt), ops.split_bf16_planes(wt.t().contiguous()))
+    assert torch.equal(ops.split_bf16_planes_t(wt[:64]), ops.split_bf16_planes(wt[:64].t().contiguous()))
+    planes = ops.split_bf16_planes_t(wt)
+    gate = torch.randn(m, n, generator=g).to(DEV)
+    key = ops.rng_next(DEV)
+    drop = ops.DropSite(key, 5, 0.3)
+    for kw in (dict(), dict(gate=gate, gate_act=ops.ACT_RELU), dict(gate=gate, gate_act=ops.ACT_LEAKY, gate_slope=0.1, drop=drop),
+               dict(act=ops.ACT_RELU, drop=drop)):
+        want, got = torch.empty(m, n, device=DEV), torch.empty(m, n, device=DEV)
+        ops.gemm_multi([dict(a1=a1, a2=a2, wt=wt, out=want, **kw)])
+        ops.gemm_split_desc(dict(a1=a1, a2=a2, out=got, **kw), planes)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-6 * scale, kw.keys()
+        assert torch.equal(got == 0, want == 0) or "drop" not in kw           # the same elements are dropped / gated out
+    # scalar tail per row class == affine_rows(product)
+    c = torch.randn(m, 3, generator=g).to(DEV)
+    v = torch.randn(Q, 3, n, generator=g).to(DEV)
+    base = ops.gemm_split(a1, planes, a2=a2)
+    for act, slope, d in ((ops.ACT_RELU, 0.0, None), (ops.ACT_LEAKY, 0.1, drop)):
+        want = ops.affine_rows(base, c, v, act, slope, d)
+        got = torch.empty(m, n, device=DEV)
+        ops.gemm_split_desc(dict(a1=a1, a2=a2, out=got, act=act, slope=slope, s=c, ws=v, drop=d), planes)
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    with pytest.raises(Exception):
+        ops.gemm_split_desc(dict(a1=a1, a2=a2, out=got, accum=True), planes)
+
+
 def test_linear_bwd_w_multi_matches_the_single_problem_form():
     g = torch.Generator().manual_seed(8)
     probs, refs = [], []
