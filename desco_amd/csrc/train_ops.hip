@@ -115,26 +115,38 @@ __device__ __forceinline__ void linear_bwd_w_partial_tile(
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int srow = tid >> 4, sc4 = tid & 15;
-  for (int64_t m0 = m_beg; m0 < m_end; m0 += TMC) {
-    float4 va0, va1, vb0, vb1;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t ra = m0 + srow, rb = m0 + srow + 16;
-    va0 = ra < m_end ? *reinterpret_cast<const float4*>(a + ra * lda + 4 * sc4) : zero;
-    va1 = rb < m_end ? *reinterpret_cast<const float4*>(a + rb * lda + 4 * sc4) : zero;
-    vb0 = ra < m_end ? *reinterpret_cast<const float4*>(b + ra * ldb + n0 + 4 * sc4) : zero;
-    vb1 = rb < m_end ? *reinterpret_cast<const float4*>(b + rb * ldb + n0 + 4 * sc4) : zero;
-    __syncthreads();   // previous chunk consumed
-    *reinterpret_cast<float4*>(As + srow * 64 + 4 * sc4) = va0;
-    *reinterpret_cast<float4*>(As + (srow + 16) * 64 + 4 * sc4) = va1;
-    *reinterpret_cast<float4*>(Bs + srow * 64 + 4 * sc4) = vb0;
-    *reinterpret_cast<float4*>(Bs + (srow + 16) * 64 + 4 * sc4) = vb1;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 va0, va1, vb0, vb1;
+  // the next chunk's rows travel under this chunk's MFMAs (round 6: they used to be requested at the top of their own
+  // iteration, a full memory round trip in front of every 16 MFMAs)
+#define DESCO_BWDW_LOAD(m0_)                                                                          \
+  {                                                                                                   \
+    const int64_t ra_ = (m0_) + srow, rb_ = (m0_) + srow + 16;                                        \
+    va0 = ra_ < m_end ? *reinterpret_cast<const float4*>(a + ra_ * lda + 4 * sc4) : zero;             \
+    va1 = rb_ < m_end ? *reinterpret_cast<const float4*>(a + rb_ * lda + 4 * sc4) : zero;            \
+    vb0 = ra_ < m_end ? *reinterpret_cast<const float4*>(b + ra_ * ldb + n0 + 4 * sc4) : zero;        \
+    vb1 = rb_ < m_end ? *reinterpret_cast<const float4*>(b + rb_ * ldb + n0 + 4 * sc4) : zero;        \
+  }
+  DESCO_BWDW_LOAD(m_beg)
+  int buf = 0;
+  for (int64_t m0 = m_beg; m0 < m_end; m0 += TMC, buf ^= 1) {
+    // two chunk images: a wave that stores chunk i + 1 has passed the barrier of chunk i, which every wave reaches only
+    // after its MFMAs on chunk i - 1 (the image being overwritten) -- one barrier per chunk
+    float* Ac = As + buf * (2 * TMC * 64);
+    float* Bc = Bs + buf * (2 * TMC * 64);
+    *reinterpret_cast<float4*>(Ac + srow * 64 + 4 * sc4) = va0;
+    *reinterpret_cast<float4*>(Ac + (srow + 16) * 64 + 4 * sc4) = va1;
+    *reinterpret_cast<float4*>(Bc + srow * 64 + 4 * sc4) = vb0;
+    *reinterpret_cast<float4*>(Bc + (srow + 16) * 64 + 4 * sc4) = vb1;
     __syncthreads();
-    const float* as = As + (lane >> 5) * 64 + wr * 32 + (lane & 31);
-    const float* bs = Bs + (lane >> 5) * 64 + wc * 32 + (lane & 31);
+    if (m0 + TMC < m_end) DESCO_BWDW_LOAD(m0 + TMC)
+    const float* as = Ac + (lane >> 5) * 64 + wr * 32 + (lane & 31);
+    const float* bs = Bc + (lane >> 5) * 64 + wc * 32 + (lane & 31);
 #pragma unroll
     for (int mm = 0; mm < TMC / 2; ++mm)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * mm * 64], bs[2 * mm * 64], acc, 0, 0, 0);
   }
+#undef DESCO_BWDW_LOAD
   float* out = direct_dwt ? direct_dwt + (int64_t)k0 * lddw + n0 : partial + ((int64_t)bz * rows + k0) * N + n0;
   const int64_t ldout = direct_dwt ? lddw : N;
   const int col = wc * 32 + (lane & 31);
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
     const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
     float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias) {
-  __shared__ float lds[2 * TMC * 64];
+  __shared__ float lds[4 * TMC * 64];          // (two chunk images: one barrier per chunk)
   linear_bwd_w_partial_tile(lds, blockIdx.x, blockIdx.y, blockIdx.z, a1, lda1, k1, a2, lda2, b, ldb, M, K, N, slab,
                             partial, direct_dwt, lddw, direct_dbias);
 }
@@ -173,7 +185,7 @@ struct BwdWMulti {
 };
 
 __global__ __launch_bounds__(256) void linear_bwd_w_multi_partial_kernel(const BwdWMulti q, float* __restrict__ ws) {
-  __shared__ float lds[2 * TMC * 64];
+  __shared__ float lds[4 * TMC * 64];          // (two chunk images: one barrier per chunk)
   int b = blockIdx.x, i = 0;
   while (i < q.num - 1 && b >= q.blk_end[i]) ++i;
   b -= i ? q.blk_end[i - 1] : 0;
