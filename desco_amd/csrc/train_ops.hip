@@ -75,8 +75,11 @@ __device__ __forceinline__ void linear_bwd_w_partial_tile(
     float* lds, const int bx, const int by, const int bz,
     const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ a2, int64_t lda2,
     const float* __restrict__ b, int64_t ldb, int64_t M, int K, int N, int64_t slab,
-    float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias) {
+    float* __restrict__ partial, float* __restrict__ direct_dwt, int64_t lddw, float* __restrict__ direct_dbias,
+    const bool want_bias = true) {
   // direct_dwt != NULL (one slab): the block's tile IS the result -- written to dwt / dbias, no reduce launch
+  // want_bias == false: nobody reads the bias row (the reduce discards it) -- its workgroups leave without reading dZ
+  if (!want_bias && bx * TK >= K) return;
   float* As = lds;              // [32 m][64 k]
   float* Bs = lds + TMC * 64;   // [32 m][64 n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_multi_partial_kernel(const B
   const bool direct = q.splits[i] == 1;
   linear_bwd_w_partial_tile(lds, bx, by, bz, q.a1[i], q.lda1[i], q.k1[i], q.a2[i], q.lda2[i], q.dz[i], q.lddz[i],
                             q.m[i], q.k[i], q.n[i], q.slab[i], ws + q.ws_off[i], direct ? q.dwt[i] : nullptr,
-                            (int64_t)q.n[i], direct ? q.dbias[i] : nullptr);
+                            (int64_t)q.n[i], direct ? q.dbias[i] : nullptr, q.dbias[i] != nullptr);
 }
 
 __global__ __launch_bounds__(256) void linear_bwd_w_multi_reduce_kernel(const BwdWMulti q, const float* __restrict__ ws) {
