@@ -381,3 +381,39 @@ def test_stacked_weight_folding_equals_the_per_layer_folding(use_tconv):
             for l in range(gnn.gnn_core.layer_num):
                 torch.testing.assert_close(Wt[l], pk["layers"][l][t]["wt"], rtol=1e-6, atol=1e-6)
                 torch.testing.assert_close(fb[l], pk["layers"][l][t]["b"], rtol=1e-6, atol=1e-6)
+
+
+def test_degree_table_index_is_a_faithful_remap_of_the_count_rows():
+    """NeighborhoodBatch.degree_table_index (round 6, gnn_model.FIRST_LAYER_TABLE): the count rows' slot-degree tuples as
+    an index into their distinct tuples.  On a real partition: the table's tuples are distinct, row_id maps every count
+    row to ITS tuple, the remapped column ids of the two count-row slots address the table row of the ORIGINAL source
+    (so that gathering T[vcol_t] equals gathering X_1[vcol] for any X_1 = T[row_id]) and the canonical slots keep their
+    ids; too many distinct tuples -> None."""
+    import torch
+    from desco_amd.batch import NeighborhoodBatch
+    part = _golden_partition()
+    nb = NeighborhoodBatch.__new__(NeighborhoodBatch)
+    nb.part, nb.device = part, torch.device("cpu")
+    nb.slots, nb.num_count, nb.num_rows = 4, part.num_count, part.num_rows
+    nb.vrowptr = torch.from_numpy(np.asarray(part.vrowptr, dtype=np.int32))
+    nb.vcol = torch.from_numpy(np.asarray(part.vcol, dtype=np.int32))
+    idx = nb.degree_table_index()
+    assert idx is not None
+    uptr, row_id, vcol_t = (t.numpy().astype(np.int64) for t in idx)
+    S, nc, n = 4, part.num_count, part.num_rows
+    vr = np.asarray(part.vrowptr, dtype=np.int64)
+    deg = np.diff(vr).reshape(n, S)
+    ut = np.diff(uptr).reshape(-1, S)
+    assert len(np.unique(ut, axis=0)) == len(ut) and len(ut) < nc
+    assert (ut[row_id] == deg[:nc]).all()
+    # any X_1 that is a function of the tuple: gathers through the table equal gathers through the rows
+    T = np.random.default_rng(0).standard_normal((len(ut), 3))
+    X1 = T[row_id]
+    vcol = np.asarray(part.vcol, dtype=np.int64)
+    slot_of = np.repeat(np.arange(n * S) % S, deg.reshape(-1))
+    low = slot_of < 2
+    assert (vcol[low] < nc).all() and (vcol_t[~low] == vcol[~low]).all()
+    assert np.array_equal(T[vcol_t[low]], X1[vcol[low]])
+    nb2 = NeighborhoodBatch.__new__(NeighborhoodBatch)
+    nb2.__dict__.update({k: v for k, v in nb.__dict__.items() if k != "_degree_table"})
+    assert nb2.degree_table_index(max_rows=2) is None
