@@ -157,10 +157,20 @@ class ShmpTrunk(torch.autograd.Function):
         P = H * (num_layers + 1)
         X, AGG = [x0.contiguous()], []
         xall = torch.empty((num_layers, N, H), device=dev)        # X_1 .. X_L in one buffer (pooled in one launch)
+        # fp32 mode: the layers' products on the bf16x6 pipe (fp32-accurate; 38 -> 26 us per product on a real-size
+        # batch): the stacked weights' n-major planes for all layers in one launch per row type
+        x6 = TRAIN_GEMM_BF16X6 and PRECISION == "fp32" and len(groups) > 1
+        planes_f = [ops.split_bf16_planes_batch(w_, True) for w_ in Wt] if x6 else None      # [L, 3, 64, K_g]
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
             xn = xall[l]
-            if drop is not None or (PRECISION == "fp32" and len(groups) > 1):
+            if x6:
+                ops.gemm_split_multi([dict(a1=agg[r0:r1, :su * H], a2=X[-1][r0:r1], bias=Bs[g][l], act=ops.ACT_RELU,
+                                           out=xn[r0:r1],
+                                           drop=None if drop is None else ops.DropSite(drop[0], 2 * l + g, drop[1]))
+                                      for g, (t, r0, r1, su) in enumerate(groups)],
+                                     [planes_f[g][l] for g in range(len(groups))])
+            elif drop is not None or (PRECISION == "fp32" and len(groups) > 1):
                 # the row types' products of one layer are independent: one launch (desco_gemm_f32_multi)
                 ops.gemm_multi([dict(a1=agg[r0:r1, :su * H], a2=X[-1][r0:r1], wt=Wt[g][l], bias=Bs[g][l],
                                      act=ops.ACT_RELU, out=xn[r0:r1],
@@ -183,6 +193,7 @@ class ShmpTrunk(torch.autograd.Function):
         ctx.batch, ctx.groups, ctx.has_anchor = batch, groups, has_anchor
         ctx.mask_scale = 1.0 if drop is None else ops.DropSite(drop[0], 0, drop[1]).scale
         ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
+        ctx.x6 = x6
         ctx.save_for_backward(*w)
         return pooled
 
@@ -239,8 +250,11 @@ class ShmpTrunk(torch.autograd.Function):
         D = torch.empty((N, (S + 1) * H), device=dev)
         fp32 = PRECISION == "fp32"
         # transposed weights of all layers in one copy per row type (dA = dZ Wt^T wants the n-major operand)
-        WtT = None
-        if fp32:
+        WtT = planes_b = None
+        if ctx.x6:
+            # dA = dZ Wt^T on the bf16x6 pipe: its n-major operand [n = in][k = out] is Wt as stored -- no transposes
+            planes_b = [ops.split_bf16_planes_batch(w_, False) for w_ in Wt]                 # [L, 3, K_g, 64]
+        elif fp32:
             WtT = [torch.empty((L, w_.shape[2], w_.shape[1]), device=dev) for w_ in Wt]
             ops.copy2d_multi([(w_[l], t_[l], True) for w_, t_ in zip(Wt, WtT) for l in range(L)])
         wgrad = []                     # the weight / bias gradients feed nothing but the optimizer: formed together,
@@ -249,7 +263,10 @@ class ShmpTrunk(torch.autograd.Function):
             for g, r0, r1, su in live:
                 wgrad.append(dict(a1=AGG[l][r0:r1, :su * H], a2=X[l][r0:r1], dz=dz[r0:r1], dwt=grads[k + 2 * g][l],
                                   dbias=grads[k + 2 * g + 1][l]))
-            if fp32 and len(groups) > 1:
+            if ctx.x6:
+                ops.gemm_split_multi([dict(a1=dz[r0:r1], out=D[r0:r1, :(su + 1) * H]) for g, r0, r1, su in live],
+                                     [planes_b[g][l] for g, r0, r1, su in live])
+            elif fp32 and len(groups) > 1:
                 ops.gemm_multi([dict(a1=dz[r0:r1], wt=WtT[g][l], out=D[r0:r1, :(su + 1) * H]) for g, r0, r1, su in live])
             else:
                 for g, r0, r1, su in live:

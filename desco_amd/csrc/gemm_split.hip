@@ -74,8 +74,10 @@ __device__ __forceinline__ int gs_chunk(const int row, const int c) { return ((c
 // BM = rows per block tile (128: 4 waves, two blocks per CU).  The A chunk AFTER the next one is kept
 // in flight too: one chunk of MFMAs (2 304 cycles) does not cover an HBM round trip under load, two do
 // (144 -> 156 TF/s fp32-equivalent on the 576^2 anchor GEMM).
+// (the kernel's body: one block tile of problem g; `id` = the block's index among the problem's blocks, a multiple of 8
+//  blocks per problem so that id & 7 is the XCD the hardware dispatched the block to)
 template <int WN, int NP, int BM, bool POOLA = false>
-__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
+__device__ __forceinline__ void gemm_split_body(const GemmSplitArgs& g, const int64_t gm, const int ny, const int64_t id) {
   constexpr int NT = 2 * BM;                   // threads
   constexpr int BN = 64 * WN, BPLANE = BN * SST, APLANE = BM * SST;
   constexpr int AR = BM / 4;                   // A staging: row step between a thread's 4 rows
@@ -87,7 +89,6 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
 
   // block id -> (m tile, n tile): ids id, id+8, id+16, ... share an XCD (round-robin dispatch);
   // within an XCD the n tile runs fastest so an A row panel is fetched from HBM once per XCD.
-  const int64_t id = blockIdx.x;
   const int64_t local = id >> 3;
   const int64_t mt = (local / ny) * 8 + (id & 7);
   if (mt >= gm) return;
@@ -411,6 +412,40 @@ __global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) voi
   }
 }
 
+template <int WN, int NP, int BM, bool POOLA = false>
+__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) void gemm_split_kernel(GemmSplitArgs g, int64_t gm, int ny) {
+  gemm_split_body<WN, NP, BM, POOLA>(g, gm, ny, blockIdx.x);
+}
+
+// Up to four INDEPENDENT products in one launch (desco_gemm_bf16x6_multi_f32: the count-row and canonical-row halves of a
+// training layer), 128 x 64 tiles for every problem; workgroups [blk_end[i-1], blk_end[i]) belong to problem i.
+constexpr int kSplitMulti = 4;
+struct GemmSplitMulti {
+  const float* a1[kSplitMulti];
+  const float* a2[kSplitMulti];
+  const short* w[kSplitMulti];
+  const float* bias[kSplitMulti];
+  const float* gate[kSplitMulti];
+  float* c[kSplitMulti];
+  int64_t lda1[kSplitMulti], lda2[kSplitMulti], ldc[kSplitMulti], ldg[kSplitMulti], m[kSplitMulti], gm[kSplitMulti];
+  int k1[kSplitMulti], k2[kSplitMulti], n[kSplitMulti], act[kSplitMulti], gate_act[kSplitMulti], ny[kSplitMulti];
+  float slope[kSplitMulti], gate_slope[kSplitMulti];
+  DropArgs drop[kSplitMulti];
+  int blk_end[kSplitMulti];
+  int num;
+};
+
+template <int NP, int BM>
+__global__ __launch_bounds__(2 * BM) __attribute__((amdgpu_waves_per_eu(2))) void gemm_split_multi_kernel(const GemmSplitMulti q) {
+  int b = blockIdx.x, i = 0;
+  while (i < q.num - 1 && b >= q.blk_end[i]) ++i;
+  b -= i ? q.blk_end[i - 1] : 0;
+  const GemmSplitArgs g{q.a1[i], q.lda1[i], q.k1[i], q.a2[i], q.lda2[i], q.k2[i], q.w[i], q.n[i], q.bias[i], 1, nullptr, 0,
+                        nullptr, q.act[i], q.slope[i], q.c[i], q.ldc[i], q.m[i], nullptr, nullptr, nullptr, {}, nullptr,
+                        q.gate[i], q.ldg[i], q.gate_act[i], q.gate_slope[i], q.drop[i], 1};
+  gemm_split_body<1, NP, BM, false>(g, q.gm[i], q.ny[i], b);
+}
+
 // w[count] -> round-to-nearest-even bf16 bit patterns
 __global__ __launch_bounds__(256) void round_bf16_kernel(const float* __restrict__ w, int64_t count,
                                                          short* __restrict__ out) {
@@ -546,6 +581,94 @@ extern "C" int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ld
   hipLaunchKernelGGL(desco::split_bf16x3_t_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                      k, n, ldw, reinterpret_cast<short*>(planes));
   return desco::launch_status("desco_split_bf16x3_t_f32");
+}
+
+// nb matrices [rows][cols] -> planes [nb][3][..]: transpose == 0: [rows][cols] as they are (n-major planes of a matrix kept
+// as [n, k]); transpose != 0: [cols][rows] (n-major planes of a matrix kept as [k, n]).  One launch for the stacked
+// weights of a training trunk.
+namespace desco {
+__global__ __launch_bounds__(256) void split_bf16x3_batch_kernel(const float* __restrict__ w, int64_t per, int rows,
+                                                                 int cols, int transpose, int64_t total,
+                                                                 short* __restrict__ planes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // output element: matrix b, position o
+  if (i >= total) return;
+  const int64_t b = i / per, o = i % per;
+  int64_t src = o;
+  if (transpose) {
+    const int64_t rr = o / rows, cc = o % rows;                   // output row rr (a source column), column cc
+    src = cc * cols + rr;
+  }
+  const float f = w[b * per + src];
+  const uint32_t uh = __float_as_uint(f) & 0xffff0000u;
+  const float r1 = f - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  short* pb = planes + b * 3 * per;
+  pb[o] = (short)(uh >> 16);
+  pb[per + o] = (short)(um >> 16);
+  pb[2 * per + o] = (short)(__float_as_uint(r2) >> 16);
+}
+}  // namespace desco
+
+extern "C" int desco_split_bf16x3_batch_f32(const float* w, int64_t num, int rows, int cols, int transpose,
+                                            int16_t* planes, desco_stream_t stream) {
+  if (num == 0) return 0;
+  if (!w || !planes || num < 0 || rows <= 0 || cols <= 0)
+    return desco::fail(DESCO_EINVAL, "desco_split_bf16x3_batch_f32: bad argument");
+  const int64_t per = (int64_t)rows * cols, total = per * num;
+  hipLaunchKernelGGL(desco::split_bf16x3_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, per, rows, cols, transpose, total, reinterpret_cast<short*>(planes));
+  return desco::launch_status("desco_split_bf16x3_batch_f32");
+}
+
+extern "C" int desco_gemm_bf16x6_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                                           desco_stream_t stream) {
+  using namespace desco;
+  if (num == 0) return 0;
+  if (num < 0 || num > kSplitMulti || !descs || !planes)
+    return fail(DESCO_EINVAL, "desco_gemm_bf16x6_multi_f32: 1..4 descriptors");
+  auto mis16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  GemmSplitMulti q{};
+  int nq = 0, blocks = 0;
+  for (int i = 0; i < num; ++i) {
+    const desco_gemm_desc& d = descs[i];
+    if (d.m == 0) continue;
+    if (d.m < 0 || !d.a1 || !planes[i] || !d.c || d.k1 <= 0 || d.k1 % SBK || d.k2 < 0 || d.k2 % SBK || d.n <= 0 ||
+        d.n % 64 || (d.k2 > 0 && !d.a2) || d.ns != 0 || d.accum || (d.bias && d.bias_rows != 1) || d.lda1 % 4 ||
+        (d.k2 > 0 && d.lda2 % 4) || mis16(d.a1) || (d.k2 > 0 && mis16(d.a2)) || mis16(planes[i]) ||
+        (d.gate && d.ldg < d.n))
+      return fail(DESCO_EINVAL, "desco_gemm_bf16x6_multi_f32: bad descriptor (k%32, n%64, 16-byte alignment, no scalar "
+                                "tail / accum / per-row bias)");
+    const int64_t gm = (d.m + 127) / 128;
+    const int ny = d.n / 64;
+    const int64_t nb = ((gm + 7) / 8) * 8 * ny;
+    if (nb + blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_gemm_bf16x6_multi_f32: m too large");
+    q.a1[nq] = d.a1; q.a2[nq] = d.a2; q.w[nq] = reinterpret_cast<const short*>(planes[i]); q.bias[nq] = d.bias;
+    q.gate[nq] = d.gate; q.c[nq] = d.c;
+    q.lda1[nq] = d.lda1; q.lda2[nq] = d.lda2; q.ldc[nq] = d.ldc; q.ldg[nq] = d.ldg; q.m[nq] = d.m; q.gm[nq] = gm;
+    q.k1[nq] = d.k1; q.k2[nq] = d.k2; q.n[nq] = d.n; q.act[nq] = d.act; q.gate_act[nq] = d.gate_act; q.ny[nq] = ny;
+    q.slope[nq] = d.slope; q.gate_slope[nq] = d.gate_slope;
+    q.drop[nq] = DropArgs{d.drop.key, d.drop.site, d.drop.threshold, d.drop.scale};
+    blocks += (int)nb;
+    q.blk_end[nq] = blocks;
+    ++nq;
+  }
+  if (nq == 0) return 0;
+  q.num = nq;
+  constexpr int BM = 128, NP = 3, BN = 64;
+  constexpr size_t stage_bytes = (size_t)(NP * BM * SST + NP * BN * SST) * sizeof(short);
+  constexpr size_t epi_bytes = (size_t)(BM / 32) * 32 * 32 * sizeof(float);
+  constexpr size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+  static DeviceOnce attr_once;
+  if (!attr_once.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_multi_kernel<NP, BM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_multi_f32: cannot size LDS");
+    attr_once.mark();
+  }
+  hipLaunchKernelGGL((gemm_split_multi_kernel<NP, BM>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
+                     (hipStream_t)stream, q);
+  return launch_status("desco_gemm_bf16x6_multi_f32");
 }
 
 // post_mp.0 on the pooled embeddings WITHOUT materialising them (round 6): pooled[b] = anchor row + the fused pooling's

@@ -326,6 +326,59 @@ def gemm_split_desc(pr: dict, planes: torch.Tensor) -> None:
                                                          _stream()), "gemm_split_desc")
 
 
+def split_bf16_planes_batch(w: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """[nb, 3, rows, cols] (or, ``transpose``, [nb, 3, cols, rows]) int16 planes of the nb contiguous matrices
+    w[nb, rows, cols] in one launch (desco_split_bf16x3_batch_f32): a training trunk's stacked weights."""
+    nb, rows, cols = w.shape
+    w = w.contiguous()
+    planes = torch.empty((nb, 3, cols, rows) if transpose else (nb, 3, rows, cols), device=w.device, dtype=torch.int16)
+    _lib.check(_lib.lib().desco_split_bf16x3_batch_f32(_dev(w, "w"), nb, rows, cols, int(bool(transpose)),
+                                                       _dev(planes, "planes", torch.int16), _stream()), "split_bf16x3_batch")
+    return planes
+
+
+def gemm_split_multi(problems, planes) -> None:
+    """Up to four independent ``gemm_split_desc`` problems (no scalar tail) in one launch (desco_gemm_bf16x6_multi_f32);
+    ``planes[i]`` [3, n_i, k_i] = problem i's n-major split weight."""
+    assert len(problems) == len(planes) <= 4
+    descs = (_lib.GemmDesc * len(problems))()
+    pl = (ctypes.c_void_p * len(problems))()
+    flops = nbytes = 0.0
+    for i, (d, pr, w) in enumerate(zip(descs, problems, planes)):
+        a1, out, a2, bias = pr["a1"], pr["out"], pr.get("a2"), pr.get("bias")
+        m, k1 = a1.shape
+        k2 = 0 if a2 is None else a2.shape[1]
+        n = w.shape[1]
+        assert tuple(w.shape) == (3, n, k1 + k2) and w.is_contiguous() and tuple(out.shape) == (m, n)
+        assert not pr.get("accum", False) and pr.get("s") is None
+        d.m = m
+        if m == 0:
+            continue
+        pl[i] = _dev(w, "planes", torch.int16)
+        d.a1, d.lda1 = _rows(a1, "a1")
+        d.k1, d.k2 = k1, k2
+        if a2 is not None:
+            d.a2, d.lda2 = _rows(a2, "a2")
+        d.n = n
+        if bias is not None:
+            assert bias.is_contiguous() and bias.dim() == 1
+            d.bias, d.bias_rows = _dev(bias, "bias"), 1
+        d.act, d.slope = pr.get("act", ACT_NONE), pr.get("slope", 0.0)
+        d.c, d.ldc = _rows(out, "out")
+        gate = pr.get("gate")
+        if gate is not None:
+            assert tuple(gate.shape) == (m, n)
+            d.gate, d.ldg = _rows(gate, "gate")
+            d.gate_act, d.gate_slope = pr["gate_act"], pr.get("gate_slope", 0.0)
+        drop = pr.get("drop")
+        if drop is not None:
+            d.drop = drop.desc()
+        flops += 2.0 * m * (k1 + k2) * n
+        nbytes += 4.0 * (m * (k1 + k2) + m * n)
+    with _Timed("gemm_split_multi_kernel", flops, nbytes):
+        _lib.check(_lib.lib().desco_gemm_bf16x6_multi_f32(len(problems), descs, pl, _stream()), "gemm_split_multi")
+
+
 def linear_bwd_w_multi(problems) -> None:
     """Up to 16 independent ``linear_bwd_w`` problems in two launches (desco_linear_bwd_w_multi_f32).  ``problems``:
     dicts a1, a2 (or None), dz, dwt (contiguous [(k1+k2), n]), dbias ([n] or None)."""

@@ -236,6 +236,15 @@ int desco_gemm_bf16x6_desc_f32(const desco_gemm_desc* d, const int16_t* w_planes
 /* planes[3][n][k] of the TRANSPOSE of w [k, n] (row stride ldw >= n): the n-major planes of a weight kept as [in, out], or
  * -- for an input-gradient product dA = dZ W -- of torch's [out, in] weight read as [k = out, n = in]. */
 int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ldw, int16_t* planes, desco_stream_t stream);
+/* Up to four INDEPENDENT descriptors on the bf16x6 pipe in one launch (planes[i] = the n-major planes of descriptor i;
+ * 128 x 64 tiles for every problem): the count-row and canonical-row halves of a training layer's forward and
+ * input-gradient products.  As desco_gemm_bf16x6_desc_f32 without the scalar tail (ns must be 0). */
+int desco_gemm_bf16x6_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                                desco_stream_t stream);
+/* planes[num][3][..] of num contiguous matrices w[num][rows][cols]: as they are ([rows][cols]) or, transpose != 0, of their
+ * transposes ([cols][rows]) -- a training trunk's stacked weights, all layers in one launch. */
+int desco_split_bf16x3_batch_f32(const float* w, int64_t num, int rows, int cols, int transpose, int16_t* planes,
+                                 desco_stream_t stream);
 
 /* Same contract as desco_gemm_f32 on the fp16 matrix pipe with fp32-level accuracy in THREE products ("f16x3",
  * csrc/gemm_f16x3.hip): operands are scaled by powers of two and split into two fp16 terms (hi = rne(s x),
