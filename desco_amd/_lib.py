@@ -93,7 +93,8 @@ SIGNATURES = {
     "desco_gemm_bf16x6_desc_f32": (c_int, [POINTER(GemmDesc), vp, i32, vp]),
     "desco_split_bf16x3_t_f32": (c_int, [vp, i32, i32, i64, vp, vp]),
     "desco_gemm_bf16x6_multi_f32": (c_int, [i32, POINTER(GemmDesc), POINTER(vp), vp]),
-    "desco_split_bf16x3_batch_f32": (c_int, [vp, i64, i32, i32, i32, vp, vp]),
+    "desco_split_bf16x3_batch_f32": (c_int, [vp, i64, i32, i32, i32, i32, vp, vp]),
+    "desco_gemm_bf16_multi_f32": (c_int, [i32, POINTER(GemmDesc), POINTER(vp), vp]),
     "desco_pool_reduce_multi_f32": (c_int, [i32, POINTER(vp), vp, vp, vp, i64, POINTER(vp), i64, POINTER(vp), i64, i32, vp]),
     "desco_shmp_layer_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, vp, i64, vp]),
     "desco_shmp_layer_pool_f16x3_f32": (c_int, [vp, i64, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),

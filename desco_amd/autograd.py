@@ -106,9 +106,8 @@ class Linear(torch.autograd.Function):
         return da1, da2, dwt, dbias, None, None
 
 
-# (fp32 precision runs on v_mfma_f32_32x32x2_f32: the six-product bf16 form of gemm_split.hip was measured on the
-#  real-size training batches -- 54 k rows, N = 64 / 320 -- at 35 us per launch against 26 us, 7.02 vs 6.58 ms per
-#  replayed step, and pushes one gradient tensor to 2e-3 of the oracle's: not used here)
+# (the remaining fp32 products -- anchor, post_mp, head: 512-row operands -- run on v_mfma_f32_32x32x2_f32; the layers'
+#  products went to the bf16x6 pipe in round 6: TRAIN_GEMM_BF16X6 above)
 def _mm_fwd(a1, a2, wt, bias, act, slope, out=None):
     """act([a1 | a2] @ wt + bias) in the training precision (see Linear)."""
     if PRECISION == "bf16" and wt.shape[1] % 64 == 0 and wt.shape[0] % 64 == 0:
@@ -159,8 +158,11 @@ class ShmpTrunk(torch.autograd.Function):
         xall = torch.empty((num_layers, N, H), device=dev)        # X_1 .. X_L in one buffer (pooled in one launch)
         # fp32 mode: the layers' products on the bf16x6 pipe (fp32-accurate; 38 -> 26 us per product on a real-size
         # batch): the stacked weights' n-major planes for all layers in one launch per row type
-        x6 = TRAIN_GEMM_BF16X6 and PRECISION == "fp32" and len(groups) > 1
-        planes_f = [ops.split_bf16_planes_batch(w_, True) for w_ in Wt] if x6 else None      # [L, 3, 64, K_g]
+        # (bf16 mode: the same launches with ONE rounded plane per weight and A rounded in the kernel; a dropout step's
+        #  products are fp32-accurate in either mode)
+        x6 = TRAIN_GEMM_BF16X6 and len(groups) > 1
+        npl = 3 if (PRECISION == "fp32" or drop is not None) else 1
+        planes_f = [ops.split_bf16_planes_batch(w_, True, npl) for w_ in Wt] if x6 else None      # [L, P, 64, K_g]
         for l in range(num_layers):
             agg = ops.csr_gather_sum(X[-1], batch.vrowptr, batch.vcol, N, S)          # [N, S*64]
             xn = xall[l]
@@ -193,7 +195,7 @@ class ShmpTrunk(torch.autograd.Function):
         ctx.batch, ctx.groups, ctx.has_anchor = batch, groups, has_anchor
         ctx.mask_scale = 1.0 if drop is None else ops.DropSite(drop[0], 0, drop[1]).scale
         ctx.X, ctx.AGG, ctx.canon, ctx.anch = X, AGG, canon, anch
-        ctx.x6 = x6
+        ctx.x6, ctx.npl = x6, npl
         ctx.save_for_backward(*w)
         return pooled
 
@@ -253,7 +255,7 @@ class ShmpTrunk(torch.autograd.Function):
         WtT = planes_b = None
         if ctx.x6:
             # dA = dZ Wt^T on the bf16x6 pipe: its n-major operand [n = in][k = out] is Wt as stored -- no transposes
-            planes_b = [ops.split_bf16_planes_batch(w_, False) for w_ in Wt]                 # [L, 3, K_g, 64]
+            planes_b = [ops.split_bf16_planes_batch(w_, False, ctx.npl) for w_ in Wt]        # [L, P, K_g, 64]
         elif fp32:
             WtT = [torch.empty((L, w_.shape[2], w_.shape[1]), device=dev) for w_ in Wt]
             ops.copy2d_multi([(w_[l], t_[l], True) for w_, t_ in zip(Wt, WtT) for l in range(L)])

@@ -588,7 +588,7 @@ extern "C" int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ld
 // weights of a training trunk.
 namespace desco {
 __global__ __launch_bounds__(256) void split_bf16x3_batch_kernel(const float* __restrict__ w, int64_t per, int rows,
-                                                                 int cols, int transpose, int64_t total,
+                                                                 int cols, int transpose, int64_t total, int np,
                                                                  short* __restrict__ planes) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // output element: matrix b, position o
   if (i >= total) return;
@@ -599,6 +599,10 @@ __global__ __launch_bounds__(256) void split_bf16x3_batch_kernel(const float* __
     src = cc * cols + rr;
   }
   const float f = w[b * per + src];
+  if (np == 1) {           // (the bf16 training mode's operand: one plane, round to nearest even)
+    planes[b * per + o] = (short)(pack2_bf16_rne(f, 0.f) & 0xffffu);
+    return;
+  }
   const uint32_t uh = __float_as_uint(f) & 0xffff0000u;
   const float r1 = f - __uint_as_float(uh);
   const uint32_t um = __float_as_uint(r1) & 0xffff0000u;
@@ -611,18 +615,31 @@ __global__ __launch_bounds__(256) void split_bf16x3_batch_kernel(const float* __
 }  // namespace desco
 
 extern "C" int desco_split_bf16x3_batch_f32(const float* w, int64_t num, int rows, int cols, int transpose,
-                                            int16_t* planes, desco_stream_t stream) {
+                                            int num_planes, int16_t* planes, desco_stream_t stream) {
   if (num == 0) return 0;
-  if (!w || !planes || num < 0 || rows <= 0 || cols <= 0)
-    return desco::fail(DESCO_EINVAL, "desco_split_bf16x3_batch_f32: bad argument");
+  if (!w || !planes || num < 0 || rows <= 0 || cols <= 0 || (num_planes != 3 && num_planes != 1))
+    return desco::fail(DESCO_EINVAL, "desco_split_bf16x3_batch_f32: bad argument (num_planes 3 or 1)");
   const int64_t per = (int64_t)rows * cols, total = per * num;
   hipLaunchKernelGGL(desco::split_bf16x3_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, per, rows, cols, transpose, total, reinterpret_cast<short*>(planes));
+                     (hipStream_t)stream, w, per, rows, cols, transpose, total, num_planes,
+                     reinterpret_cast<short*>(planes));
   return desco::launch_status("desco_split_bf16x3_batch_f32");
 }
 
+static int gemm_planes_multi(int np, int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                             desco_stream_t stream);
 extern "C" int desco_gemm_bf16x6_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
                                            desco_stream_t stream) {
+  return gemm_planes_multi(3, num, descs, planes, stream);
+}
+// ... and with ONE plane per weight (round-to-nearest bf16, desco_split_bf16x3_batch_f32 with num_planes = 1) and A rounded
+// in the kernel: the bf16 training mode's products (desco_gemm_bf16_f32's arithmetic), several problems per launch
+extern "C" int desco_gemm_bf16_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                                         desco_stream_t stream) {
+  return gemm_planes_multi(1, num, descs, planes, stream);
+}
+static int gemm_planes_multi(int np, int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                             desco_stream_t stream) {
   using namespace desco;
   if (num == 0) return 0;
   if (num < 0 || num > kSplitMulti || !descs || !planes)
@@ -655,19 +672,26 @@ extern "C" int desco_gemm_bf16x6_multi_f32(int num, const desco_gemm_desc* descs
   }
   if (nq == 0) return 0;
   q.num = nq;
-  constexpr int BM = 128, NP = 3, BN = 64;
-  constexpr size_t stage_bytes = (size_t)(NP * BM * SST + NP * BN * SST) * sizeof(short);
+  constexpr int BM = 128, BN = 64;
+  constexpr size_t stage_bytes = (size_t)(3 * BM * SST + 3 * BN * SST) * sizeof(short);      // (sized for three planes)
   constexpr size_t epi_bytes = (size_t)(BM / 32) * 32 * 32 * sizeof(float);
   constexpr size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   static DeviceOnce attr_once;
   if (!attr_once.done()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_multi_kernel<NP, BM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_multi_kernel<3, BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_multi_kernel<1, BM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return fail((int)e, "desco_gemm_bf16x6_multi_f32: cannot size LDS");
     attr_once.mark();
   }
-  hipLaunchKernelGGL((gemm_split_multi_kernel<NP, BM>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
-                     (hipStream_t)stream, q);
+  if (np == 3)
+    hipLaunchKernelGGL((gemm_split_multi_kernel<3, BM>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
+                       (hipStream_t)stream, q);
+  else
+    hipLaunchKernelGGL((gemm_split_multi_kernel<1, BM>), dim3((unsigned)blocks), dim3(2 * BM), lds_bytes,
+                       (hipStream_t)stream, q);
   return launch_status("desco_gemm_bf16x6_multi_f32");
 }
 

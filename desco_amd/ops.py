@@ -326,21 +326,26 @@ def gemm_split_desc(pr: dict, planes: torch.Tensor) -> None:
                                                          _stream()), "gemm_split_desc")
 
 
-def split_bf16_planes_batch(w: torch.Tensor, transpose: bool) -> torch.Tensor:
-    """[nb, 3, rows, cols] (or, ``transpose``, [nb, 3, cols, rows]) int16 planes of the nb contiguous matrices
-    w[nb, rows, cols] in one launch (desco_split_bf16x3_batch_f32): a training trunk's stacked weights."""
+def split_bf16_planes_batch(w: torch.Tensor, transpose: bool, num_planes: int = 3) -> torch.Tensor:
+    """[nb, P, rows, cols] (or, ``transpose``, [nb, P, cols, rows]) int16 planes of the nb contiguous matrices
+    w[nb, rows, cols] in one launch (desco_split_bf16x3_batch_f32): a training trunk's stacked weights.  P = 3: the
+    bf16x6 truncation split; P = 1: round-to-nearest bf16 (the bf16 training mode)."""
     nb, rows, cols = w.shape
     w = w.contiguous()
-    planes = torch.empty((nb, 3, cols, rows) if transpose else (nb, 3, rows, cols), device=w.device, dtype=torch.int16)
-    _lib.check(_lib.lib().desco_split_bf16x3_batch_f32(_dev(w, "w"), nb, rows, cols, int(bool(transpose)),
+    planes = torch.empty((nb, num_planes, cols, rows) if transpose else (nb, num_planes, rows, cols), device=w.device,
+                         dtype=torch.int16)
+    _lib.check(_lib.lib().desco_split_bf16x3_batch_f32(_dev(w, "w"), nb, rows, cols, int(bool(transpose)), num_planes,
                                                        _dev(planes, "planes", torch.int16), _stream()), "split_bf16x3_batch")
     return planes
 
 
 def gemm_split_multi(problems, planes) -> None:
     """Up to four independent ``gemm_split_desc`` problems (no scalar tail) in one launch (desco_gemm_bf16x6_multi_f32);
-    ``planes[i]`` [3, n_i, k_i] = problem i's n-major split weight."""
+    ``planes[i]`` [3, n_i, k_i] = problem i's n-major split weight -- or [1, n_i, k_i] for all of them: plain bf16
+    products (desco_gemm_bf16_multi_f32, the bf16 training mode)."""
     assert len(problems) == len(planes) <= 4
+    npl = planes[0].shape[0]
+    assert npl in (1, 3)
     descs = (_lib.GemmDesc * len(problems))()
     pl = (ctypes.c_void_p * len(problems))()
     flops = nbytes = 0.0
@@ -349,7 +354,7 @@ def gemm_split_multi(problems, planes) -> None:
         m, k1 = a1.shape
         k2 = 0 if a2 is None else a2.shape[1]
         n = w.shape[1]
-        assert tuple(w.shape) == (3, n, k1 + k2) and w.is_contiguous() and tuple(out.shape) == (m, n)
+        assert w.shape[0] == npl and tuple(w.shape[1:]) == (n, k1 + k2) and w.is_contiguous() and tuple(out.shape) == (m, n)
         assert not pr.get("accum", False) and pr.get("s") is None
         d.m = m
         if m == 0:
@@ -376,7 +381,8 @@ def gemm_split_multi(problems, planes) -> None:
         flops += 2.0 * m * (k1 + k2) * n
         nbytes += 4.0 * (m * (k1 + k2) + m * n)
     with _Timed("gemm_split_multi_kernel", flops, nbytes):
-        _lib.check(_lib.lib().desco_gemm_bf16x6_multi_f32(len(problems), descs, pl, _stream()), "gemm_split_multi")
+        fn = _lib.lib().desco_gemm_bf16x6_multi_f32 if npl == 3 else _lib.lib().desco_gemm_bf16_multi_f32
+        _lib.check(fn(len(problems), descs, pl, _stream()), "gemm_split_multi")
 
 
 def linear_bwd_w_multi(problems) -> None:

@@ -241,10 +241,15 @@ int desco_split_bf16x3_t_f32(const float* w, int k, int n, int64_t ldw, int16_t*
  * input-gradient products.  As desco_gemm_bf16x6_desc_f32 without the scalar tail (ns must be 0). */
 int desco_gemm_bf16x6_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
                                 desco_stream_t stream);
-/* planes[num][3][..] of num contiguous matrices w[num][rows][cols]: as they are ([rows][cols]) or, transpose != 0, of their
- * transposes ([cols][rows]) -- a training trunk's stacked weights, all layers in one launch. */
-int desco_split_bf16x3_batch_f32(const float* w, int64_t num, int rows, int cols, int transpose, int16_t* planes,
-                                 desco_stream_t stream);
+/* The same launch with ONE plane per weight (round-to-nearest bf16) and A rounded in the kernel: desco_gemm_bf16_f32's
+ * arithmetic (the bf16 training mode, BASELINE config 3), several problems per launch. */
+int desco_gemm_bf16_multi_f32(int num, const desco_gemm_desc* descs, const int16_t* const* planes,
+                              desco_stream_t stream);
+/* planes[num][num_planes][..] of num contiguous matrices w[num][rows][cols]: as they are ([rows][cols]) or, transpose != 0,
+ * of their transposes ([cols][rows]) -- a training trunk's stacked weights, all layers in one launch.  num_planes = 3: the
+ * truncation split of desco_split_bf16x3_f32; 1: round-to-nearest bf16 (desco_round_bf16_f32). */
+int desco_split_bf16x3_batch_f32(const float* w, int64_t num, int rows, int cols, int transpose, int num_planes,
+                                 int16_t* planes, desco_stream_t stream);
 
 /* Same contract as desco_gemm_f32 on the fp16 matrix pipe with fp32-level accuracy in THREE products ("f16x3",
  * csrc/gemm_f16x3.hip): operands are scaled by powers of two and split into two fp16 terms (hi = rne(s x),
