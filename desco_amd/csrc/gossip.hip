@@ -111,17 +111,37 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restric
                                                           const float* __restrict__ V, int QV,
                                                           int act, float slope, DropArgs drop,
                                                           float* __restrict__ out, int64_t R) {
+  // a wave takes FOUR consecutive rows per step (aligned to 4: one Philox call gives the four rows' dropout bits of a
+  // column) and walks the rows with a grid stride -- round 6: one wave per row was a million waves of one 256-byte
+  // store each, and a Philox call per element
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
-  if (r >= R) return;
-  const float* v = V + (int64_t)(r % QV) * KS * 64 + lane;
-  float acc = base ? base[r * 64 + lane] : 0.f;
-  for (int k = 0; k < KS; ++k) acc += C[r * KS + k] * v[k * 64];
-  acc = apply_act(acc, act, slope);
-  // dropout behind the activation (gnn_model.py:273-274; post_mp.1 in front of its LeakyReLU is the same thing: relu
-  // and leaky commute with a non-negative factor); the factor is regenerated in the backward pass, not stored
-  if (drop.key) acc *= dropout_factor(drop, drop.key[0], drop.key[1], r, lane);
-  out[r * 64 + lane] = acc;
+  const int64_t ngroups = (R + 3) / 4;
+  for (int64_t gq = (int64_t)blockIdx.x * 4 + wave; gq < ngroups; gq += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = 4 * gq;
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t r = r0 + e < R ? r0 + e : R - 1;
+      acc[e] = base ? base[r * 64 + lane] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t r = r0 + e < R ? r0 + e : R - 1;
+      const float* v = V + (int64_t)(r % QV) * KS * 64 + lane;
+      for (int k = 0; k < KS; ++k) acc[e] += C[r * KS + k] * v[k * 64];
+      acc[e] = apply_act(acc[e], act, slope);
+    }
+    // dropout behind the activation (gnn_model.py:273-274; post_mp.1 in front of its LeakyReLU is the same thing: relu
+    // and leaky commute with a non-negative factor); the factor is regenerated in the backward pass, not stored
+    if (drop.key) {
+      const PhiloxOut o = dropout_bits4(drop, drop.key[0], drop.key[1], (uint32_t)gq, (uint32_t)lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] *= o.w[e] < drop.threshold ? 0.f : drop.scale;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (r0 + e < R) out[(r0 + e) * 64 + lane] = acc[e];
+  }
 }
 
 // partial[slab][qv][k][c] = sum over rows r = i*QV + qv of the slab of C[r,k] * dZ[r,c]
@@ -137,12 +157,28 @@ __global__ __launch_bounds__(256) void affine_rows_bwd_kernel(const float* __res
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  for (int64_t i = i_beg + wave; i < i_end; i += 4) {
-    const int64_t r = i * QV + qv;
-    const float d = dZ[r * 64 + lane];
+  // eight rows of the class in flight per wave (round 6: one row per iteration was one memory round trip per
+  // iteration -- 0.25 ms per call for 0.26 GB); rows beyond the slab re-read its last row with weight 0
+  for (int64_t i = i_beg + wave; i < i_end; i += 32) {
+    float d[8], cw[8];
+    int64_t r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < KS) acc[k] += C[r * KS + k] * d;
+    for (int u = 0; u < 8; ++u) {
+      const int64_t iu = i + 4 * u;
+      cw[u] = iu < i_end ? 1.f : 0.f;
+      r[u] = (iu < i_end ? iu : i_end - 1) * QV + qv;
+      d[u] = dZ[r[u] * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < KS) {
+        float c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = C[r[u] * KS + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[k] = fmaf(c[u] * cw[u], d[u], acc[k]);
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[wave][k][lane] = acc[k];
@@ -224,8 +260,8 @@ static int affine_rows_launch(const char* who, const float* base, const float* c
     std::string msg = std::string(who) + ": bad argument (1 <= ks <= 8)";
     return fail(DESCO_EINVAL, msg.c_str());
   }
-  const int64_t blocks = (num_rows + 3) / 4;
-  if (blocks > INT32_MAX) return fail(DESCO_EINVAL, "desco_affine_rows_f32: too many rows");
+  int64_t blocks = ((num_rows + 3) / 4 + 3) / 4;            // a wave per group of four rows ...
+  if (blocks > 16 * 1024) blocks = 16 * 1024;                // ... and a grid-stride walk beyond 64 k waves
   DropArgs da = DropArgs{nullptr, 0u, 0u, 1.f};
   if (d) {
     if (const char* why = dropout_check(d, num_rows, 64)) return fail(DESCO_EINVAL, why);
