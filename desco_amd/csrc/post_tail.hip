@@ -37,7 +37,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int D1 = 64, D2 = 256, D3 = 64;     // output widths of the three layers (input 64)
 constexpr int ST64 = 72, ST256 = 264;         // LDS row strides in halves: 16-byte reads of 32 rows conflict-free
 constexpr int W1_H = 2 * D1 * ST64, W2_H = 2 * D2 * ST64, W3_H = 2 * D3 * ST256;
-constexpr int NWT = 8;
+constexpr int NWT = 8;                        // waves per workgroup: the count head (224 registers) ...
+#ifndef DESCO_TAIL_WAVES
+#define DESCO_TAIL_WAVES 12
+#endif
+constexpr int TNW = DESCO_TAIL_WAVES;         // ... and the post_mp tail (162 registers: three waves per SIMD)
 constexpr size_t TAIL_LDS = (size_t)(W1_H + W2_H + W3_H) * 2 + (size_t)(D1 + D2 + D3) * 4;
 static_assert(TAIL_LDS <= 160 * 1024, "post_mp tail: LDS budget exceeded");
 
@@ -65,11 +69,11 @@ __device__ __forceinline__ f16x8 frag_of(const uint32_t a, const uint32_t b, con
 
 // fill one weight image: [2 planes][rows][K] halves -> LDS rows of `stride` halves; `swap` = the 4-half chunks of each
 // 16-k group stored in the order 0, 2, 1, 3 (bits 2 and 3 of k exchanged)
-template <int K, bool SWAP>
+template <int K, bool SWAP, int NT = NWT * 64>
 __device__ __forceinline__ void fill_image(short* dst, const short* __restrict__ src, const int rows2, const int stride,
                                            const int tid) {
   constexpr int CH = K / 4;
-  for (int i = tid; i < rows2 * CH; i += NWT * 64) {
+  for (int i = tid; i < rows2 * CH; i += NT) {
     const int row = i / CH, c = i % CH;
     const int cd = SWAP ? ((c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1)) : c;
     *reinterpret_cast<uint2*>(dst + row * stride + 4 * cd) = *reinterpret_cast<const uint2*>(src + (int64_t)row * K + 4 * c);
@@ -81,7 +85,7 @@ __device__ __forceinline__ void fill_image(short* dst, const short* __restrict__
   acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_, bl_, acc_, 0, 0, 0);          \
   acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_, bh_, acc_, 0, 0, 0);
 
-__global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
+__global__ __launch_bounds__(TNW * 64) void post_tail_kernel(TailArgs g) {
   extern __shared__ __attribute__((aligned(16))) short lds_h[];
   short* W1 = lds_h;
   short* W2 = W1 + W1_H;
@@ -90,10 +94,10 @@ __global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
   float* B2 = B1 + D1;
   float* B3 = B2 + D2;
   const int tid = (int)__builtin_amdgcn_workitem_id_x(), lane = tid & 63, wave = tid >> 6;
-  fill_image<64, false>(W1, g.w1, 2 * D1, ST64, tid);
-  fill_image<64, true>(W2, g.w2, 2 * D2, ST64, tid);
-  fill_image<256, true>(W3, g.w3, 2 * D3, ST256, tid);
-  for (int i = tid; i < D1 + D2 + D3; i += NWT * 64) {
+  fill_image<64, false, TNW * 64>(W1, g.w1, 2 * D1, ST64, tid);
+  fill_image<64, true, TNW * 64>(W2, g.w2, 2 * D2, ST64, tid);
+  fill_image<256, true, TNW * 64>(W3, g.w3, 2 * D3, ST256, tid);
+  for (int i = tid; i < D1 + D2 + D3; i += TNW * 64) {
     const float* b = i < D1 ? g.b1 : (i < D1 + D2 ? g.b2 : g.b3);
     const int j = i < D1 ? i : (i < D1 + D2 ? i - D1 : i - D1 - D2);
     B1[i] = b ? b[j] : 0.f;
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(NWT * 64) void post_tail_kernel(TailArgs g) {
   __syncthreads();
   const int n = lane & 31, h = lane >> 5;
   const int64_t ntiles = (g.m + 31) / 32;
-  int64_t tile = (int64_t)(int)__builtin_amdgcn_workgroup_id_x() * NWT + wave;
+  int64_t tile = (int64_t)(int)__builtin_amdgcn_workgroup_id_x() * TNW + wave;
   if (tile >= ntiles) return;
-  const int64_t tstep = (int64_t)g.grid * NWT;
+  const int64_t tstep = (int64_t)g.grid * TNW;
   // K step s of the first product: the lane supplies k = 16 s + 8 h + 0..7 of its row (the MFMA's own order)
   float4 xv[8];
 #define DESCO_TAIL_LOAD(t_)                                                     \
@@ -531,7 +535,7 @@ extern "C" int desco_post_mp_tail_f16x3_f32(const float* x, int64_t ldx, int64_t
     attr_once.mark();
   }
   const int64_t tiles = (m + 31) / 32;
-  const int64_t want = (tiles + tail::NWT - 1) / tail::NWT;
+  const int64_t want = (tiles + tail::TNW - 1) / tail::TNW;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -539,7 +543,7 @@ extern "C" int desco_post_mp_tail_f16x3_f32(const float* x, int64_t ldx, int64_t
   }
   const unsigned grid = (unsigned)(want < cus ? want : cus);
   g.grid = grid;
-  hipLaunchKernelGGL(tail::post_tail_kernel, dim3(grid), dim3(tail::NWT * 64), tail::TAIL_LDS, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(tail::post_tail_kernel, dim3(grid), dim3(tail::TNW * 64), tail::TAIL_LDS, (hipStream_t)stream, g);
   return launch_status("desco_post_mp_tail_f16x3_f32");
 }
 
