@@ -345,11 +345,21 @@ __device__ __forceinline__ float raw_max(const float a, const float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-constexpr int HSTEPS = HQ * 4, HRING = 4;
+#ifndef DESCO_HEAD_RING
+#define DESCO_HEAD_RING 4      // (6 and 8 measured 3-5 % slower: more registers, nothing left to cover)
+#endif
+constexpr int HSTEPS = HQ * 4, HRING = DESCO_HEAD_RING;
 template <int I>
 __device__ __forceinline__ void head_request(desco_f4& slot, const uint32_t qaddr) {
   constexpr int off = (I % HQ) * (HHID * 4) + (I / HQ) * 16;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(slot) : "v"(qaddr), "n"(off));
+}
+template <int I>
+__device__ __forceinline__ void head_prime(desco_f4 (&ring)[HRING], const uint32_t qaddr) {
+  if constexpr (I < HRING) {
+    head_request<I>(ring[I], qaddr);
+    head_prime<I + 1>(ring, qaddr);
+  }
 }
 template <int I>
 __device__ __forceinline__ void head_steps(desco_f4 (&ring)[HRING], const uint32_t qaddr, const desco_f2 (&t2)[8],
@@ -479,10 +489,7 @@ __global__ __launch_bounds__(NWT * 64) void count_head_emb_kernel(HeadArgs g) {
       }
       const uint32_t qaddr = qbase + (uint32_t)(32 * 4) * (uint32_t)c;
       desco_f4 ring[HRING];
-      head_request<0>(ring[0], qaddr);
-      head_request<1>(ring[1], qaddr);
-      head_request<2>(ring[2], qaddr);
-      head_request<3>(ring[3], qaddr);
+      head_prime<0>(ring, qaddr);
       head_steps<0>(ring, qaddr, t2, r2, acc);
     }
     // both halves' partial sums; lanes of half 0 store queries 0..14, half 1 queries 15..28 (and 14 again)
